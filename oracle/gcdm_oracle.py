@@ -1,0 +1,423 @@
+"""CPU oracle for the GCDM denoising inner loop -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+
+A plain PyTorch (CPU, fp32 or fp64) restatement of the reference algorithm for the one hot path this
+repository accelerates: ``GCPNetDynamics.forward`` evaluated at each DDPM step of
+``EquivariantVariationalDiffusion.mol_gen_sample``.  It follows the reference's own formulation (explicit
+edge lists, gather / index_add) so that it can be compared with the reference function by function, and
+it consumes a ``state_dict`` with the *reference's* parameter names.
+
+Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may import this file,
+and only as the checker / reported baseline.  The product package (``bio-diffusion_amd``) never imports it.
+
+Parity pin: the reference has no numeric tests for this path, so this oracle is
+pinned against golden vectors produced by importing the reference itself in the build container
+(``tests/golden/make_golden.py`` -> ``tests/golden/*.npz``; checked by ``tests/test_oracle_golden.py``)
+and, when ``/root/reference`` is present, directly against the imported reference
+(``tests/test_oracle_vs_reference.py``).
+
+All "file:line" citations are relative to the reference checkout (``/root/reference``).
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass, field
+from typing import Callable, Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+Tensor = torch.Tensor
+Params = Dict[str, Tensor]
+
+
+# ------------------------------------------------------------------------------------------------
+# configuration
+# ------------------------------------------------------------------------------------------------
+@dataclass
+class OracleConfig:
+    """The handful of hyper-parameters the hot path depends on (production values as defaults).
+
+    Sources: configs/model/module_cfg/*_gcp_module.yaml, configs/model/diffusion_cfg/*.yaml,
+    configs/datamodule/dataloader_cfg/edm_*_dataloader.yaml.
+    """
+
+    num_atom_types: int = 5
+    include_charges: bool = True
+    num_context: int = 0                 # len(module_cfg.conditioning)
+    num_layers: int = 9                  # model_cfg.num_encoder_layers
+    bottleneck: int = 4                  # module_cfg.bottleneck == default_bottleneck
+    num_message_layers: int = 4          # layer_cfg.mp_cfg.num_message_layers
+    node_positions_weight: float = 1.0
+    condition_on_time: bool = True
+    num_timesteps: int = 1000
+    noise_schedule: str = "polynomial_2"
+    noise_precision: float = 1e-5
+    norm_values: Sequence[float] = (1.0, 4.0, 10.0)
+    norm_biases: Sequence[Optional[float]] = (None, 0.0, 0.0)
+
+    @property
+    def num_node_scalar_features(self) -> int:
+        return self.num_atom_types + int(self.include_charges)
+
+
+# ------------------------------------------------------------------------------------------------
+# graph + geometry helpers
+# ------------------------------------------------------------------------------------------------
+def num_nodes_to_batch_index(num_nodes: Tensor) -> Tensor:
+    """src/models/components/__init__.py:314-321."""
+    return torch.repeat_interleave(torch.arange(len(num_nodes)), num_nodes)
+
+
+def fully_connected_edges(batch_index: Tensor, mask: Optional[Tensor] = None) -> Tuple[Tensor, Tensor]:
+    """gcpnet.py:1054-1066 -- all (i, j) with batch[i] == batch[j] INCLUDING i == j, sorted by (i, j).
+
+    Built from per-molecule offsets instead of the reference's N x N boolean matrix (same result:
+    ``batch_index`` is sorted, so each molecule is one contiguous block).
+    """
+    counts = torch.bincount(batch_index)
+    counts = counts[counts > 0]
+    offs = torch.cumsum(counts, 0) - counts
+    rows, cols = [], []
+    for o, n in zip(offs.tolist(), counts.tolist()):
+        idx = torch.arange(o, o + n)
+        rows.append(idx.repeat_interleave(n))
+        cols.append(idx.repeat(n))
+    row, col = torch.cat(rows), torch.cat(cols)
+    if mask is not None and not bool(mask.all()):
+        keep = mask[row] & mask[col]
+        row, col = row[keep], col[keep]
+    return row, col
+
+
+def _normalize(t: Tensor, dim: int = -1) -> Tensor:
+    """src/datamodules/components/helper.py:15-24."""
+    return torch.nan_to_num(t / torch.norm(t, dim=dim, keepdim=True))
+
+
+def orientations(x: Tensor) -> Tensor:
+    """protein_graph_dataset.py:217-225 via edm_dataset.py:41-76 (``edm_sampling=True``).
+
+    chi0[i] = [nrm(x[i+1]-x[i]), nrm(x[i-1]-x[i])] over the FLAT batch (crosses molecule boundaries,
+    SURVEY A.6.2); zero-padded at the global ends; NaN -> 0.
+    """
+    fwd = _normalize(x[1:] - x[:-1])
+    bwd = _normalize(x[:-1] - x[1:])
+    fwd = F.pad(fwd, [0, 0, 0, 1])
+    bwd = F.pad(bwd, [0, 0, 1, 0])
+    return torch.nan_to_num(torch.stack((fwd, bwd), dim=-2))
+
+
+def edge_features(x: Tensor, row: Tensor, col: Tensor) -> Tuple[Tensor, Tensor]:
+    """edm_dataset.py:22-38: e = |x_i-x_j|^2 [E,1]; xi = nrm(x_i-x_j) [E,1,3]; NaN -> 0."""
+    d = x[row] - x[col]
+    e = torch.sum(d ** 2, dim=1, keepdim=True)
+    xi = _normalize(d).unsqueeze(-2)
+    return torch.nan_to_num(e), torch.nan_to_num(xi)
+
+
+def centralize(x: Tensor, batch_index: Tensor, num_graphs: int, mask: Tensor) -> Tensor:
+    """components/__init__.py:45-98, ``edm=True`` branch: subtract the per-molecule mean (sum / count)."""
+    cnt = torch.zeros(num_graphs, dtype=x.dtype).index_add_(0, batch_index, mask.to(x.dtype)).unsqueeze(-1)
+    s = torch.zeros(num_graphs, x.shape[1], dtype=x.dtype).index_add_(0, batch_index, x)
+    cen = s / cnt
+    return x - cen[batch_index] * mask.to(x.dtype).unsqueeze(-1)
+
+
+def localize(x: Tensor, row: Tensor, col: Tensor) -> Tensor:
+    """components/__init__.py:122-171 (norm_x_diff=True): rows [a; b; c],
+    a = (x_i-x_j)/(|.|+1), b = (x_i x x_j)/(|.|+1), c = a x b."""
+    xd = x[row] - x[col]
+    xc = torch.linalg.cross(x[row], x[col], dim=-1)
+    xd = xd / (torch.sqrt(torch.sum(xd ** 2, dim=1, keepdim=True)) + 1)
+    xc = xc / (torch.sqrt(torch.sum(xc ** 2, dim=1, keepdim=True)) + 1)
+    xv = torch.linalg.cross(xd, xc, dim=-1)
+    return torch.stack((xd, xc, xv), dim=1)
+
+
+def scalarize(u: Tensor, row: Tensor, frames: Tensor, node_inputs: bool, dim_size: int) -> Tensor:
+    """components/__init__.py:174-219.  ``u`` is [M, 3ch, 3xyz]; q[3c+r] = f[r,:].u[c,:];
+    node mode: scatter-MEAN over ``row`` (count clamped >= 1)."""
+    ui = u[row] if node_inputs else u
+    loc = torch.matmul(frames, ui.transpose(-1, -2)).transpose(-1, -2).reshape(ui.shape[0], 9)
+    if not node_inputs:
+        return loc
+    out = torch.zeros(dim_size, 9, dtype=u.dtype).index_add_(0, row, loc)
+    cnt = torch.zeros(dim_size, dtype=u.dtype).index_add_(0, row, torch.ones(row.shape[0], dtype=u.dtype))
+    return out / cnt.clamp(min=1).unsqueeze(-1)
+
+
+def safe_norm(x: Tensor, dim: int, eps: float = 1e-8) -> Tensor:
+    """components/__init__.py:275-286 (eps added twice)."""
+    return torch.sqrt(torch.sum(x ** 2, dim=dim) + eps) + eps
+
+
+def _act(name: Optional[str]) -> Callable[[Tensor], Tensor]:
+    """src/models/__init__.py:30-45 (only the two values the production config uses)."""
+    if name is None:
+        return lambda t: t
+    if name == "silu":
+        return F.silu
+    raise NotImplementedError(name)
+
+
+# ------------------------------------------------------------------------------------------------
+# GCP2
+# ------------------------------------------------------------------------------------------------
+def gcp2(P: Params, pre: str, s: Tensor, v: Tensor, row: Tensor, frames: Tensor, node_inputs: bool,
+         act: Optional[str], vector_out: bool, feedforward_out: bool = False):
+    """gcpnet.py:418-491 + process_vector_with_frames :378-415 in the production configuration
+    (vector_gate=True, frame_gate=False, no residuals, no ablations).
+
+    s [M,S_in], v [M,V_in,3] -> (act(p) [M,S_out], v' [M,V_out,3]) or act(p) if not ``vector_out``.
+    Note: the vector gate sees ``act(p)`` *computed from the pre-activation p*.
+    """
+    a = _act(act)
+    vt = v.transpose(-1, -2)                                   # [M,3,V_in]
+    vh = vt @ P[pre + "vector_down.weight"].T                  # [M,3,H]
+    merged = torch.cat((s, safe_norm(vh, dim=-2)), dim=-1)
+    u = (vt @ P[pre + "vector_down_frames.weight"].T).transpose(-1, -2)  # [M,3ch,3xyz]
+    merged = torch.cat((merged, scalarize(u, row, frames, node_inputs, u.shape[0])), dim=-1)
+    if feedforward_out:   # Linear - SiLU - Linear (gcpnet.py:321-325; scalar_out_nonlinearity default "silu")
+        p = F.linear(merged, P[pre + "scalar_out.0.weight"], P[pre + "scalar_out.0.bias"])
+        p = F.linear(F.silu(p), P[pre + "scalar_out.2.weight"], P[pre + "scalar_out.2.bias"])
+    else:
+        p = F.linear(merged, P[pre + "scalar_out.weight"], P[pre + "scalar_out.bias"])
+    if not vector_out:
+        return a(p)
+    vo = (vh @ P[pre + "vector_up.weight"].T).transpose(-1, -2)         # [M,V_out,3]
+    gate = F.linear(a(p), P[pre + "vector_out_scale.weight"], P[pre + "vector_out_scale.bias"])
+    vo = vo * torch.sigmoid(gate).unsqueeze(-1)
+    return a(p), vo
+
+
+# ------------------------------------------------------------------------------------------------
+# message passing / interaction layer / dynamics
+# ------------------------------------------------------------------------------------------------
+def message_passing(P: Params, pre: str, h: Tensor, chi: Tensor, e: Tensor, xi: Tensor, row: Tensor,
+                    col: Tensor, frames: Tensor, cfg: OracleConfig) -> Tuple[Tensor, Tensor]:
+    """GCPMessagePassing.message/aggregate/forward, gcpnet.py:676-737 (residual message GCPs, scalar
+    message attention, sum aggregation over ``row``)."""
+    s = torch.cat((h[row], e, h[col]), dim=-1)
+    v = torch.cat((chi[row], xi, chi[col]), dim=1)
+    ms, mv = gcp2(P, pre + "message_fusion.0.", s, v, row, frames, False, "silu", True)
+    for k in range(1, cfg.num_message_layers):
+        ns, nv = gcp2(P, pre + f"message_fusion.{k}.", ms, mv, row, frames, False, "silu", True)
+        ms, mv = ms + ns, mv + nv
+    attn = torch.sigmoid(F.linear(ms, P[pre + "scalar_message_attention.0.weight"],
+                                  P[pre + "scalar_message_attention.0.bias"]))
+    ms = ms * attn
+    flat = torch.cat((ms, mv.reshape(mv.shape[0], -1)), dim=-1)
+    agg = torch.zeros(h.shape[0], flat.shape[1], dtype=h.dtype).index_add_(0, row, flat)
+    V = chi.shape[1]
+    return agg[:, : -3 * V], agg[:, -3 * V:].reshape(-1, V, 3)
+
+
+def interaction_layer(P: Params, pre: str, h: Tensor, chi: Tensor, e: Tensor, xi: Tensor, row: Tensor,
+                      col: Tensor, frames: Tensor, x: Tensor, maskf: Tensor, cfg: OracleConfig):
+    """GCPInteractions.forward + derive_x_update, gcpnet.py:834-930 (pre_norm False, norms/dropout identity,
+    one feed-forward GCP2 with feedforward_out, position update from a (S,1) GCP2)."""
+    a_s, a_v = message_passing(P, pre + "interaction.", h, chi, e, xi, row, col, frames, cfg)
+    hs = torch.cat((a_s, h), dim=-1)
+    hv = torch.cat((a_v, chi), dim=1)
+    fs, fv = gcp2(P, pre + "feedforward_network.0.", hs, hv, row, frames, True, None, True, feedforward_out=True)
+    h = (h + fs) * maskf[:, None]
+    chi = (chi + fv) * maskf[:, None, None]
+    _, pv = gcp2(P, pre + "node_position_update_gcp.", h, chi, row, frames, True, "silu", True)
+    x = (x + pv[:, 0, :] * cfg.node_positions_weight) * maskf[:, None]
+    return h, chi, x
+
+
+def infer_num_layers(P: Params) -> int:
+    n = 0
+    while f"interaction_layers.{n}.interaction.message_fusion.0.vector_down.weight" in P:
+        n += 1
+    return n
+
+
+def dynamics_forward(P: Params, cfg: OracleConfig, xh: Tensor, t: Tensor, batch_index: Tensor,
+                     mask: Optional[Tensor] = None, context: Optional[Tensor] = None,
+                     return_intermediates: bool = False):
+    """GCPNetDynamics.atom_types_and_coords_forward, gcpnet.py:1069-1232 (self_condition False).
+
+    xh [N,3+F], t [N,1], batch_index [N] sorted, context [N,C] or None  ->  net_out [N,3+F].
+    """
+    N = xh.shape[0]
+    mask = torch.ones(N, dtype=torch.bool) if mask is None else mask
+    maskf = mask.to(xh.dtype)
+    B = int(batch_index.max().item()) + 1
+    xh = xh * maskf[:, None]
+    x0, h0 = xh[:, :3].clone(), xh[:, 3:].clone()
+    row, col = fully_connected_edges(batch_index, mask)
+    chi = orientations(x0)                                      # :1105
+    e, xi = edge_features(x0, row, col)                         # :1109 (un-centralised x)
+    h = h0
+    if cfg.condition_on_time:
+        h = torch.cat((h, t.view(N, 1)), dim=-1)               # :1142-1150
+    if cfg.num_context:
+        h = torch.cat((h, context.view(N, cfg.num_context)), dim=-1)   # :1153-1155
+    x = centralize(x0, batch_index, B, mask)                    # :1160
+    frames = localize(x, row, col)                              # :1169
+    # GCPEmbedding.forward :551-603 (pre-norms are identity: use_gcp_norm False)
+    e, xi = gcp2(P, "gcp_embedding.edge_embedding.", e, xi, row, frames, False, "silu", True)
+    h, chi = gcp2(P, "gcp_embedding.node_embedding.", h, chi, row, frames, True, None, True)
+    inter = {}
+    if return_intermediates:
+        inter.update(row=row, col=col, frames=frames, e=e, xi=xi, h_embed=h, chi_embed=chi, x_central=x)
+    L = cfg.num_layers if cfg.num_layers else infer_num_layers(P)
+    for l in range(L):
+        h, chi, x = interaction_layer(P, f"interaction_layers.{l}.", h, chi, e, xi, row, col, frames, x, maskf, cfg)
+        if return_intermediates:
+            inter[f"h_{l}"], inter[f"chi_{l}"], inter[f"x_{l}"] = h, chi, x
+    hout = gcp2(P, "scalar_node_projection_gcp.", h, chi, row, frames, True, None, False)   # :1191
+    vel = (x - x0) * maskf[:, None]                             # :1204
+    if cfg.num_context:
+        hout = hout[:, : -cfg.num_context]
+    if cfg.condition_on_time:
+        hout = hout[:, :-1]
+    if bool(vel.isnan().any()):                                 # :1213-1216 (whole batch zeroed)
+        vel = torch.zeros_like(vel)
+    vel = centralize(vel, batch_index, B, mask)                 # :1220
+    out = torch.cat((vel, hout), dim=-1)
+    return (out, inter) if return_intermediates else out
+
+
+# ------------------------------------------------------------------------------------------------
+# noise schedule + sampler
+# ------------------------------------------------------------------------------------------------
+def gamma_table(cfg: OracleConfig) -> Tensor:
+    """PredefinedNoiseSchedule ("polynomial_<p>"), variational_diffusion.py:67-107, 206-250.
+    Computed in float64 numpy and rounded to fp32 exactly as the reference does."""
+    T = cfg.num_timesteps
+    power = float(cfg.noise_schedule.split("_")[1])
+    steps = T + 1
+    x = np.linspace(0, steps, steps)
+    a2 = (1 - np.power(x / steps, power)) ** 2
+    a2 = np.concatenate([np.ones(1), a2], axis=0)
+    step = np.clip(a2[1:] / a2[:-1], a_min=0.001, a_max=1.0)
+    a2 = np.cumprod(step, axis=0)
+    a2 = (1 - 2 * cfg.noise_precision) * a2 + cfg.noise_precision
+    g = -(np.log(a2) - np.log(1 - a2))
+    return torch.tensor(g).float()
+
+
+def gamma_at(gam: Tensor, t: Tensor, T: int) -> Tensor:
+    """variational_diffusion.py:252-255."""
+    return gam[torch.round(t * T).long()]
+
+
+def sigma_and_alpha_t_given_s(gt: Tensor, gs: Tensor):
+    """variational_diffusion.py:342-367."""
+    s2 = -torch.expm1(F.softplus(gs) - F.softplus(gt))
+    a = torch.exp(0.5 * (F.logsigmoid(-gt) - F.logsigmoid(-gs)))
+    return s2, torch.sqrt(s2), a
+
+
+class TapeNoise:
+    """Noise source reproducing the reference's ``torch.randn`` call order: per draw an x-part [N,3]
+    then an h-part [N,F] (variational_diffusion.py:804-817), fp32 from a seeded CPU generator."""
+
+    def __init__(self, seed: int = 1234):
+        self.gen = torch.Generator().manual_seed(seed)
+
+    def __call__(self, n: int, k: int, dtype=torch.float32) -> Tensor:
+        return torch.randn((n, k), generator=self.gen, dtype=torch.float32).to(dtype)
+
+
+def sample_combined_noise(noise, batch_index: Tensor, B: int, mask: Tensor, F_: int, dtype) -> Tensor:
+    """variational_diffusion.py:795-819: CoM-free x-noise, plain h-noise."""
+    N = batch_index.shape[0]
+    zx = noise(N, 3, dtype) * mask.to(dtype)[:, None]
+    zx = centralize(zx, batch_index, B, mask)
+    zh = noise(N, F_, dtype) * mask.to(dtype)[:, None]
+    return torch.cat((zx, zh), dim=-1)
+
+
+def sample_p_zs_given_zt(P: Params, cfg: OracleConfig, gam: Tensor, s: float, t: float, z: Tensor,
+                         batch_index: Tensor, B: int, mask: Tensor, context: Optional[Tensor], noise,
+                         eps_override: Optional[Tensor] = None) -> Tuple[Tensor, Tensor]:
+    """variational_diffusion.py:1204-1278.  Returns (z_s, eps_t)."""
+    dt = z.dtype
+    sv = torch.full((B, 1), s, dtype=dt)
+    tv = torch.full((B, 1), t, dtype=dt)
+    gs, gt = gamma_at(gam, sv, cfg.num_timesteps).to(dt), gamma_at(gam, tv, cfg.num_timesteps).to(dt)
+    s2ts, sts, ats = sigma_and_alpha_t_given_s(gt, gs)
+    sig_s, sig_t = torch.sqrt(torch.sigmoid(gs)), torch.sqrt(torch.sigmoid(gt))
+    eps = dynamics_forward(P, cfg, z, tv[batch_index], batch_index, mask, context) if eps_override is None else eps_override
+    mu = z / ats[batch_index] - (s2ts[batch_index] / ats[batch_index] / sig_t[batch_index]) * eps
+    sigma = sts * sig_s / sig_t
+    zs = mu + sigma[batch_index] * sample_combined_noise(noise, batch_index, B, mask, cfg.num_node_scalar_features, dt)
+    zs = torch.cat((centralize(zs[:, :3], batch_index, B, mask), zs[:, 3:]), dim=-1)
+    return zs, eps
+
+
+def sample_p_xh_given_z0(P: Params, cfg: OracleConfig, gam: Tensor, z0: Tensor, batch_index: Tensor, B: int,
+                         mask: Tensor, context: Optional[Tensor], noise):
+    """variational_diffusion.py:840-907 (+ unnormalize :735-757)."""
+    dt = z0.dtype
+    t0 = torch.zeros((B, 1), dtype=dt)
+    g0 = gamma_at(gam, t0, cfg.num_timesteps).to(dt)
+    sigma_x = torch.exp(-(-0.5 * g0))                            # SNR(-0.5*gamma_0) = exp(0.5*gamma_0)
+    eps = dynamics_forward(P, cfg, z0, t0[batch_index], batch_index, mask, context)
+    sig0, alp0 = torch.sqrt(torch.sigmoid(g0)), torch.sqrt(torch.sigmoid(-g0))
+    mu = 1.0 / alp0[batch_index] * (z0 - sig0[batch_index] * eps)
+    xh = mu + sigma_x[batch_index] * sample_combined_noise(noise, batch_index, B, mask, cfg.num_node_scalar_features, dt)
+    x = xh[:, :3] * cfg.norm_values[0]
+    mf = mask.to(dt)[:, None]
+    if cfg.include_charges:
+        h_cat, h_int = xh[:, 3:-1], xh[:, -1:]
+    else:
+        h_cat, h_int = xh[:, 3:], torch.zeros(0, dtype=dt)
+    h_cat = (h_cat * cfg.norm_values[1] + cfg.norm_biases[1]) * mf
+    h_int = h_int * cfg.norm_values[2] + cfg.norm_biases[2]
+    if cfg.include_charges:
+        h_int = h_int * mf
+    one_hot = F.one_hot(torch.argmax(h_cat, dim=-1), cfg.num_atom_types) * mask.long()[:, None]
+    charges = torch.round(h_int).long() * mask.long()[:, None] if cfg.include_charges else h_int.long()
+    return x, one_hot, charges
+
+
+def mol_gen_sample(P: Params, cfg: OracleConfig, num_nodes: Tensor, noise, context: Optional[Tensor] = None,
+                   num_timesteps: Optional[int] = None, dtype=torch.float32,
+                   record: Optional[List[Tensor]] = None) -> Tuple[Tensor, Tensor]:
+    """EquivariantVariationalDiffusion.mol_gen_sample, variational_diffusion.py:1282-1412
+    (return_frames=1, no self-conditioning, fix_noise False).  Returns (out [N,3+F], batch_index)."""
+    T = cfg.num_timesteps if num_timesteps is None else num_timesteps
+    B = len(num_nodes)
+    bi = num_nodes_to_batch_index(num_nodes)
+    mask = torch.ones_like(bi).bool()
+    ctx = None
+    if context is not None:
+        ctx = context.to(dtype)[bi] * mask.to(dtype)[:, None]
+    gam = gamma_table(cfg)
+    z = sample_combined_noise(noise, bi, B, mask, cfg.num_node_scalar_features, dtype)
+    for s in reversed(range(T)):
+        z, _ = sample_p_zs_given_zt(P, cfg, gam, s / T, (s + 1) / T, z, bi, B, mask, ctx, noise)
+        if record is not None:
+            record.append(z.clone())
+    x, one_hot, charges = sample_p_xh_given_z0(P, cfg, gam, z, bi, B, mask, ctx, noise)
+    cog = torch.zeros(B, 3, dtype=dtype).index_add_(0, bi, x).abs().max().item()
+    if cog > 5e-2:                                               # :1392-1402
+        x = centralize(x, bi, B, mask)
+    parts = [x, one_hot.to(dtype)] + ([charges.to(dtype)] if cfg.include_charges else [])
+    return torch.cat(parts, dim=-1), bi
+
+
+# ------------------------------------------------------------------------------------------------
+# algorithmic FLOP count -- used by bench.py for the roofline line
+# ------------------------------------------------------------------------------------------------
+def _gcp2_flops(M, S_in, V_in, S_out, V_out, bn, ff=False):
+    H = V_in // bn if bn > 1 else max(V_in, V_out)
+    f = 3 * V_in * H + 9 * V_in + 27 + (S_in + H + 9) * S_out
+    if ff:
+        f += S_out * S_out
+    if V_out:
+        f += 3 * H * V_out + S_out * V_out
+    return 2 * M * f
+
+
+def forward_flops(N: int, E: int, S: int, V: int, Se: int, Ve: int, L: int, h_in: int) -> int:
+    per_layer = (_gcp2_flops(E, 2 * S + Se, 2 * V + Ve, S, V, 4) + 3 * _gcp2_flops(E, S, V, S, V, 4) + 2 * E * S
+                 + _gcp2_flops(N, 2 * S, 2 * V, S, V, 4, ff=True) + _gcp2_flops(N, S, V, S, 1, 4))
+    return (_gcp2_flops(E, 1, 1, Se, Ve, 1) + _gcp2_flops(N, h_in, 2, S, V, 1) + L * per_layer
+            + _gcp2_flops(N, S, V, h_in, 0, 1))

@@ -1,0 +1,131 @@
+"""Pins the CPU oracle (oracle/gcdm_oracle.py) to golden vectors produced by the REFERENCE itself
+(tests/golden/make_golden.py).  CPU only."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import synth
+from oracle import gcdm_oracle as O
+
+CASES = ["qm9", "qm9cond", "geom"]
+
+
+def load(golden_dir, name):
+    z = np.load(os.path.join(golden_dir, name + ".npz"))
+    return {k: torch.tensor(z[k]) for k in z.files}
+
+
+def weights_of(g):
+    return {k[2:]: v for k, v in g.items() if k.startswith("w:")}
+
+
+def cfg_for(case, L):
+    d = synth.DATASET_DIMS[case]
+    return O.OracleConfig(num_atom_types=d["num_atom_types"], include_charges=d["include_charges"],
+                          num_context=d["n_ctx"], num_layers=L, norm_values=d["norm_values"])
+
+
+def test_geometry_functions(golden_dir):
+    g = load(golden_dir, "fn_geometry")
+    bi = O.num_nodes_to_batch_index(g["num_nodes"])
+    mask = torch.ones(len(bi), dtype=torch.bool)
+    row, col = O.fully_connected_edges(bi, mask)
+    assert torch.equal(torch.stack((row, col)), g["edge_index"])
+    e, xi = O.edge_features(g["x"], row, col)
+    assert torch.equal(e, g["e"]) and torch.allclose(xi, g["xi"], atol=1e-7)
+    assert torch.allclose(O.orientations(g["x"]), g["chi0"], atol=1e-7)
+    xc = O.centralize(g["x"], bi, len(g["num_nodes"]), mask)
+    assert torch.allclose(xc, g["x_central"], atol=1e-7)
+    fr = O.localize(xc, row, col)
+    assert torch.allclose(fr, g["frames"], atol=1e-7)
+    assert torch.allclose(O.scalarize(g["u_edge"], row, fr, False, len(row)), g["q_edge"], atol=1e-6)
+    assert torch.allclose(O.scalarize(g["u_node"], row, fr, True, len(bi)), g["q_node"], atol=1e-6)
+    assert torch.allclose(O.safe_norm(g["sn_in"].transpose(-1, -2), dim=-2), g["sn_out"], rtol=1e-6, atol=0)
+
+
+@pytest.mark.parametrize("name,node,act,ff,vout", [("edge", False, "silu", False, True), ("node", True, None, False, True),
+                                                    ("nodeff", True, None, True, True), ("proj", True, None, False, False)])
+def test_single_gcp2(golden_dir, name, node, act, ff, vout):
+    g = load(golden_dir, "fn_gcp2")
+    bi = O.num_nodes_to_batch_index(g["num_nodes"])
+    mask = torch.ones(len(bi), dtype=torch.bool)
+    row, col = O.fully_connected_edges(bi, mask)
+    fr = O.localize(O.centralize(g["x"], bi, len(g["num_nodes"]), mask), row, col)
+    P = {k[len(name) + 3:]: v for k, v in g.items() if k.startswith(name + "_w_")}
+    r = O.gcp2(P, "", g[name + "_s"], g[name + "_v"], row, fr, node, act, vout, feedforward_out=ff)
+    if vout:
+        assert torch.allclose(r[0], g[name + "_os"], atol=2e-6)
+        assert torch.allclose(r[1], g[name + "_ov"], atol=2e-6)
+    else:
+        assert torch.allclose(r, g[name + "_os"], atol=2e-6)
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_dynamics_small(golden_dir, case):
+    g = load(golden_dir, f"dyn_small_{case}")
+    P = weights_of(g)
+    cfg = cfg_for(case, O.infer_num_layers(P))
+    bi = O.num_nodes_to_batch_index(g["num_nodes"])
+    out, inter = O.dynamics_forward(P, cfg, g["xh"], g["t"], bi, None, g.get("ctx"), return_intermediates=True)
+    assert torch.allclose(inter["h_embed"], g["h_embed"], atol=1e-5)
+    assert torch.allclose(inter["e"], g["e_embed"], atol=1e-5)
+    assert torch.allclose(inter["xi"], g["xi_embed"], atol=1e-5)
+    assert torch.allclose(inter["h_0"], g["h_l0"], atol=1e-5)
+    assert torch.allclose(inter["x_0"], g["x_l0"], atol=1e-5)
+    assert (out - g["out32"]).abs().max().item() <= 1e-5
+    # fp64 twin: the oracle in fp64 reproduces the reference in fp64 to (stored) fp32 precision
+    P64 = {k: v.double() for k, v in P.items()}
+    ctx = g.get("ctx")
+    out64 = O.dynamics_forward(P64, cfg, g["xh"].double(), g["t"].double(), bi, None, None if ctx is None else ctx.double())
+    assert (out64.float() - g["out64"]).abs().max().item() <= 1e-6
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_schedule_and_sampler_small(golden_dir, case):
+    g = load(golden_dir, f"sampler_small_{case}")
+    P = weights_of(g)
+    cfg = cfg_for(case, O.infer_num_layers(P))
+    gam = O.gamma_table(cfg)
+    assert torch.equal(gam, g["gamma"])
+    # SURVEY A.5 known answers
+    kn = {0: -11.5129156, 1: -11.330595, 2: -10.9251308, 500: -0.251309335, 998: 10.5586309, 999: 11.1767302, 1000: 11.512516}
+    for i, v in kn.items():
+        assert abs(gam[i].item() - v) < 2e-6 * max(1, abs(v))
+    s2, s_, a_ = O.sigma_and_alpha_t_given_s(gam[1000].view(1, 1), gam[999].view(1, 1))
+    pins = g["pins"]
+    assert torch.allclose(torch.stack([s2.squeeze(), s_.squeeze(), a_.squeeze()]), pins[:3], rtol=1e-6)
+    assert abs(pins[0].item() - 0.285220444) < 1e-7 and abs(pins[5].item() - 0.00316229323) < 1e-9
+
+    nn_ = g["num_nodes"]
+    bi = O.num_nodes_to_batch_index(nn_)
+    B = len(nn_)
+    mask = torch.ones(len(bi), dtype=torch.bool)
+    ctx_b = g.get("ctx")
+    ctx = None if ctx_b is None else ctx_b[bi]
+    for idx in range(3):
+        s = int(g[f"tf{idx}_s"])
+        zs, _ = O.sample_p_zs_given_zt(P, cfg, gam, s / 1000, (s + 1) / 1000, g[f"tf{idx}_z"], bi, B, mask, ctx,
+                                       O.TapeNoise(int(g[f"tf{idx}_noise_seed"])))
+        assert (zs - g[f"tf{idx}_zs"]).abs().max().item() <= 1e-5
+    out, _ = O.mol_gen_sample(P, cfg, nn_, O.TapeNoise(int(g["free_seed"])), context=ctx_b, num_timesteps=int(g["free_T"]))
+    ref = g["free_out"]
+    assert (out[:, :3] - ref[:, :3]).abs().max().item() <= 1e-4 * max(1.0, ref[:, :3].abs().max().item())
+    assert torch.equal(out[:, 3:], ref[:, 3:])
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_dynamics_full_width(golden_dir, case):
+    """Full-width production architecture; weights re-created from the seed recipe (tests/synth.py)."""
+    g = load(golden_dir, f"dyn_full_{case}")
+    d = synth.DATASET_DIMS[case]
+    P = synth.make_weights(synth.dynamics_shapes(d["S"], d["V"], d["Se"], d["Ve"], d["L"], synth.dims_h_in(d)),
+                           seed=int(g["weight_seed"]))
+    cfg = cfg_for(case, d["L"])
+    bi = O.num_nodes_to_batch_index(g["num_nodes"])
+    out, inter = O.dynamics_forward(P, cfg, g["xh"], g["t"], bi, None, g.get("ctx"), return_intermediates=True)
+    assert torch.allclose(inter["h_embed"], g["h_embed"], atol=1e-5)
+    assert torch.allclose(inter["h_0"], g["h_l0"], atol=2e-5)
+    assert (out - g["out32"]).abs().max().item() <= 2e-5
+    assert (out - g["out64"]).abs().max().item() <= 1e-4
