@@ -1,0 +1,23 @@
+"""bio-diffusion_amd -- MI355X-native implementation of the GCDM denoising inner loop.
+
+Drop-in for ONE path of BioinfoMachineLearning/bio-diffusion: the GCPNet dynamics network evaluated at
+every DDPM step of molecule sampling (reference: src/models/components/gcpnet.py:933-1232 and the sampler
+in src/models/components/variational_diffusion.py:1204-1412).  Host code is Python on PyTorch-ROCm
+(device memory + streams only); the compute is hand-written HIP for gfx950 behind the C ABI declared in
+``include/gcdm_hip.h`` (``libgcdm_hip.so``).  There is no CPU fallback: without the library or without a
+GPU the forward raises.
+
+The directory name contains a hyphen; import it with ``importlib.import_module("bio-diffusion_amd")`` or
+through the alias module ``bio_diffusion_amd`` at the repository root.
+"""
+from .config import AttrDict, default_cfgs, load_cfg_tree, dataset_info          # noqa: F401
+from .gcpnet import GCP2, GCPNetDynamics                                        # noqa: F401
+from .variational_diffusion import EquivariantVariationalDiffusion, PredefinedNoiseSchedule, NumNodesDistribution  # noqa: F401
+from .mol_gen_ddpm import QM9MoleculeGenerationDDPM, GEOMMoleculeGenerationDDPM  # noqa: F401
+from . import _native                                                           # noqa: F401
+
+__all__ = [
+    "AttrDict", "default_cfgs", "load_cfg_tree", "dataset_info", "GCP2", "GCPNetDynamics",
+    "EquivariantVariationalDiffusion", "PredefinedNoiseSchedule", "NumNodesDistribution",
+    "QM9MoleculeGenerationDDPM", "GEOMMoleculeGenerationDDPM",
+]

@@ -1,0 +1,96 @@
+"""ctypes binding of libgcdm_hip.so (C ABI: include/gcdm_hip.h).  This file IS the binding a maintainer of the
+reference would add; it contains no compute."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+from typing import Optional
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libgcdm_hip.so")
+SOURCES = [os.path.join(_HERE, "csrc", "gcdm_api.hip")]
+HEADERS = [os.path.join(_HERE, "csrc", "gcdm_kernels.hip.h"), os.path.join(os.path.dirname(_HERE), "include", "gcdm_hip.h")]
+ABI_VERSION = 1
+
+FLAG_NAN_VEL, FLAG_MEAN_NOT_ZERO, FLAG_COG_DRIFT = 1, 2, 4
+
+
+class GcdmConfig(C.Structure):
+    _fields_ = [
+        ("abi_version", C.c_int32), ("num_atom_types", C.c_int32), ("include_charges", C.c_int32),
+        ("num_context", C.c_int32), ("condition_on_time", C.c_int32), ("num_layers", C.c_int32),
+        ("h_hidden_dim", C.c_int32), ("chi_hidden_dim", C.c_int32), ("e_hidden_dim", C.c_int32),
+        ("xi_hidden_dim", C.c_int32), ("bottleneck", C.c_int32), ("num_timesteps", C.c_int32),
+        ("node_positions_weight", C.c_float), ("norm_values", C.c_float * 3), ("norm_biases", C.c_float * 3),
+        ("device", C.c_int32),
+    ]
+
+
+EXPORTS = [
+    "gcdm_create", "gcdm_destroy", "gcdm_last_error", "gcdm_set_weight", "gcdm_finalize_weights", "gcdm_set_gamma",
+    "gcdm_plan_batch", "gcdm_forward", "gcdm_sample_step", "gcdm_sample_final", "gcdm_sample_init", "gcdm_debug_read",
+    "gcdm_debug_set_layer_limit", "gcdm_num_nodes", "gcdm_num_edges", "gcdm_forward_flops_executed",
+]
+
+_lib: Optional[C.CDLL] = None
+
+
+def build(force: bool = False) -> str:
+    """hipcc --offload-arch=gfx950 (cross-compiles without a GPU).  Rebuilds when a source is newer than the .so."""
+    deps = SOURCES + HEADERS
+    if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in deps):
+        return LIB_PATH
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-o", LIB_PATH] + SOURCES
+    subprocess.run(cmd, check=True)
+    return LIB_PATH
+
+
+def load() -> C.CDLL:
+    """Loads the library; raises (loudly) if it has not been built -- there is no fallback path."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                           "(hipcc --offload-arch=gfx950).  bio-diffusion_amd has no CPU / eager fallback.")
+    lib = C.CDLL(LIB_PATH)
+    H = C.c_void_p
+    lib.gcdm_create.argtypes = [C.POINTER(GcdmConfig), C.POINTER(H)]
+    lib.gcdm_destroy.argtypes = [H]
+    lib.gcdm_last_error.argtypes = [H]
+    lib.gcdm_last_error.restype = C.c_char_p
+    lib.gcdm_set_weight.argtypes = [H, C.c_char_p, C.c_void_p, C.c_int64]
+    lib.gcdm_finalize_weights.argtypes = [H]
+    lib.gcdm_set_gamma.argtypes = [H, C.c_void_p, C.c_int64]
+    lib.gcdm_plan_batch.argtypes = [H, C.c_int32, C.c_void_p]
+    lib.gcdm_forward.argtypes = [H, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.gcdm_sample_step.argtypes = [H, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]
+    lib.gcdm_sample_final.argtypes = [H, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.gcdm_sample_init.argtypes = [H, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]
+    lib.gcdm_debug_read.argtypes = [H, C.c_char_p, C.c_void_p, C.c_int64]
+    lib.gcdm_debug_read.restype = C.c_int64
+    lib.gcdm_debug_set_layer_limit.argtypes = [H, C.c_int32]
+    lib.gcdm_num_nodes.argtypes = [H]
+    lib.gcdm_num_nodes.restype = C.c_int64
+    lib.gcdm_num_edges.argtypes = [H]
+    lib.gcdm_num_edges.restype = C.c_int64
+    lib.gcdm_forward_flops_executed.argtypes = [H]
+    lib.gcdm_forward_flops_executed.restype = C.c_double
+    for name in EXPORTS:
+        if getattr(lib, name).restype is C.c_int:
+            getattr(lib, name).restype = C.c_int
+    _lib = lib
+    return lib
+
+
+class NativeError(RuntimeError):
+    pass
+
+
+def check(lib, handle, status, what: str):
+    if status < 0:
+        msg = lib.gcdm_last_error(handle)
+        raise NativeError(f"{what} failed: {msg.decode() if msg else 'unknown error'}")
+    return status

@@ -1,0 +1,648 @@
+// gcdm_api.hip -- host side of libgcdm_hip.so: C ABI (include/gcdm_hip.h), weight re-packing into the MFMA
+// fragment layout, batch plan, kernel launches.  gfx950 only; no torch types, no exceptions across the ABI.
+#include "gcdm_kernels.hip.h"
+#include "../../include/gcdm_hip.h"
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+namespace {
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t bytes = 0;
+};
+
+struct LayerDev {
+    // edge kernel
+    const v4f* w0; int G0; const float* wddE; const v4f* wg0; const float* bg0; const float* wup0;
+    GcpW mk[3];
+    const float* wa; float ba;
+    // node kernel
+    GcpW ff, pos;
+    const v4f* wpq; const float* bpq; const float* wddI; const float* wddJ;
+};
+
+}  // namespace
+
+struct gcdm_handle {
+    GcdmConfig cfg{};
+    std::string err;
+    std::map<std::string, std::vector<float>> host_w;
+    bool finalized = false;
+    // derived dims
+    int F = 0, C = 0, Fin = 0, FinG = 0, D = 0, Se = 0, Ve = 0, L = 0, H0 = 0;
+    // device weights
+    float* wpool = nullptr;
+    std::vector<LayerDev> layers;
+    GcpW emb{}, proj{};
+    const float *ee_ws = nullptr, *ee_bs = nullptr, *ee_wd = nullptr, *ee_wdf = nullptr, *ee_kappa = nullptr, *ee_wg = nullptr, *ee_bg = nullptr;
+    std::vector<float> gamma;
+    // plan
+    int B = 0, N = 0, max_n = 0;
+    int64_t E = 0;
+    int *d_noff = nullptr, *d_erow = nullptr, *d_ecol = nullptr, *d_ncnt = nullptr;
+    float* ws = nullptr;  // workspace pool
+    size_t ws_floats = 0;
+    float *X0 = nullptr, *XC = nullptr, *FBAR = nullptr, *CHI0 = nullptr, *HIN4 = nullptr, *H4 = nullptr, *CHI = nullptr, *PQ4 = nullptr,
+          *VDI = nullptr, *VDJ = nullptr, *AGG = nullptr, *VEL = nullptr, *EPS = nullptr, *TBUF = nullptr, *EP4 = nullptr, *AL = nullptr, *U = nullptr, *FR = nullptr;
+    uint32_t* d_flags = nullptr;
+    int layer_limit = -1;
+    bool attr_set = false;
+};
+
+namespace {
+
+int fail(gcdm_handle* h, const std::string& msg) {
+    if (h) h->err = msg;
+    return -1;
+}
+
+#define HIP_OK(h, expr)                                                                              \
+    do {                                                                                             \
+        hipError_t _e = (expr);                                                                      \
+        if (_e != hipSuccess) return fail(h, std::string(#expr) + ": " + hipGetErrorString(_e));     \
+    } while (0)
+
+// ---- pool builder: 16-byte aligned sub-arrays of one device allocation ---------------------------
+struct Pool {
+    std::vector<float> host;
+    size_t add(const std::vector<float>& a) {
+        size_t off = (host.size() + 3) & ~size_t(3);
+        host.resize(off + a.size(), 0.f);
+        std::memcpy(host.data() + off, a.data(), a.size() * sizeof(float));
+        return off;
+    }
+};
+
+struct Dense {
+    int M, K;
+    std::vector<float> a;
+    Dense(int m, int k) : M(m), K(k), a((size_t)m * k, 0.f) {}
+    float& at(int m, int k) { return a[(size_t)m * K + k]; }
+};
+
+// packed[mt][g][lane][t] = W[32 mt + (lane & 31)][8 g + 4 (lane >> 5) + t]
+std::vector<float> pack_mfma(Dense& W) {
+    const int MT = W.M / 32, G = W.K / 8;
+    std::vector<float> out((size_t)W.M * W.K);
+    for (int mt = 0; mt < MT; ++mt)
+        for (int g = 0; g < G; ++g)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int t = 0; t < 4; ++t)
+                    out[(((size_t)mt * G + g) * 64 + lane) * 4 + t] = W.at(32 * mt + (lane & 31), 8 * g + 4 * (lane >> 5) + t);
+    return out;
+}
+
+struct WView {
+    const std::vector<float>* v;
+    int rows, cols;
+    float at(int r, int c) const { return (*v)[(size_t)r * cols + c]; }
+};
+
+bool get_w(gcdm_handle* h, const std::string& key, int rows, int cols, WView& out) {
+    auto it = h->host_w.find(key);
+    if (it == h->host_w.end()) {
+        h->err = "missing weight: " + key;
+        return false;
+    }
+    if ((int64_t)it->second.size() != (int64_t)rows * cols) {
+        h->err = "bad shape for " + key + ": expected " + std::to_string(rows) + "x" + std::to_string(cols) + " got numel " +
+                 std::to_string(it->second.size());
+        return false;
+    }
+    out = WView{&it->second, rows, cols};
+    return true;
+}
+
+std::vector<float> padded(const WView& w, int n) {
+    std::vector<float> o(n, 0.f);
+    for (int i = 0; i < w.rows * w.cols && i < n; ++i) o[i] = (*w.v)[i];
+    return o;
+}
+
+int round_up(int x, int m) { return (x + m - 1) / m * m; }
+
+// Pending pointer fix-ups (offsets into the pool until it is uploaded)
+struct GcpOff {
+    size_t w = 0, b = 0, w2 = 0, b2 = 0, wdd = 0, wg = 0, bg = 0, wup = 0;
+    bool has_w2 = false, has_gate = false;
+    int G = 0, H = 0, V_in = 0, V_out = 0;
+};
+
+// generic GCP2 (scalar input = s_in channels laid out in 4-groups starting at K' = 0)
+bool build_gcp(gcdm_handle* h, Pool& pool, const std::string& pre, int s_in, int v_in, int s_out, int v_out, int bottleneck,
+               bool ff, GcpOff& o) {
+    const int H = bottleneck > 1 ? v_in / bottleneck : std::max(v_in, v_out);
+    const int SIg = (s_in + 3) / 4, Hg = (H + 3) / 4;
+    const int Kp = round_up(4 * (SIg + Hg + 3), 8), Mp = round_up(s_out, 32);
+    WView ws, bs, wd, wdf;
+    const std::string so = ff ? "scalar_out.0." : "scalar_out.";
+    if (!get_w(h, pre + so + "weight", s_out, s_in + H + 9, ws) || !get_w(h, pre + so + "bias", 1, s_out, bs) ||
+        !get_w(h, pre + "vector_down.weight", H, v_in, wd) || !get_w(h, pre + "vector_down_frames.weight", 3, v_in, wdf))
+        return false;
+    Dense W(Mp, Kp);
+    for (int m = 0; m < s_out; ++m) {
+        for (int k = 0; k < s_in; ++k) W.at(m, k) = ws.at(m, k);
+        for (int k = 0; k < H; ++k) W.at(m, 4 * SIg + k) = ws.at(m, s_in + k);
+        for (int k = 0; k < 9; ++k) W.at(m, 4 * (SIg + Hg) + k) = ws.at(m, s_in + H + k);
+    }
+    o.w = pool.add(pack_mfma(W));
+    o.b = pool.add(padded(bs, Mp));
+    o.G = Kp / 8; o.H = H; o.V_in = v_in; o.V_out = v_out;
+    std::vector<float> dd((size_t)(H + 3) * v_in);
+    for (int r = 0; r < H; ++r) for (int c = 0; c < v_in; ++c) dd[(size_t)r * v_in + c] = wd.at(r, c);
+    for (int r = 0; r < 3; ++r) for (int c = 0; c < v_in; ++c) dd[(size_t)(H + r) * v_in + c] = wdf.at(r, c);
+    o.wdd = pool.add(dd);
+    if (ff) {
+        WView w2, b2;
+        if (!get_w(h, pre + "scalar_out.2.weight", s_out, s_out, w2) || !get_w(h, pre + "scalar_out.2.bias", 1, s_out, b2)) return false;
+        Dense W2(s_out, s_out);
+        for (int m = 0; m < s_out; ++m) for (int k = 0; k < s_out; ++k) W2.at(m, k) = w2.at(m, k);
+        o.w2 = pool.add(pack_mfma(W2));
+        o.b2 = pool.add(padded(b2, s_out));
+        o.has_w2 = true;
+    }
+    if (v_out) {
+        WView wg, bg, wu;
+        if (!get_w(h, pre + "vector_out_scale.weight", v_out, s_out, wg) || !get_w(h, pre + "vector_out_scale.bias", 1, v_out, bg) ||
+            !get_w(h, pre + "vector_up.weight", v_out, H, wu))
+            return false;
+        Dense Wg(32, s_out);
+        for (int m = 0; m < v_out; ++m) for (int k = 0; k < s_out; ++k) Wg.at(m, k) = wg.at(m, k);
+        o.wg = pool.add(pack_mfma(Wg));
+        o.bg = pool.add(padded(bg, 32));
+        o.wup = pool.add(padded(wu, v_out * H));
+        o.has_gate = true;
+    }
+    return true;
+}
+
+GcpW resolve(const GcpOff& o, const float* base) {
+    GcpW g{};
+    g.w = (const v4f*)(base + o.w);
+    g.b = base + o.b;
+    g.w2 = o.has_w2 ? (const v4f*)(base + o.w2) : nullptr;
+    g.b2 = o.has_w2 ? base + o.b2 : nullptr;
+    g.wdd = base + o.wdd;
+    g.wg = o.has_gate ? (const v4f*)(base + o.wg) : nullptr;
+    g.bg = o.has_gate ? base + o.bg : nullptr;
+    g.wup = o.has_gate ? base + o.wup : nullptr;
+    g.G = o.G; g.H = o.H; g.V_in = o.V_in; g.V_out = o.V_out;
+    return g;
+}
+
+struct LayerOff {
+    size_t w0, wddE, wg0, bg0, wup0, wa, wpq, bpq, wddI, wddJ;
+    int G0;
+    float ba;
+    GcpOff mk[3], ff, pos;
+};
+
+void free_plan(gcdm_handle* h) {
+    if (h->d_noff) (void)hipFree(h->d_noff);
+    if (h->d_erow) (void)hipFree(h->d_erow);
+    if (h->d_ecol) (void)hipFree(h->d_ecol);
+    if (h->d_ncnt) (void)hipFree(h->d_ncnt);
+    if (h->ws) (void)hipFree(h->ws);
+    h->d_noff = h->d_erow = h->d_ecol = h->d_ncnt = nullptr;
+    h->ws = nullptr;
+    h->B = h->N = 0;
+    h->E = 0;
+}
+
+template <typename K>
+int set_lds_attr(gcdm_handle* h, K kernel, int bytes) {
+    HIP_OK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int gcdm_create(const GcdmConfig* cfg, gcdm_handle** out) {
+    if (!cfg || !out) return -1;
+    gcdm_handle* h = new (std::nothrow) gcdm_handle();
+    if (!h) return -1;
+    *out = h;
+    h->cfg = *cfg;
+    if (cfg->abi_version != GCDM_ABI_VERSION) return fail(h, "abi_version mismatch");
+    if (cfg->h_hidden_dim != GCDM_S || cfg->chi_hidden_dim != GCDM_V) return fail(h, "only h_hidden_dim=256, chi_hidden_dim=32 are built");
+    if (cfg->bottleneck != 4) return fail(h, "only bottleneck=4 is built");
+    if (!cfg->condition_on_time) return fail(h, "condition_on_time must be true");
+    if (!((cfg->e_hidden_dim == 64 && cfg->xi_hidden_dim == 16) || (cfg->e_hidden_dim == 16 && cfg->xi_hidden_dim == 8)))
+        return fail(h, "edge dims must be (64,16) [QM9] or (16,8) [GEOM]");
+    h->F = cfg->num_atom_types + (cfg->include_charges ? 1 : 0);
+    h->C = cfg->num_context;
+    h->Fin = h->F + 1 + h->C;
+    if (h->Fin > 32) return fail(h, "too many node input features (max 32)");
+    h->FinG = (h->Fin + 3) / 4;
+    h->D = 3 + h->F;
+    h->Se = cfg->e_hidden_dim;
+    h->Ve = cfg->xi_hidden_dim;
+    h->L = cfg->num_layers;
+    h->H0 = (2 * GCDM_V + h->Ve) / 4;
+    HIP_OK(h, hipSetDevice(cfg->device));
+    HIP_OK(h, hipMalloc(&h->d_flags, sizeof(uint32_t)));
+    HIP_OK(h, hipMemset(h->d_flags, 0, sizeof(uint32_t)));
+    return 0;
+}
+
+int gcdm_destroy(gcdm_handle* h) {
+    if (!h) return 0;
+    (void)hipSetDevice(h->cfg.device);
+    free_plan(h);
+    if (h->wpool) (void)hipFree(h->wpool);
+    if (h->d_flags) (void)hipFree(h->d_flags);
+    delete h;
+    return 0;
+}
+
+const char* gcdm_last_error(const gcdm_handle* h) { return h ? h->err.c_str() : "null handle"; }
+
+int gcdm_set_weight(gcdm_handle* h, const char* key, const float* host_data, int64_t numel) {
+    if (!h || !key || !host_data || numel <= 0) return fail(h, "gcdm_set_weight: bad argument");
+    h->host_w[key] = std::vector<float>(host_data, host_data + numel);
+    h->finalized = false;
+    return 0;
+}
+
+int gcdm_set_gamma(gcdm_handle* h, const float* host_gamma, int64_t numel) {
+    if (!h || !host_gamma || numel != (int64_t)h->cfg.num_timesteps + 1) return fail(h, "gcdm_set_gamma: expected num_timesteps+1 values");
+    h->gamma.assign(host_gamma, host_gamma + numel);
+    return 0;
+}
+
+int gcdm_finalize_weights(gcdm_handle* h) {
+    if (!h) return -1;
+    HIP_OK(h, hipSetDevice(h->cfg.device));
+    const int S = GCDM_S, V = GCDM_V, Se = h->Se, Ve = h->Ve, H0 = h->H0, L = h->L;
+    Pool pool;
+    // ---- edge embedding (1,1) -> (Se,Ve), bottleneck 1: H = max(1, Ve) = Ve ------------------------
+    size_t o_ws, o_bs, o_wd, o_wdf, o_kap, o_wg, o_bg;
+    {
+        const std::string p = "gcp_embedding.edge_embedding.";
+        WView ws, bs, wd, wdf, wu, wg, bg;
+        if (!get_w(h, p + "scalar_out.weight", Se, 1 + Ve + 9, ws) || !get_w(h, p + "scalar_out.bias", 1, Se, bs) ||
+            !get_w(h, p + "vector_down.weight", Ve, 1, wd) || !get_w(h, p + "vector_down_frames.weight", 3, 1, wdf) ||
+            !get_w(h, p + "vector_up.weight", Ve, Ve, wu) || !get_w(h, p + "vector_out_scale.weight", Ve, Se, wg) ||
+            !get_w(h, p + "vector_out_scale.bias", 1, Ve, bg))
+            return -1;
+        std::vector<float> kap(Ve, 0.f);
+        for (int c = 0; c < Ve; ++c) {
+            float s = 0.f;
+            for (int k = 0; k < Ve; ++k) s += wu.at(c, k) * wd.at(k, 0);
+            kap[c] = s;
+        }
+        o_ws = pool.add(*ws.v); o_bs = pool.add(*bs.v); o_wd = pool.add(*wd.v); o_wdf = pool.add(*wdf.v);
+        o_kap = pool.add(kap); o_wg = pool.add(*wg.v); o_bg = pool.add(*bg.v);
+    }
+    // ---- node embedding (Fin,2) -> (S,V), bottleneck 1 ------------------------------------------------
+    GcpOff emb, proj;
+    if (!build_gcp(h, pool, "gcp_embedding.node_embedding.", h->Fin, 2, S, V, 1, false, emb)) return -1;
+    if (!build_gcp(h, pool, "scalar_node_projection_gcp.", S, V, h->Fin, 0, 1, false, proj)) return -1;
+    std::vector<LayerOff> lo(L);
+    for (int l = 0; l < L; ++l) {
+        const std::string lp = "interaction_layers." + std::to_string(l) + ".";
+        LayerOff& o = lo[l];
+        // msg0: scalar_out split into node-level halves (PQ) and the per-edge part [e' | n | q]
+        {
+            const std::string p = lp + "interaction.message_fusion.0.";
+            const int Vin0 = 2 * V + Ve, Kin = 2 * S + Se + H0 + 9;
+            WView ws, bs, wd, wdf, wg, bg, wu;
+            if (!get_w(h, p + "scalar_out.weight", S, Kin, ws) || !get_w(h, p + "scalar_out.bias", 1, S, bs) ||
+                !get_w(h, p + "vector_down.weight", H0, Vin0, wd) || !get_w(h, p + "vector_down_frames.weight", 3, Vin0, wdf) ||
+                !get_w(h, p + "vector_out_scale.weight", V, S, wg) || !get_w(h, p + "vector_out_scale.bias", 1, V, bg) ||
+                !get_w(h, p + "vector_up.weight", V, H0, wu))
+                return -1;
+            const int SEG = Se / 4, H0G = (H0 + 3) / 4;
+            const int Kp = round_up(4 * (SEG + H0G + 3), 8);
+            Dense W0(S, Kp);
+            for (int m = 0; m < S; ++m) {
+                for (int k = 0; k < Se; ++k) W0.at(m, k) = ws.at(m, S + k);
+                for (int k = 0; k < H0; ++k) W0.at(m, 4 * SEG + k) = ws.at(m, 2 * S + Se + k);
+                for (int k = 0; k < 9; ++k) W0.at(m, 4 * (SEG + H0G) + k) = ws.at(m, 2 * S + Se + H0 + k);
+            }
+            o.w0 = pool.add(pack_mfma(W0));
+            o.G0 = Kp / 8;
+            Dense PQ(2 * S, S);
+            for (int m = 0; m < S; ++m)
+                for (int k = 0; k < S; ++k) {
+                    PQ.at(m, k) = ws.at(m, k);
+                    PQ.at(S + m, k) = ws.at(m, S + Se + k);
+                }
+            o.wpq = pool.add(pack_mfma(PQ));
+            o.bpq = pool.add(padded(bs, 2 * S));
+            std::vector<float> dI((size_t)(H0 + 3) * V), dJ((size_t)(H0 + 3) * V), dE((size_t)(H0 + 3) * Ve);
+            for (int r = 0; r < H0 + 3; ++r) {
+                const WView& src = r < H0 ? wd : wdf;
+                const int rr = r < H0 ? r : r - H0;
+                for (int c = 0; c < V; ++c) dI[(size_t)r * V + c] = src.at(rr, c);
+                for (int c = 0; c < Ve; ++c) dE[(size_t)r * Ve + c] = src.at(rr, V + c);
+                for (int c = 0; c < V; ++c) dJ[(size_t)r * V + c] = src.at(rr, V + Ve + c);
+            }
+            o.wddI = pool.add(dI); o.wddJ = pool.add(dJ); o.wddE = pool.add(dE);
+            Dense Wg(32, S);
+            for (int m = 0; m < V; ++m) for (int k = 0; k < S; ++k) Wg.at(m, k) = wg.at(m, k);
+            o.wg0 = pool.add(pack_mfma(Wg));
+            o.bg0 = pool.add(padded(bg, 32));
+            o.wup0 = pool.add(*wu.v);
+        }
+        for (int k = 1; k <= 3; ++k)
+            if (!build_gcp(h, pool, lp + "interaction.message_fusion." + std::to_string(k) + ".", S, V, S, V, 4, false, o.mk[k - 1])) return -1;
+        {
+            WView wa, ba;
+            if (!get_w(h, lp + "interaction.scalar_message_attention.0.weight", 1, S, wa) ||
+                !get_w(h, lp + "interaction.scalar_message_attention.0.bias", 1, 1, ba))
+                return -1;
+            o.wa = pool.add(*wa.v);
+            o.ba = ba.at(0, 0);
+        }
+        if (!build_gcp(h, pool, lp + "feedforward_network.0.", 2 * S, 2 * V, S, V, 4, true, o.ff)) return -1;
+        if (!build_gcp(h, pool, lp + "node_position_update_gcp.", S, V, S, 1, 4, false, o.pos)) return -1;
+    }
+    if (h->wpool) (void)hipFree(h->wpool);
+    h->wpool = nullptr;
+    HIP_OK(h, hipMalloc(&h->wpool, pool.host.size() * sizeof(float)));
+    HIP_OK(h, hipMemcpy(h->wpool, pool.host.data(), pool.host.size() * sizeof(float), hipMemcpyHostToDevice));
+    const float* base = h->wpool;
+    h->ee_ws = base + o_ws; h->ee_bs = base + o_bs; h->ee_wd = base + o_wd; h->ee_wdf = base + o_wdf;
+    h->ee_kappa = base + o_kap; h->ee_wg = base + o_wg; h->ee_bg = base + o_bg;
+    h->emb = resolve(emb, base);
+    h->proj = resolve(proj, base);
+    h->layers.resize(L);
+    for (int l = 0; l < L; ++l) {
+        const LayerOff& o = lo[l];
+        LayerDev& d = h->layers[l];
+        d.w0 = (const v4f*)(base + o.w0); d.G0 = o.G0; d.wddE = base + o.wddE;
+        d.wg0 = (const v4f*)(base + o.wg0); d.bg0 = base + o.bg0; d.wup0 = base + o.wup0;
+        for (int k = 0; k < 3; ++k) d.mk[k] = resolve(o.mk[k], base);
+        d.wa = base + o.wa; d.ba = o.ba;
+        d.ff = resolve(o.ff, base); d.pos = resolve(o.pos, base);
+        d.wpq = (const v4f*)(base + o.wpq); d.bpq = base + o.bpq; d.wddI = base + o.wddI; d.wddJ = base + o.wddJ;
+    }
+    if (!h->attr_set) {
+        if (set_lds_attr(h, k_edge_msg<64, 16>, EK_LDS_BYTES) || set_lds_attr(h, k_edge_msg<16, 8>, EK_LDS_BYTES) ||
+            set_lds_attr(h, k_node<true>, NK_LDS_BYTES) || set_lds_attr(h, k_node<false>, NK_LDS_BYTES))
+            return -1;
+        h->attr_set = true;
+    }
+    h->finalized = true;
+    h->host_w.clear();
+    return 0;
+}
+
+int gcdm_plan_batch(gcdm_handle* h, int32_t B, const int32_t* nn) {
+    if (!h || B <= 0 || !nn) return fail(h, "gcdm_plan_batch: bad argument");
+    HIP_OK(h, hipSetDevice(h->cfg.device));
+    free_plan(h);
+    std::vector<int> noff(B + 1, 0);
+    int64_t E = 0;
+    int max_n = 0;
+    for (int b = 0; b < B; ++b) {
+        if (nn[b] <= 0) return fail(h, "gcdm_plan_batch: every molecule needs >= 1 atom");
+        noff[b + 1] = noff[b] + nn[b];
+        E += (int64_t)nn[b] * nn[b];
+        max_n = std::max(max_n, (int)nn[b]);
+    }
+    if (E >= (int64_t)1 << 31) return fail(h, "gcdm_plan_batch: too many edges");
+    if (max_n > 4096) return fail(h, "gcdm_plan_batch: molecule too large");
+    const int N = noff[B];
+    std::vector<int> erow(E), ecol(E), ncnt(N);
+    int64_t p = 0;
+    for (int b = 0; b < B; ++b) {
+        const int o = noff[b], n = nn[b];
+        for (int i = 0; i < n; ++i) {
+            ncnt[o + i] = n;
+            for (int j = 0; j < n; ++j, ++p) { erow[p] = o + i; ecol[p] = o + j; }
+        }
+    }
+    HIP_OK(h, hipMalloc(&h->d_noff, (B + 1) * sizeof(int)));
+    HIP_OK(h, hipMalloc(&h->d_erow, E * sizeof(int)));
+    HIP_OK(h, hipMalloc(&h->d_ecol, E * sizeof(int)));
+    HIP_OK(h, hipMalloc(&h->d_ncnt, N * sizeof(int)));
+    HIP_OK(h, hipMemcpy(h->d_noff, noff.data(), (B + 1) * sizeof(int), hipMemcpyHostToDevice));
+    HIP_OK(h, hipMemcpy(h->d_erow, erow.data(), E * sizeof(int), hipMemcpyHostToDevice));
+    HIP_OK(h, hipMemcpy(h->d_ecol, ecol.data(), E * sizeof(int), hipMemcpyHostToDevice));
+    HIP_OK(h, hipMemcpy(h->d_ncnt, ncnt.data(), N * sizeof(int), hipMemcpyHostToDevice));
+    // workspace (all sub-buffers 16-byte aligned)
+    size_t off = 0;
+    auto take = [&](size_t n) { size_t o = off; off += (n + 3) & ~size_t(3); return o; };
+    const size_t n = (size_t)N, e = (size_t)E;
+    const size_t oX0 = take(3 * n), oXC = take(3 * n), oFB = take(9 * n), oC0 = take(6 * n), oHIN = take(4 * h->FinG * n), oH4 = take(GCDM_S * n),
+                 oCHI = take(96 * n), oPQ = take(512 * n), oVDI = take((size_t)(h->H0 + 3) * 3 * n), oVDJ = take((size_t)(h->H0 + 3) * 3 * n),
+                 oAGG = take(GCDM_AGGW * n), oVEL = take(3 * n), oEPS = take((size_t)h->D * n), oT = take(n), oEP = take((size_t)h->Se * e),
+                 oAL = take((size_t)h->Ve * e), oU = take(3 * e), oFR = take(9 * e);
+    h->ws_floats = off;
+    HIP_OK(h, hipMalloc(&h->ws, off * sizeof(float)));
+    HIP_OK(h, hipMemset(h->ws, 0, off * sizeof(float)));
+    float* w = h->ws;
+    h->X0 = w + oX0; h->XC = w + oXC; h->FBAR = w + oFB; h->CHI0 = w + oC0; h->HIN4 = w + oHIN; h->H4 = w + oH4; h->CHI = w + oCHI;
+    h->PQ4 = w + oPQ; h->VDI = w + oVDI; h->VDJ = w + oVDJ; h->AGG = w + oAGG; h->VEL = w + oVEL; h->EPS = w + oEPS; h->TBUF = w + oT; h->EP4 = w + oEP;
+    h->AL = w + oAL; h->U = w + oU; h->FR = w + oFR;
+    h->B = B; h->N = N; h->E = E; h->max_n = max_n;
+    return 0;
+}
+
+int64_t gcdm_num_nodes(const gcdm_handle* h) { return h ? h->N : -1; }
+int64_t gcdm_num_edges(const gcdm_handle* h) { return h ? h->E : -1; }
+
+int gcdm_debug_set_layer_limit(gcdm_handle* h, int32_t n) {
+    if (!h) return -1;
+    h->layer_limit = n;
+    return 0;
+}
+
+int gcdm_forward(gcdm_handle* h, const float* xh, const float* t, const float* context, float* out, uint32_t* flags, void* stream_) {
+    if (!h) return -1;
+    if (!h->finalized) return fail(h, "gcdm_forward: weights not finalized");
+    if (!h->N) return fail(h, "gcdm_forward: no batch plan");
+    if (!xh || !t || !out) return fail(h, "gcdm_forward: null tensor");
+    if (h->C && !context) return fail(h, "gcdm_forward: context required");
+    hipStream_t st = (hipStream_t)stream_;
+    const int N = h->N, B = h->B;
+    const int E = (int)h->E;
+    HIP_OK(h, hipMemsetAsync(h->d_flags, 0, sizeof(uint32_t), st));
+    PrepArgs pa{xh, t, context, h->d_noff, N, h->F, h->C, h->FinG, h->X0, h->XC, h->FBAR, h->CHI0, (v4f*)h->HIN4};
+    hipLaunchKernelGGL(k_prep, dim3(B), dim3(64), 3 * h->max_n * sizeof(float), st, pa);
+    EdgeEmbedArgs ea{h->X0, h->XC, N, h->d_erow, h->d_ecol, E, h->ee_ws, h->ee_bs, h->ee_wd, h->ee_wdf, h->ee_kappa, h->ee_wg, h->ee_bg,
+                     (v4f*)h->EP4, h->AL, h->U, h->FR};
+    const int egrid = (E + 255) / 256;
+    if (h->Se == 64) hipLaunchKernelGGL((k_edge_embed<64, 16>), dim3(egrid), dim3(256), 0, st, ea);
+    else hipLaunchKernelGGL((k_edge_embed<16, 8>), dim3(egrid), dim3(256), 0, st, ea);
+
+    const int L = (h->layer_limit >= 0 && h->layer_limit < h->L) ? h->layer_limit : h->L;
+    const bool truncated = L < h->L;
+    NodeArgs na{};
+    na.N = N; na.F = h->F; na.C = h->C; na.FinG = h->FinG; na.Dout = h->D; na.pos_weight = h->cfg.node_positions_weight;
+    na.HIN4 = (const v4f*)h->HIN4; na.CHI0 = h->CHI0; na.emb = h->emb;
+    na.AGG = h->AGG; na.H4 = (v4f*)h->H4; na.CHI = h->CHI; na.XC = h->XC; na.X0 = h->X0; na.FBAR = h->FBAR;
+    na.PQ4 = (v4f*)h->PQ4; na.VDI = h->VDI; na.VDJ = h->VDJ; na.H0 = h->H0;
+    na.proj = h->proj; na.OUT = out; na.VEL = h->VEL; na.flags_dev = h->d_flags;
+    auto set_next = [&](int l) {
+        if (l < h->L) {
+            const LayerDev& d = h->layers[l];
+            na.has_next = 1; na.wpq = d.wpq; na.bpq = d.bpq; na.wddI = d.wddI; na.wddJ = d.wddJ;
+        } else {
+            na.has_next = 0;
+        }
+    };
+    const int ngrid = (N + NT_ - 1) / NT_;
+    set_next(0);
+    hipLaunchKernelGGL(k_node<true>, dim3(ngrid), dim3(256), NK_LDS_BYTES, st, na);
+    const int tiles = (E + ET - 1) / ET;
+    for (int l = 0; l < L; ++l) {
+        const LayerDev& d = h->layers[l];
+        HIP_OK(h, hipMemsetAsync(h->AGG, 0, (size_t)N * GCDM_AGGW * sizeof(float), st));
+        EdgeMsgArgs ma{};
+        ma.EP4 = (const v4f*)h->EP4; ma.AL = h->AL; ma.U = h->U; ma.FR = h->FR; ma.EROW = h->d_erow; ma.ECOL = h->d_ecol; ma.NCNT = h->d_ncnt;
+        ma.E = E; ma.N = N; ma.PQ4 = (const v4f*)h->PQ4; ma.VDI = h->VDI; ma.VDJ = h->VDJ; ma.AGG = h->AGG;
+        ma.w0 = d.w0; ma.G0 = d.G0; ma.wddE = d.wddE; ma.wg0 = d.wg0; ma.bg0 = d.bg0; ma.wup0 = d.wup0;
+        for (int k = 0; k < 3; ++k) ma.mk[k] = d.mk[k];
+        ma.wa = d.wa; ma.ba = d.ba;
+        if (h->Se == 64) hipLaunchKernelGGL((k_edge_msg<64, 16>), dim3(tiles), dim3(256), EK_LDS_BYTES, st, ma);
+        else hipLaunchKernelGGL((k_edge_msg<16, 8>), dim3(tiles), dim3(256), EK_LDS_BYTES, st, ma);
+        na.ff = d.ff; na.pos = d.pos;
+        set_next(l + 1);   // next layer's msg0 halves, or the output projection after the last layer
+        hipLaunchKernelGGL(k_node<false>, dim3(ngrid), dim3(256), NK_LDS_BYTES, st, na);
+    }
+    if (!truncated) {
+        FinishArgs fa{h->VEL, h->d_noff, N, h->D, out, h->d_flags, flags};
+        hipLaunchKernelGGL(k_finish, dim3(B), dim3(64), 0, st, fa);
+    }
+    HIP_OK(h, hipGetLastError());
+    return 0;
+}
+
+// ---- sampler ------------------------------------------------------------------------------------
+static inline float softplusf(float x) { return x > 20.f ? x : log1pf(expf(x)); }               // torch F.softplus (threshold 20)
+static inline float logsigmoidf(float x) { return x < 0.f ? x - log1pf(expf(x)) : -log1pf(expf(-x)); }
+static inline float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+static float gamma_lookup(const gcdm_handle* h, float t) {
+    long idx = lroundf(t * (float)h->cfg.num_timesteps);   // torch.round(t * T).long()  (variational_diffusion.py:252-255)
+    if (idx < 0) idx = 0;
+    if (idx > h->cfg.num_timesteps) idx = h->cfg.num_timesteps;
+    return h->gamma[idx];
+}
+
+static int launch_sample(gcdm_handle* h, StepArgs& sa, hipStream_t st) {
+    sa.noff = h->d_noff; sa.N = h->N; sa.D = h->D;
+    hipLaunchKernelGGL(k_sample, dim3(h->B), dim3(64), (size_t)h->max_n * h->D * sizeof(float), st, sa);
+    HIP_OK(h, hipGetLastError());
+    return 0;
+}
+
+int gcdm_sample_init(gcdm_handle* h, float* z, const float* noise, uint64_t seed, void* stream_) {
+    if (!h || !z || !h->N) return fail(h, "gcdm_sample_init: bad argument / no plan");
+    StepArgs sa{};
+    sa.z = z; sa.noise = noise; sa.seed = seed; sa.draw = 0x7fffffffu; sa.mode = 1; sa.flags_dev = h->d_flags;
+    return launch_sample(h, sa, (hipStream_t)stream_);
+}
+
+static int fill_t(gcdm_handle* h, float value, hipStream_t st) {
+    hipLaunchKernelGGL(k_fill, dim3((h->N + 255) / 256), dim3(256), 0, st, h->TBUF, h->N, value);
+    HIP_OK(h, hipGetLastError());
+    return 0;
+}
+
+int gcdm_sample_step(gcdm_handle* h, float* z, const float* context, int32_t s_index, int32_t num_steps, const float* noise, uint64_t seed,
+                     uint32_t* flags, void* stream_) {
+    if (!h || !z || num_steps <= 0 || s_index < 0 || s_index >= num_steps) return fail(h, "gcdm_sample_step: bad argument");
+    if ((int64_t)h->gamma.size() != (int64_t)h->cfg.num_timesteps + 1) return fail(h, "gcdm_sample_step: gamma table not set");
+    hipStream_t st = (hipStream_t)stream_;
+    // s = s_index / num_steps, t = (s_index + 1) / num_steps (variational_diffusion.py:1335-1341); t [N] = t[batch_index] (:1239)
+    const float s = (float)s_index / (float)num_steps, t = (float)(s_index + 1) / (float)num_steps;
+    if (fill_t(h, t, st)) return -1;
+    if (gcdm_forward(h, z, h->TBUF, context, h->EPS, flags, stream_)) return -1;
+    const float gs = gamma_lookup(h, s), gt = gamma_lookup(h, t);
+    // sigma_and_alpha_t_given_s (:342-367), sigma (:318-325)
+    const float s2ts = -expm1f(softplusf(gs) - softplusf(gt));
+    const float alpha_ts = expf(0.5f * (logsigmoidf(-gt) - logsigmoidf(-gs)));
+    const float sts = sqrtf(s2ts), sig_s = sqrtf(sigmoidf_(gs)), sig_t = sqrtf(sigmoidf_(gt));
+    StepArgs sa{};
+    sa.z = z; sa.eps = h->EPS; sa.noise = noise; sa.seed = seed; sa.draw = (uint32_t)s_index; sa.mode = 0;
+    sa.alpha_coef = alpha_ts;
+    sa.c_eps = s2ts / alpha_ts / sig_t;
+    sa.sigma = sts * sig_s / sig_t;
+    sa.user_flags = flags; sa.flags_dev = h->d_flags;
+    return launch_sample(h, sa, st);
+}
+
+int gcdm_sample_final(gcdm_handle* h, const float* z0, const float* context, const float* noise, uint64_t seed, float* out, uint32_t* flags,
+                      void* stream_) {
+    if (!h || !z0 || !out) return fail(h, "gcdm_sample_final: bad argument");
+    if ((int64_t)h->gamma.size() != (int64_t)h->cfg.num_timesteps + 1) return fail(h, "gcdm_sample_final: gamma table not set");
+    hipStream_t st = (hipStream_t)stream_;
+    if (fill_t(h, 0.0f, st)) return -1;
+    if (gcdm_forward(h, z0, h->TBUF, context, h->EPS, flags, stream_)) return -1;
+    const float g0 = gamma_lookup(h, 0.0f);
+    const float sigma_x = expf(0.5f * g0);                       // SNR(-0.5 * gamma_0)   (:855-859)
+    const float sig0 = sqrtf(sigmoidf_(g0)), alp0 = sqrtf(sigmoidf_(-g0));
+    StepArgs sa{};
+    sa.z = const_cast<float*>(z0); sa.eps = h->EPS; sa.noise = noise; sa.seed = seed; sa.draw = 0x7ffffffeu; sa.mode = 2;
+    sa.alpha_coef = 1.0f / alp0; sa.c_eps = sig0; sa.sigma = sigma_x;
+    sa.out = out; sa.num_atom_types = h->cfg.num_atom_types; sa.include_charges = h->cfg.include_charges;
+    sa.nv0 = h->cfg.norm_values[0]; sa.nv1 = h->cfg.norm_values[1]; sa.nv2 = h->cfg.norm_values[2];
+    sa.nb1 = h->cfg.norm_biases[1]; sa.nb2 = h->cfg.norm_biases[2];
+    sa.user_flags = flags; sa.flags_dev = h->d_flags;
+    if (launch_sample(h, sa, st)) return -1;
+    // CoG drift re-projection is a whole-batch decision in the reference (:1389-1402)
+    hipLaunchKernelGGL(k_cog_fix, dim3(h->B), dim3(64), 0, st, out, h->d_noff, h->D, h->d_flags, flags);
+    HIP_OK(h, hipGetLastError());
+    return 0;
+}
+
+int64_t gcdm_debug_read(gcdm_handle* h, const char* name, float* host_out, int64_t capacity) {
+    if (!h || !name || !h->N) return fail(h, "gcdm_debug_read: bad argument / no plan");
+    const int64_t n = h->N, e = h->E;
+    const std::string k(name);
+    const float* p = nullptr;
+    int64_t cnt = 0;
+    if (k == "h") { p = h->H4; cnt = GCDM_S * n; }
+    else if (k == "chi") { p = h->CHI; cnt = 96 * n; }
+    else if (k == "x") { p = h->XC; cnt = 3 * n; }
+    else if (k == "x0") { p = h->X0; cnt = 3 * n; }
+    else if (k == "agg") { p = h->AGG; cnt = GCDM_AGGW * n; }
+    else if (k == "ep") { p = h->EP4; cnt = (int64_t)h->Se * e; }
+    else if (k == "alpha") { p = h->AL; cnt = (int64_t)h->Ve * e; }
+    else if (k == "u") { p = h->U; cnt = 3 * e; }
+    else if (k == "frames") { p = h->FR; cnt = 9 * e; }
+    else if (k == "pq") { p = h->PQ4; cnt = 512 * n; }
+    else if (k == "vdi") { p = h->VDI; cnt = (int64_t)(h->H0 + 3) * 3 * n; }
+    else if (k == "vdj") { p = h->VDJ; cnt = (int64_t)(h->H0 + 3) * 3 * n; }
+    else if (k == "hin") { p = h->HIN4; cnt = 4 * (int64_t)h->FinG * n; }
+    else if (k == "fbar") { p = h->FBAR; cnt = 9 * n; }
+    else if (k == "chi0") { p = h->CHI0; cnt = 6 * n; }
+    else if (k == "vel") { p = h->VEL; cnt = 3 * n; }
+    else return fail(h, "gcdm_debug_read: unknown buffer " + k);
+    if (!host_out) return cnt;
+    if (capacity < cnt) return fail(h, "gcdm_debug_read: capacity too small");
+    if (hipSetDevice(h->cfg.device) != hipSuccess || hipDeviceSynchronize() != hipSuccess ||
+        hipMemcpy(host_out, p, cnt * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess)
+        return fail(h, "gcdm_debug_read: copy failed");
+    return cnt;
+}
+
+double gcdm_forward_flops_executed(const gcdm_handle* h) {
+    if (!h || !h->N) return 0.0;
+    // MFMA + VALU multiply-adds actually issued per forward (x2), see DESIGN.md section 4
+    const double N = h->N, E = (double)h->E, S = GCDM_S, V = GCDM_V, Se = h->Se, Ve = h->Ve, H0 = h->H0;
+    const double G0 = h->layers.empty() ? 0 : h->layers[0].G0;
+    const double msg0 = 8.0 * G0 * S + 32.0 * S + (H0 + 3) * (Ve + 2) * 1.0 + 3.0 * V * H0;
+    const double msgk = 280.0 * S + 32.0 * S + 11.0 * 3 * V + 3.0 * V * 8;
+    const double edge = msg0 + 3 * msgk + S;
+    const double node = 544.0 * S + S * S + 32.0 * S + 19.0 * 3 * 2 * V + 3.0 * V * 16      // ff
+                        + 280.0 * S + 32.0 * S + 11.0 * 3 * V + 3.0 * 8                       // pos
+                        + 512.0 * S + 2.0 * (H0 + 3) * 3 * V;                                 // next-layer halves
+    const double emb_e = Se * (1 + Ve + 9) + Ve * Se, emb_n = 8.0 * h->emb.G * S + 32.0 * S + 35.0 * 3 * 2 + 3.0 * V * 32;
+    const double proj = 8.0 * h->proj.G * 32 + 35.0 * 3 * V;
+    return 2.0 * (h->L * (E * edge + N * node) + E * emb_e + N * (emb_n + proj));
+}
+
+}  // extern "C"

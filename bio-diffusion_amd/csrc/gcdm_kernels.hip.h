@@ -1,0 +1,981 @@
+// gcdm_kernels.hip.h -- device code of libgcdm_hip.so (gfx950 / CDNA4 only).
+//
+// Formulation.  Every dense map of the network is evaluated TRANSPOSED,
+//     Out^T[M, T] = W[M, K] . X[K, T]
+// with the T "entities" of a tile (64 flat edges, or 32 nodes) on the MFMA column / lane axis and the
+// feature channels on the row axis, using v_mfma_f32_32x32x2_f32 (exact fp32, 64 FLOP/clk/SIMD):
+//   * X lives in LDS as float4 "channel groups":  XS4[g][e] = channels 4g..4g+3 of entity e;
+//   * a wave's B operand for 8 consecutive channels is one ds_read_b128 per N-tile
+//     (lanes 0-31 take group 2g, lanes 32-63 group 2g+1 -- the contraction order is free);
+//   * W is pre-packed on the host so that a lane's A operands for the same 4 MFMAs are one
+//     global_load_dwordx4 (each wave owns its own M-tiles: weights go L2 -> VGPR, no LDS staging);
+//   * the 32x32 accumulator layout (lane = entity, regs = channels 8q+4*half+{0..3}) is exactly a
+//     float4 channel group, so results go back to LDS with ds_write_b128 and can also be fed straight
+//     back as a B operand (the vector-gate GEMM contracts over the channels a wave already holds).
+//
+// Reference semantics follow oracle/gcdm_oracle.py <-> src/models/components/gcpnet.py (cited per kernel).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef float v4f __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define GCDM_S 256      // h_hidden_dim
+#define GCDM_V 32       // chi_hidden_dim
+#define GCDM_SG 64      // scalar channel groups (S/4)
+#define GCDM_AGGW 352   // S + 3V : width of one aggregated message row
+
+#define MFMA32(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
+
+__device__ __forceinline__ float fast_sigmoid(float x) { return __frcp_rn(1.0f + __expf(-x)); }
+__device__ __forceinline__ float fast_silu(float x) { return x * fast_sigmoid(x); }
+
+// ------------------------------------------------------------------------------------------------
+// packed weights of one GCP2 (gcpnet.py:265-491, production config) as the kernels consume them
+// ------------------------------------------------------------------------------------------------
+struct GcpW {
+    const v4f* w;      // scalar_out packed [M'/32][G][64] float4   (K' = 8G)
+    const float* b;    // scalar_out bias [M'] (zero padded)
+    const v4f* w2;     // feed-forward second Linear packed [8][32][64] (or null)
+    const float* b2;   // [256]
+    const float* wdd;  // [(H+3)][V_in]: vector_down rows, then the 3 vector_down_frames rows
+    const v4f* wg;     // vector_out_scale packed [1][32][64] (K = 256), rows >= V_out are zero
+    const float* bg;   // [32]
+    const float* wup;  // vector_up [V_out][H]
+    int G;             // k-groups (of 8 channels) of the scalar_out GEMM
+    int H;             // hidden vector channels
+    int V_in;
+    int V_out;
+};
+
+// ------------------------------------------------------------------------------------------------
+// tile GEMM:  acc[m][n] += Wpacked(M-tiles mt0..mt0+MT-1) . XS4(groups gbase .. gbase+2G-1)
+// ------------------------------------------------------------------------------------------------
+template <int MT, int NT>
+__device__ __forceinline__ void tile_gemm(f32x16 (&acc)[MT][NT], const v4f* __restrict__ wp, int G,
+                                          const v4f* xs4, int TP, int lane) {
+    const v4f* wl = wp + lane;
+    const v4f* sl = xs4 + (lane >> 5) * TP + (lane & 31);
+    const int wstride = G * 64;
+    v4f a_cur[MT], a_nxt[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) a_cur[m] = wl[m * wstride];
+    for (int g = 0; g < G; ++g) {
+        const int gn = (g + 1 < G) ? g + 1 : g;
+#pragma unroll
+        for (int m = 0; m < MT; ++m) a_nxt[m] = wl[m * wstride + gn * 64];
+        v4f b[NT];
+#pragma unroll
+        for (int n = 0; n < NT; ++n) b[n] = sl[(2 * g) * TP + n * 32];
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int n = 0; n < NT; ++n) acc[m][n] = MFMA32(a_cur[m][t], b[n][t], acc[m][n]);
+#pragma unroll
+        for (int m = 0; m < MT; ++m) a_cur[m] = a_nxt[m];
+    }
+}
+
+// acc[m][n][r] <- bias[channel(r)]   (channel = 32*(mt0+m) + 8*(r>>2) + 4*half + (r&3))
+template <int MT, int NT>
+__device__ __forceinline__ void acc_init_bias(f32x16 (&acc)[MT][NT], const float* __restrict__ bias, int mt0, int lane) {
+    const int half = lane >> 5;
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const v4f bv = *(const v4f*)(bias + 32 * (mt0 + m) + 8 * q + 4 * half);
+#pragma unroll
+            for (int n = 0; n < NT; ++n)
+#pragma unroll
+                for (int t = 0; t < 4; ++t) acc[m][n][4 * q + t] = bv[t];
+        }
+}
+
+// partial vector-gate GEMM over the channels this wave holds: gacc[n] += Wg[:, own channels] . act[own channels, :]
+template <int MT, int NT>
+__device__ __forceinline__ void gate_partial(f32x16 (&gacc)[NT], const f32x16 (&act)[MT][NT],
+                                             const v4f* __restrict__ wg, int mt0, int lane) {
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const v4f a = wg[(4 * (mt0 + m) + q) * 64 + lane];
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int n = 0; n < NT; ++n) gacc[n] = MFMA32(a[t], act[m][n][4 * q + t], gacc[n]);
+        }
+}
+
+// PG[wave][c][e] <- gacc  (c = 8*(r>>2) + 4*half + (r&3))
+template <int NT>
+__device__ __forceinline__ void store_gate_partial(float* PG, const f32x16 (&gacc)[NT], int TP, int wave, int lane) {
+    const int half = lane >> 5, l31 = lane & 31;
+#pragma unroll
+    for (int n = 0; n < NT; ++n)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int c = (r & 3) + 8 * (r >> 2) + 4 * half;
+            PG[(wave * 32 + c) * TP + 32 * n + l31] = gacc[n][r];
+        }
+}
+
+// XS4[gbase + own groups][e] (+)= acc
+template <int MT, int NT, bool ADD>
+__device__ __forceinline__ void store_state(v4f* xs4, int gbase, const f32x16 (&acc)[MT][NT], int TP, int mt0, int lane) {
+    const int half = lane >> 5, l31 = lane & 31;
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int idx = (gbase + 8 * (mt0 + m) + 2 * q + half) * TP + 32 * n + l31;
+                v4f v = {acc[m][n][4 * q], acc[m][n][4 * q + 1], acc[m][n][4 * q + 2], acc[m][n][4 * q + 3]};
+                if (ADD) v += xs4[idx];
+                xs4[idx] = v;
+            }
+}
+
+template <int MT, int NT>
+__device__ __forceinline__ void apply_silu(f32x16 (&acc)[MT][NT]) {
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[m][n][r] = fast_silu(acc[m][n][r]);
+}
+
+// ------------------------------------------------------------------------------------------------
+// GCP2 pre-phase for entity e (gcpnet.py:442-459 + scalarize components/__init__.py:174-219):
+//   vh = W_down v ; n = sqrt(sum_xyz vh^2 + 1e-8) + 1e-8 ; u = W_frames v ; q[3k+r] = F[r,:].u[:,k]
+// rows hh of [W_down; W_frames] are split over the PARTS threads that share an entity.
+// ------------------------------------------------------------------------------------------------
+template <int T>
+__device__ __forceinline__ void gcp2_pre(const float* __restrict__ wdd, int H, int V_in, const float* VV, int vch0,
+                                         const float* FR, float* XSf, int gN, int gQ, int gEnd, float* VH, int e,
+                                         int part) {
+    constexpr int TP = T + 1, PARTS = 256 / T;
+    float f[9];
+#pragma unroll
+    for (int r = 0; r < 9; ++r) f[r] = FR[r * TP + e];
+    for (int hh = part; hh < H + 3; hh += PARTS) {
+        const float* w = wdd + hh * V_in;
+        const float* vp = VV + (vch0 * 3) * TP + e;
+        float vx = 0.f, vy = 0.f, vz = 0.f;
+        for (int c = 0; c < V_in; ++c) {
+            const float wc = w[c];
+            vx += wc * vp[0];
+            vy += wc * vp[TP];
+            vz += wc * vp[2 * TP];
+            vp += 3 * TP;
+        }
+        if (hh < H) {
+            XSf[((gN + (hh >> 2)) * TP + e) * 4 + (hh & 3)] = sqrtf(vx * vx + vy * vy + vz * vz + 1e-8f) + 1e-8f;
+            VH[(hh * 3 + 0) * TP + e] = vx;
+            VH[(hh * 3 + 1) * TP + e] = vy;
+            VH[(hh * 3 + 2) * TP + e] = vz;
+        } else {
+            const int k = hh - H;
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+                const int idx = 3 * k + r;
+                XSf[((gQ + (idx >> 2)) * TP + e) * 4 + (idx & 3)] = f[3 * r] * vx + f[3 * r + 1] * vy + f[3 * r + 2] * vz;
+            }
+        }
+    }
+    if (part == 0) {  // zero the padding slots of the extended-K rows (weights there are zero, LDS is not)
+        for (int hh = H; hh < 4 * (gQ - gN); ++hh) XSf[((gN + (hh >> 2)) * TP + e) * 4 + (hh & 3)] = 0.f;
+        for (int idx = 9; idx < 12; ++idx) XSf[((gQ + (idx >> 2)) * TP + e) * 4 + (idx & 3)] = 0.f;
+        for (int g = gQ + 3; g < gEnd; ++g) ((v4f*)XSf)[g * TP + e] = (v4f){0.f, 0.f, 0.f, 0.f};
+    }
+}
+
+// vector output: v'[c] = (W_up vh)[c] * sigmoid(gate[c])  (gcpnet.py:388-411); channels split over PARTS threads
+template <int T, typename StoreFn>
+__device__ __forceinline__ void vec_finish(const float* PG, const float* __restrict__ bg, const float* __restrict__ wup,
+                                           int H, int V_out, const float* VH, int e, int part, StoreFn store) {
+    constexpr int TP = T + 1, PARTS = 256 / T;
+    for (int c = part; c < V_out; c += PARTS) {
+        float g = bg[c];
+#pragma unroll
+        for (int w = 0; w < 4; ++w) g += PG[(w * 32 + c) * TP + e];
+        const float sg = fast_sigmoid(g);
+        float ox = 0.f, oy = 0.f, oz = 0.f;
+        const float* wu = wup + c * H;
+        for (int h = 0; h < H; ++h) {
+            const float wv = wu[h];
+            ox += wv * VH[(h * 3 + 0) * TP + e];
+            oy += wv * VH[(h * 3 + 1) * TP + e];
+            oz += wv * VH[(h * 3 + 2) * TP + e];
+        }
+        store(c, ox * sg, oy * sg, oz * sg);
+    }
+}
+
+__device__ __forceinline__ void frame_of(float xi0, float xi1, float xi2, float xj0, float xj1, float xj2, float (&f)[9]) {
+    // localize, components/__init__.py:122-171 (norm_x_diff=True)
+    float d0 = xi0 - xj0, d1 = xi1 - xj1, d2 = xi2 - xj2;
+    float c0 = xi1 * xj2 - xi2 * xj1, c1 = xi2 * xj0 - xi0 * xj2, c2 = xi0 * xj1 - xi1 * xj0;
+    const float dn = sqrtf(d0 * d0 + d1 * d1 + d2 * d2) + 1.0f;
+    const float cn = sqrtf(c0 * c0 + c1 * c1 + c2 * c2) + 1.0f;
+    d0 /= dn; d1 /= dn; d2 /= dn;
+    c0 /= cn; c1 /= cn; c2 /= cn;
+    f[0] = d0; f[1] = d1; f[2] = d2;
+    f[3] = c0; f[4] = c1; f[5] = c2;
+    f[6] = d1 * c2 - d2 * c1; f[7] = d2 * c0 - d0 * c2; f[8] = d0 * c1 - d1 * c0;
+}
+
+// ================================================================================================
+// K1  prep: one workgroup per molecule (gcpnet.py:1081-1109, 1142-1166; scalarize node-mode mean)
+// ================================================================================================
+struct PrepArgs {
+    const float* xh;   // [N][3+F]
+    const float* t;    // [N]
+    const float* ctx;  // [N][C] or null
+    const int* noff;   // [B+1]
+    int N, F, C, FinG; // FinG = ceil((F+1+C)/4)
+    float* X0;         // [3][N] un-centralised positions
+    float* XC;         // [3][N] centralised positions (updated in place by the layers)
+    float* FBAR;       // [9][N] mean_j f_ij
+    float* CHI0;       // [6][N] orientations (flat-batch adjacency)
+    v4f* HIN4;         // [FinG][N]
+};
+
+__global__ __launch_bounds__(64) void k_prep(PrepArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float xs[];  // [3][n] centralised
+    const int b = blockIdx.x, o = a.noff[b], n = a.noff[b + 1] - o, D = 3 + a.F;
+    float m0 = 0.f, m1 = 0.f, m2 = 0.f;
+    for (int i = 0; i < n; ++i) {  // same summation order as scatter(sum) over a sorted index
+        const float* p = a.xh + (size_t)(o + i) * D;
+        m0 += p[0]; m1 += p[1]; m2 += p[2];
+    }
+    m0 /= (float)n; m1 /= (float)n; m2 /= (float)n;
+    for (int i = threadIdx.x; i < n; i += 64) {
+        const int g = o + i;
+        const float* p = a.xh + (size_t)g * D;
+        const float x0 = p[0], x1 = p[1], x2 = p[2];
+        a.X0[g] = x0; a.X0[a.N + g] = x1; a.X0[2 * a.N + g] = x2;
+        const float c0 = x0 - m0, c1 = x1 - m1, c2 = x2 - m2;
+        a.XC[g] = c0; a.XC[a.N + g] = c1; a.XC[2 * a.N + g] = c2;
+        xs[i] = c0; xs[n + i] = c1; xs[2 * n + i] = c2;
+        // orientations (protein_graph_dataset.py:217-225): flat neighbours, zero padded at the global ends
+        float fw[3] = {0.f, 0.f, 0.f}, bw[3] = {0.f, 0.f, 0.f};
+        if (g + 1 < a.N) {
+            const float* q = p + D;
+            const float e0 = q[0] - x0, e1 = q[1] - x1, e2 = q[2] - x2, nr = sqrtf(e0 * e0 + e1 * e1 + e2 * e2);
+            if (nr > 0.f) { fw[0] = e0 / nr; fw[1] = e1 / nr; fw[2] = e2 / nr; }
+        }
+        if (g > 0) {
+            const float* q = p - D;
+            const float e0 = q[0] - x0, e1 = q[1] - x1, e2 = q[2] - x2, nr = sqrtf(e0 * e0 + e1 * e1 + e2 * e2);
+            if (nr > 0.f) { bw[0] = e0 / nr; bw[1] = e1 / nr; bw[2] = e2 / nr; }
+        }
+#pragma unroll
+        for (int x = 0; x < 3; ++x) { a.CHI0[x * a.N + g] = fw[x]; a.CHI0[(3 + x) * a.N + g] = bw[x]; }
+        // h_in = [h0 | t | context], zero padded to a whole number of float4 groups
+        const int Fin = a.F + 1 + a.C;
+        for (int gg = 0; gg < a.FinG; ++gg) {
+            v4f v;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int c = 4 * gg + k;
+                float val = 0.f;
+                if (c < a.F) val = p[3 + c];
+                else if (c == a.F) val = a.t[g];
+                else if (c < Fin) val = a.ctx[(size_t)g * a.C + (c - a.F - 1)];
+                v[k] = val;
+            }
+            a.HIN4[(size_t)gg * a.N + g] = v;
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < n; i += 64) {
+        float s[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, f[9];
+        const float xi0 = xs[i], xi1 = xs[n + i], xi2 = xs[2 * n + i];
+        for (int j = 0; j < n; ++j) {
+            frame_of(xi0, xi1, xi2, xs[j], xs[n + j], xs[2 * n + j], f);
+#pragma unroll
+            for (int r = 0; r < 9; ++r) s[r] += f[r];
+        }
+#pragma unroll
+        for (int r = 0; r < 9; ++r) a.FBAR[r * a.N + o + i] = s[r] / (float)n;
+    }
+}
+
+// ================================================================================================
+// K2  edge geometry + edge embedding GCP2 (1,1)->(Se,Ve): one thread per edge
+//     (edm_dataset.py:22-38, components/__init__.py:122-171, gcpnet.py:584-590)
+// ================================================================================================
+struct EdgeEmbedArgs {
+    const float* X0; const float* XC; int N;
+    const int* EROW; const int* ECOL; int E;
+    const float* ws;    // scalar_out.weight [Se][1+Ve+9]
+    const float* bs;    // [Se]
+    const float* wd;    // vector_down.weight [Ve]  (Ve x 1)
+    const float* wdf;   // vector_down_frames.weight [3]
+    const float* kappa; // [Ve] = vector_up.weight @ vector_down.weight
+    const float* wg;    // vector_out_scale.weight [Ve][Se]
+    const float* bg;    // [Ve]
+    v4f* EP4;           // [Se/4][E]   e' (SiLU'd scalar edge features)
+    float* AL;          // [Ve][E]     xi'_c = AL[c] * U
+    float* U;           // [3][E]      unit vector (0 for self loops)
+    float* FR;          // [9][E]      frames
+};
+
+template <int SE, int VE>
+__global__ __launch_bounds__(256) void k_edge_embed(EdgeEmbedArgs a) {
+    const int eid = blockIdx.x * 256 + threadIdx.x;
+    if (eid >= a.E) return;
+    const int i = a.EROW[eid], j = a.ECOL[eid], N = a.N, E = a.E;
+    // e = |x_i - x_j|^2, xi = unit vector, both from the UN-centralised positions (gcpnet.py:1102,1109)
+    const float d0 = a.X0[i] - a.X0[j], d1 = a.X0[N + i] - a.X0[N + j], d2 = a.X0[2 * N + i] - a.X0[2 * N + j];
+    const float es = d0 * d0 + d1 * d1 + d2 * d2;
+    const float nr = sqrtf(es);
+    float u[3] = {0.f, 0.f, 0.f};
+    if (nr > 0.f) { u[0] = d0 / nr; u[1] = d1 / nr; u[2] = d2 / nr; }
+    float f[9];
+    frame_of(a.XC[i], a.XC[N + i], a.XC[2 * N + i], a.XC[j], a.XC[N + j], a.XC[2 * N + j], f);
+#pragma unroll
+    for (int r = 0; r < 9; ++r) a.FR[(size_t)r * E + eid] = f[r];
+#pragma unroll
+    for (int x = 0; x < 3; ++x) a.U[(size_t)x * E + eid] = u[x];
+    constexpr int KIN = 1 + VE + 9;
+    float in[KIN];
+    in[0] = es;
+#pragma unroll
+    for (int h = 0; h < VE; ++h) {
+        const float w = a.wd[h], v0 = u[0] * w, v1 = u[1] * w, v2 = u[2] * w;
+        in[1 + h] = sqrtf(v0 * v0 + v1 * v1 + v2 * v2 + 1e-8f) + 1e-8f;
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const float w = a.wdf[k], v0 = u[0] * w, v1 = u[1] * w, v2 = u[2] * w;
+#pragma unroll
+        for (int r = 0; r < 3; ++r) in[1 + VE + 3 * k + r] = f[3 * r] * v0 + f[3 * r + 1] * v1 + f[3 * r + 2] * v2;
+    }
+    float gate[VE];
+#pragma unroll
+    for (int c = 0; c < VE; ++c) gate[c] = a.bg[c];
+    for (int g = 0; g < SE / 4; ++g) {
+        v4f o;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int ch = 4 * g + k;
+            float p = a.bs[ch];
+            const float* w = a.ws + ch * KIN;
+#pragma unroll
+            for (int q = 0; q < KIN; ++q) p += w[q] * in[q];
+            p = fast_silu(p);
+            o[k] = p;
+#pragma unroll
+            for (int c = 0; c < VE; ++c) gate[c] += a.wg[c * SE + ch] * p;
+        }
+        a.EP4[(size_t)g * E + eid] = o;
+    }
+#pragma unroll
+    for (int c = 0; c < VE; ++c) a.AL[(size_t)c * E + eid] = a.kappa[c] * fast_sigmoid(gate[c]);
+}
+
+// ================================================================================================
+// K4  fused edge-message kernel: one workgroup = 64 consecutive flat edges, all four message GCP2s,
+//     scalar message attention and the per-row segment sum (gcpnet.py:676-737)
+// ================================================================================================
+struct EdgeMsgArgs {
+    // per-edge (constant over layers)
+    const v4f* EP4; const float* AL; const float* U; const float* FR; const int* EROW; const int* ECOL;
+    const int* NCNT;  // [N] atoms in the node's molecule (row length)
+    int E, N;
+    // per-node, for this layer (written by the previous node kernel)
+    const v4f* PQ4;   // [128][N]: groups 0..63 = W_i h_i + b, groups 64..127 = W_j h_j  (msg0 scalar_out split)
+    const float* VDI; // [(H0+3)*3][N] rows hh*3+x: [W_down;W_frames][:, 0:V] chi_i
+    const float* VDJ; // same with the column block of chi_j
+    float* AGG;       // [N][352] (zeroed before launch; rows split across tiles are accumulated atomically)
+    // msg0
+    const v4f* w0; int G0;       // packed [8][G0][64]; K' = [e'(Se) | n(H0 pad 4) | q(9 pad 12)] padded to 8
+    const float* wddE;           // [(H0+3)][Ve]: columns V..V+Ve of [W_down; W_frames]
+    const v4f* wg0; const float* bg0; const float* wup0;  // gate / vector_up [32][H0] of msg0
+    // msg1..3
+    GcpW mk[3];
+    const float* wa; float ba;   // scalar_message_attention
+};
+
+constexpr int ET = 64, ETP = 65;
+constexpr int EK_XS_GROUPS = 72;
+constexpr int EK_OFF_XS = 0;
+constexpr int EK_OFF_VV = EK_OFF_XS + EK_XS_GROUPS * ETP * 16;
+constexpr int EK_OFF_VH = EK_OFF_VV + 96 * ETP * 4;
+constexpr int EK_OFF_PG = EK_OFF_VH + 60 * ETP * 4;
+constexpr int EK_OFF_FR = EK_OFF_PG + 4 * 32 * ETP * 4;
+constexpr int EK_OFF_META = EK_OFF_FR + 9 * ETP * 4;
+constexpr int EK_LDS_BYTES = EK_OFF_META + (64 + 64 + 66 + 64 + 4) * 4;
+
+template <int SE, int VE>
+__global__ __launch_bounds__(256) void k_edge_msg(EdgeMsgArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    v4f* XS4 = (v4f*)(smem + EK_OFF_XS);
+    float* XSf = (float*)XS4;
+    float* VV = (float*)(smem + EK_OFF_VV);
+    float* VH = (float*)(smem + EK_OFF_VH);
+    float* PG = (float*)(smem + EK_OFF_PG);
+    float* FR = (float*)(smem + EK_OFF_FR);
+    int* m_row = (int*)(smem + EK_OFF_META);
+    int* m_col = m_row + 64;
+    int* m_seg = m_col + 64;   // [66] segment starts (+ end sentinel)
+    float* m_att = (float*)(m_seg + 66);
+    int* m_misc = (int*)(m_att + 64);  // [0] = nseg
+
+    constexpr int H0 = (2 * GCDM_V + VE) / 4;       // bottleneck 4
+    constexpr int H0G = (H0 + 3) / 4;
+    constexpr int SEG = SE / 4;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int e = lane, part = wave;  // T = 64: entity = lane, the 4 waves are the 4 "parts"
+    const int E = a.E, N = a.N;
+    const int e0 = blockIdx.x * ET;
+    const int nvalid = min(ET, E - e0);
+    const int eid = min(e0 + e, E - 1);
+    const int ni = a.EROW[eid], nj = a.ECOL[eid];
+
+    // ---- P0: tile metadata + row segments (wave 0) -------------------------------------------
+    if (wave == 0) {
+        m_row[e] = ni;
+        m_col[e] = nj;
+        const int prev = __shfl_up(ni, 1);
+        const bool start = (e < nvalid) && (e == 0 || prev != ni);
+        const unsigned long long mask = __ballot(start);
+        const int sid = __popcll(mask & ((2ull << e) - 1ull)) - 1;
+        if (start) m_seg[sid] = e;
+        if (e == 0) {
+            const int ns = __popcll(mask);
+            m_seg[ns] = nvalid;
+            m_misc[0] = ns;
+        }
+    }
+    // ---- P1: msg0 pre-phase ---------------------------------------------------------------------
+    {
+        float fr[9];
+#pragma unroll
+        for (int r = 0; r < 9; ++r) fr[r] = a.FR[(size_t)r * E + eid];
+        if (wave == 0) {
+#pragma unroll
+            for (int r = 0; r < 9; ++r) FR[r * ETP + e] = fr[r];
+        }
+        for (int g = part; g < SEG; g += 4) XS4[g * ETP + e] = a.EP4[(size_t)g * E + eid];
+        float al[VE];
+#pragma unroll
+        for (int c = 0; c < VE; ++c) al[c] = a.AL[(size_t)c * E + eid];
+        const float u0 = a.U[eid], u1 = a.U[(size_t)E + eid], u2 = a.U[2 * (size_t)E + eid];
+        constexpr int gN = SEG, gQ = SEG + H0G;
+        for (int hh = part; hh < H0 + 3; hh += 4) {
+            const float* w = a.wddE + hh * VE;
+            float beta = 0.f;
+#pragma unroll
+            for (int c = 0; c < VE; ++c) beta += w[c] * al[c];
+            const size_t r0 = (size_t)(hh * 3) * N;
+            const float vx = a.VDI[r0 + ni] + beta * u0 + a.VDJ[r0 + nj];
+            const float vy = a.VDI[r0 + N + ni] + beta * u1 + a.VDJ[r0 + N + nj];
+            const float vz = a.VDI[r0 + 2 * (size_t)N + ni] + beta * u2 + a.VDJ[r0 + 2 * (size_t)N + nj];
+            if (hh < H0) {
+                XSf[((gN + (hh >> 2)) * ETP + e) * 4 + (hh & 3)] = sqrtf(vx * vx + vy * vy + vz * vz + 1e-8f) + 1e-8f;
+                VH[(hh * 3 + 0) * ETP + e] = vx;
+                VH[(hh * 3 + 1) * ETP + e] = vy;
+                VH[(hh * 3 + 2) * ETP + e] = vz;
+            } else {
+                const int k = hh - H0;
+#pragma unroll
+                for (int r = 0; r < 3; ++r) {
+                    const int idx = 3 * k + r;
+                    XSf[((gQ + (idx >> 2)) * ETP + e) * 4 + (idx & 3)] = fr[3 * r] * vx + fr[3 * r + 1] * vy + fr[3 * r + 2] * vz;
+                }
+            }
+        }
+        if (part == 0) {
+            for (int hh = H0; hh < 4 * H0G; ++hh) XSf[((gN + (hh >> 2)) * ETP + e) * 4 + (hh & 3)] = 0.f;
+            for (int idx = 9; idx < 12; ++idx) XSf[((gQ + (idx >> 2)) * ETP + e) * 4 + (idx & 3)] = 0.f;
+            for (int g = gQ + 3; g < 2 * a.G0; ++g) XS4[g * ETP + e] = (v4f){0.f, 0.f, 0.f, 0.f};
+        }
+    }
+    __syncthreads();
+
+    const int half = lane >> 5, l31 = lane & 31;
+    const int mt0 = 2 * wave;  // this wave's two M-tiles (64 output channels), both N-tiles
+    f32x16 acc[2][2];
+    f32x16 gacc[2];
+
+    // ---- P2: msg0 GEMM.  acc starts from the node-level halves P_i + Q_j of scalar_out -----------
+    {
+#pragma unroll
+        for (int n = 0; n < 2; ++n) {
+            const int ri = m_row[32 * n + l31], cj = m_col[32 * n + l31];
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int g = 8 * (mt0 + m) + 2 * q + half;
+                    const v4f p = a.PQ4[(size_t)g * N + ri];
+                    const v4f qq = a.PQ4[(size_t)(64 + g) * N + cj];
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) acc[m][n][4 * q + t] = p[t] + qq[t];
+                }
+        }
+        tile_gemm<2, 2>(acc, a.w0 + (size_t)mt0 * a.G0 * 64, a.G0, XS4, ETP, lane);
+        apply_silu<2, 2>(acc);
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) gacc[n][r] = 0.f;
+        gate_partial<2, 2>(gacc, acc, a.wg0, mt0, lane);
+        store_gate_partial<2>(PG, gacc, ETP, wave, lane);
+    }
+    __syncthreads();
+    // ---- P3: m.s = silu(p) ; m.v = (W_up vh) * sigmoid(gate) -------------------------------------
+    store_state<2, 2, false>(XS4, 0, acc, ETP, mt0, lane);
+    vec_finish<ET>(PG, a.bg0, a.wup0, H0, GCDM_V, VH, e, part, [&](int c, float ox, float oy, float oz) {
+        VV[(c * 3 + 0) * ETP + e] = ox;
+        VV[(c * 3 + 1) * ETP + e] = oy;
+        VV[(c * 3 + 2) * ETP + e] = oz;
+    });
+    __syncthreads();
+
+    // ---- residual message GCP2s k = 1..3 (gcpnet.py:698-701) ------------------------------------
+    for (int k = 0; k < 3; ++k) {
+        const GcpW& w = a.mk[k];
+        gcp2_pre<ET>(w.wdd, w.H, GCDM_V, VV, 0, FR, XSf, GCDM_SG, GCDM_SG + 2, 2 * w.G, VH, e, part);
+        __syncthreads();
+        acc_init_bias<2, 2>(acc, w.b, mt0, lane);
+        tile_gemm<2, 2>(acc, w.w + (size_t)mt0 * w.G * 64, w.G, XS4, ETP, lane);
+        apply_silu<2, 2>(acc);
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) gacc[n][r] = 0.f;
+        gate_partial<2, 2>(gacc, acc, w.wg, mt0, lane);
+        store_gate_partial<2>(PG, gacc, ETP, wave, lane);
+        __syncthreads();
+        store_state<2, 2, true>(XS4, 0, acc, ETP, mt0, lane);
+        vec_finish<ET>(PG, w.bg, w.wup, w.H, GCDM_V, VH, e, part, [&](int c, float ox, float oy, float oz) {
+            VV[(c * 3 + 0) * ETP + e] += ox;
+            VV[(c * 3 + 1) * ETP + e] += oy;
+            VV[(c * 3 + 2) * ETP + e] += oz;
+        });
+        __syncthreads();
+    }
+
+    // ---- scalar message attention (gcpnet.py:709-711): att = sigmoid(w_a . m.s + b_a) -----------
+    {
+        float s = 0.f;
+        for (int g = part * 16; g < part * 16 + 16; ++g) {
+            const v4f wv = *(const v4f*)(a.wa + 4 * g);
+            const v4f x = XS4[g * ETP + e];
+            s += wv[0] * x[0] + wv[1] * x[1] + wv[2] * x[2] + wv[3] * x[3];
+        }
+        PG[part * ETP + e] = s;
+        __syncthreads();
+        if (wave == 0) m_att[e] = fast_sigmoid(PG[e] + PG[ETP + e] + PG[2 * ETP + e] + PG[3 * ETP + e] + a.ba);
+        __syncthreads();
+    }
+    // ---- aggregation: agg_i = sum_j [m.s * att | m.v]  over the row segments of this tile --------
+    {
+        const int nseg = m_misc[0];
+        constexpr int UNITS = GCDM_SG + 3 * GCDM_V;  // 64 float4 scalar groups + 96 vector floats
+        for (int wk = tid; wk < nseg * UNITS; wk += 256) {
+            const int sg = wk / UNITS, un = wk - sg * UNITS;
+            const int st = m_seg[sg], en = m_seg[sg + 1];
+            const int node = m_row[st];
+            const bool whole = (en - st) == a.NCNT[node];
+            float* dst = a.AGG + (size_t)node * GCDM_AGGW;
+            if (un < GCDM_SG) {
+                v4f s = {0.f, 0.f, 0.f, 0.f};
+                for (int x = st; x < en; ++x) s += XS4[un * ETP + x] * m_att[x];
+                if (whole) {
+                    *(v4f*)(dst + 4 * un) = s;
+                } else {
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) atomicAdd(dst + 4 * un + t, s[t]);
+                }
+            } else {
+                const int r = un - GCDM_SG;
+                float s = 0.f;
+                for (int x = st; x < en; ++x) s += VV[r * ETP + x];
+                if (whole) dst[GCDM_S + r] = s;
+                else atomicAdd(dst + GCDM_S + r, s);
+            }
+        }
+    }
+}
+
+// ================================================================================================
+// K3/K5  node kernels: one workgroup = 32 consecutive nodes.
+//   EMBED : node embedding GCP2 (gcpnet.py:591-597)                      -> h, chi
+//   LAYER : feed-forward GCP2 + residual + position-update GCP2 (gcpnet.py:894-928) -> h, chi, x
+//   then either the node-level halves of the NEXT layer's msg0 (PQ4, VDI, VDJ) or, after the last layer,
+//   the scalar projection GCP2 + vel (gcpnet.py:1191-1216).
+// ================================================================================================
+struct NodeArgs {
+    int N, F, C, FinG, Dout;   // Dout = 3 + F
+    float pos_weight;
+    // embed inputs
+    const v4f* HIN4; const float* CHI0;
+    GcpW emb;
+    // layer inputs
+    const float* AGG;
+    GcpW ff; GcpW pos;
+    // shared state
+    v4f* H4;        // [64][N]
+    float* CHI;     // [96][N]
+    float* XC;      // [3][N]
+    const float* X0;
+    const float* FBAR;
+    // next-layer pre (has_next) ...
+    int has_next;
+    const v4f* wpq; const float* bpq;           // packed [16][32][64], bias [512]
+    const float* wddI; const float* wddJ; int H0; // [(H0+3)][32] each
+    v4f* PQ4; float* VDI; float* VDJ;
+    // ... or projection (last layer)
+    GcpW proj;
+    float* OUT;     // [N][Dout] : columns 3.. get h_final
+    float* VEL;     // [3][N]
+    uint32_t* flags_dev;
+};
+
+constexpr int NT_ = 32, NTP = 33;
+constexpr int NK_XS_GROUPS = 140;
+constexpr int NK_OFF_XS = 0;
+constexpr int NK_OFF_VV = NK_OFF_XS + NK_XS_GROUPS * NTP * 16;
+constexpr int NK_OFF_VH = NK_OFF_VV + 192 * NTP * 4;
+constexpr int NK_OFF_PG = NK_OFF_VH + 96 * NTP * 4;
+constexpr int NK_OFF_FR = NK_OFF_PG + 4 * 32 * NTP * 4;
+constexpr int NK_OFF_XP = NK_OFF_FR + 9 * NTP * 4;
+constexpr int NK_LDS_BYTES = NK_OFF_XP + 3 * NTP * 4;
+
+template <bool EMBED>
+__global__ __launch_bounds__(256) void k_node(NodeArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    v4f* XS4 = (v4f*)(smem + NK_OFF_XS);
+    float* XSf = (float*)XS4;
+    float* VV = (float*)(smem + NK_OFF_VV);
+    float* VH = (float*)(smem + NK_OFF_VH);
+    float* PG = (float*)(smem + NK_OFF_PG);
+    float* FR = (float*)(smem + NK_OFF_FR);
+    float* XP = (float*)(smem + NK_OFF_XP);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int e = tid & 31, part = tid >> 5;   // T = 32: 8 threads share an entity
+    const int half = lane >> 5, l31 = lane & 31;
+    const int N = a.N;
+    const int n0 = blockIdx.x * NT_;
+    const int nid = min(n0 + e, N - 1);
+    const bool valid = (n0 + e) < N;
+    constexpr int HB = 64;   // group base of h inside XS4 (LAYER: groups 0..63 hold agg.s)
+    constexpr int CB = 32;   // channel base of chi inside VV (LAYER: channels 0..31 hold agg.v)
+
+    // ---- load tile --------------------------------------------------------------------------------
+    for (int r = part; r < 9; r += 8) FR[r * NTP + e] = a.FBAR[(size_t)r * N + nid];
+    if (part < 3) XP[part * NTP + e] = a.XC[(size_t)part * N + nid];
+    f32x16 acc[2][1];
+    f32x16 gacc[1];
+    const int mt0 = 2 * wave;
+
+    if (EMBED) {
+        for (int g = part; g < a.FinG; g += 8) XS4[g * NTP + e] = a.HIN4[(size_t)g * N + nid];
+        if (part < 6) VV[part * NTP + e] = a.CHI0[(size_t)part * N + nid];
+        __syncthreads();
+        const GcpW& w = a.emb;
+        const int gN = a.FinG, gQ = gN + (w.H + 3) / 4;
+        gcp2_pre<NT_>(w.wdd, w.H, 2, VV, 0, FR, XSf, gN, gQ, 2 * w.G, VH, e, part);
+        __syncthreads();
+        acc_init_bias<2, 1>(acc, w.b, mt0, lane);
+        tile_gemm<2, 1>(acc, w.w + (size_t)mt0 * w.G * 64, w.G, XS4, NTP, lane);
+        // nonlinearities (None, None): h = p, the vector gate sees p (gcpnet.py:539, 410)
+        for (int r = 0; r < 16; ++r) gacc[0][r] = 0.f;
+        gate_partial<2, 1>(gacc, acc, w.wg, mt0, lane);
+        store_gate_partial<1>(PG, gacc, NTP, wave, lane);
+        __syncthreads();
+        store_state<2, 1, false>(XS4, HB, acc, NTP, mt0, lane);
+        vec_finish<NT_>(PG, w.bg, w.wup, w.H, GCDM_V, VH, e, part, [&](int c, float ox, float oy, float oz) {
+            VV[((CB + c) * 3 + 0) * NTP + e] = ox;
+            VV[((CB + c) * 3 + 1) * NTP + e] = oy;
+            VV[((CB + c) * 3 + 2) * NTP + e] = oz;
+        });
+        __syncthreads();
+    } else {
+        // agg (node-major rows of 352 floats): one wave reads a node's 64 scalar groups + 96 vector floats coalesced
+        for (int x = wave; x < NT_; x += 4) {
+            const int nd = min(n0 + x, N - 1);
+            const float* src = a.AGG + (size_t)nd * GCDM_AGGW;
+            XS4[lane * NTP + x] = *(const v4f*)(src + 4 * lane);
+            VV[lane * NTP + x] = src[GCDM_S + lane];
+            if (lane < 32) VV[(64 + lane) * NTP + x] = src[GCDM_S + 64 + lane];
+        }
+        for (int g = part; g < GCDM_SG; g += 8) XS4[(HB + g) * NTP + e] = a.H4[(size_t)g * N + nid];
+        for (int r = part; r < 96; r += 8) VV[(CB * 3 + r) * NTP + e] = a.CHI[(size_t)r * N + nid];
+        __syncthreads();
+        // ---- feed-forward GCP2: ([agg.s | h], [agg.v ; chi]) -> (S, V), scalar_out = Linear-SiLU-Linear
+        {
+            const GcpW& w = a.ff;
+            const int gN = 2 * GCDM_SG, gQ = gN + (w.H + 3) / 4;
+            gcp2_pre<NT_>(w.wdd, w.H, 2 * GCDM_V, VV, 0, FR, XSf, gN, gQ, 2 * w.G, VH, e, part);
+            __syncthreads();
+            acc_init_bias<2, 1>(acc, w.b, mt0, lane);
+            tile_gemm<2, 1>(acc, w.w + (size_t)mt0 * w.G * 64, w.G, XS4, NTP, lane);
+            apply_silu<2, 1>(acc);
+            __syncthreads();                                   // all waves done reading groups 0..63 (agg.s)
+            store_state<2, 1, false>(XS4, 0, acc, NTP, mt0, lane);  // hidden activations overwrite agg.s
+            __syncthreads();
+            acc_init_bias<2, 1>(acc, w.b2, mt0, lane);
+            tile_gemm<2, 1>(acc, w.w2 + (size_t)mt0 * 32 * 64, 32, XS4, NTP, lane);
+            for (int r = 0; r < 16; ++r) gacc[0][r] = 0.f;
+            gate_partial<2, 1>(gacc, acc, w.wg, mt0, lane);    // nonlinearities (None, None)
+            store_gate_partial<1>(PG, gacc, NTP, wave, lane);
+            __syncthreads();
+            store_state<2, 1, true>(XS4, HB, acc, NTP, mt0, lane);  // h <- h + ff.s (gcpnet.py:907)
+            vec_finish<NT_>(PG, w.bg, w.wup, w.H, GCDM_V, VH, e, part, [&](int c, float ox, float oy, float oz) {
+                VV[((CB + c) * 3 + 0) * NTP + e] += ox;
+                VV[((CB + c) * 3 + 1) * NTP + e] += oy;
+                VV[((CB + c) * 3 + 2) * NTP + e] += oz;
+            });
+            __syncthreads();
+        }
+        // ---- position update GCP2: (h, chi) -> (S, 1); x += v[0] * weight (gcpnet.py:834-857, 922-928)
+        {
+            const GcpW& w = a.pos;
+            const int gN = 2 * GCDM_SG, gQ = gN + (w.H + 3) / 4;
+            gcp2_pre<NT_>(w.wdd, w.H, GCDM_V, VV, CB, FR, XSf, gN, gQ, HB + 2 * w.G, VH, e, part);
+            __syncthreads();
+            acc_init_bias<2, 1>(acc, w.b, mt0, lane);
+            tile_gemm<2, 1>(acc, w.w + (size_t)mt0 * w.G * 64, w.G, XS4 + HB * NTP, NTP, lane);
+            apply_silu<2, 1>(acc);
+            for (int r = 0; r < 16; ++r) gacc[0][r] = 0.f;
+            gate_partial<2, 1>(gacc, acc, w.wg, mt0, lane);
+            store_gate_partial<1>(PG, gacc, NTP, wave, lane);
+            __syncthreads();
+            vec_finish<NT_>(PG, w.bg, w.wup, w.H, 1, VH, e, part, [&](int c, float ox, float oy, float oz) {
+                XP[0 * NTP + e] += ox * a.pos_weight;
+                XP[1 * NTP + e] += oy * a.pos_weight;
+                XP[2 * NTP + e] += oz * a.pos_weight;
+            });
+            __syncthreads();
+            if (part < 3 && valid) a.XC[(size_t)part * N + nid] = XP[part * NTP + e];
+        }
+    }
+    // ---- write the node state back (h, chi) -------------------------------------------------------
+    if (valid) {
+        for (int g = part; g < GCDM_SG; g += 8) a.H4[(size_t)g * N + nid] = XS4[(HB + g) * NTP + e];
+        for (int r = part; r < 96; r += 8) a.CHI[(size_t)r * N + nid] = VV[(CB * 3 + r) * NTP + e];
+    }
+
+    if (a.has_next) {
+        // ---- node-level halves of the next layer's msg0 --------------------------------------------
+        // PQ = [W_s[:, :S] h + b ; W_s[:, S+Se:2S+Se] h]  (scalar_out column split)
+        f32x16 pacc[4][1];
+        const int pmt0 = 4 * wave;
+        acc_init_bias<4, 1>(pacc, a.bpq, pmt0, lane);
+        tile_gemm<4, 1>(pacc, a.wpq + (size_t)pmt0 * 32 * 64, 32, XS4 + HB * NTP, NTP, lane);
+        if ((n0 + l31) < N) {
+            const int nd = n0 + l31;
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int g = 8 * (pmt0 + m) + 2 * q + half;
+                    a.PQ4[(size_t)g * N + nd] = (v4f){pacc[m][0][4 * q], pacc[m][0][4 * q + 1], pacc[m][0][4 * q + 2], pacc[m][0][4 * q + 3]};
+                }
+        }
+        // VDI / VDJ = [W_down; W_frames][:, block] chi   (3 x (H0+3) per node and side)
+        if (valid) {
+            const int rows = a.H0 + 3;
+            for (int it = part; it < 2 * rows; it += 8) {
+                const int side = it >= rows, hh = side ? it - rows : it;
+                const float* w = (side ? a.wddJ : a.wddI) + hh * GCDM_V;
+                const float* vp = VV + (CB * 3) * NTP + e;
+                float vx = 0.f, vy = 0.f, vz = 0.f;
+                for (int c = 0; c < GCDM_V; ++c) {
+                    const float wc = w[c];
+                    vx += wc * vp[0]; vy += wc * vp[NTP]; vz += wc * vp[2 * NTP];
+                    vp += 3 * NTP;
+                }
+                float* dst = (side ? a.VDJ : a.VDI) + (size_t)(hh * 3) * N + nid;
+                dst[0] = vx; dst[N] = vy; dst[2 * (size_t)N] = vz;
+            }
+        }
+    } else {
+        // ---- scalar projection GCP2 (S, V) -> (F+1+C, 0), bottleneck 1, no activation (gcpnet.py:1191-1197)
+        const GcpW& w = a.proj;
+        const int gN = 2 * GCDM_SG, gQ = gN + (w.H + 3) / 4;
+        gcp2_pre<NT_>(w.wdd, w.H, GCDM_V, VV, CB, FR, XSf, gN, gQ, HB + 2 * w.G, VH, e, part);
+        __syncthreads();
+        if (wave == 0) {
+            f32x16 qacc[1][1];
+            acc_init_bias<1, 1>(qacc, w.b, 0, lane);
+            tile_gemm<1, 1>(qacc, w.w, w.G, XS4 + HB * NTP, NTP, lane);
+            if ((n0 + l31) < N) {
+                float* dst = a.OUT + (size_t)(n0 + l31) * a.Dout + 3;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int c = (r & 3) + 8 * (r >> 2) + 4 * half;
+                    if (c < a.F) dst[c] = qacc[0][0][r];   // context and time columns are dropped (gcpnet.py:1208-1211)
+                }
+            }
+        }
+        // vel = x - x_init (un-centralised x_init, gcpnet.py:1204); NaN -> flag (whole batch zeroed by k_finish)
+        if (part < 3 && valid) {
+            const float v = XP[part * NTP + e] - a.X0[(size_t)part * N + nid];
+            a.VEL[(size_t)part * N + nid] = v;
+            if (v != v) atomicOr(a.flags_dev, 1u);
+        }
+    }
+}
+
+// ================================================================================================
+// K6  finish: per molecule CoM projection of vel, NaN guard, assemble net_out (gcpnet.py:1213-1230)
+// ================================================================================================
+struct FinishArgs {
+    const float* VEL; const int* noff; int N, Dout; float* OUT; const uint32_t* flags_dev; uint32_t* user_flags;
+};
+
+__global__ __launch_bounds__(64) void k_finish(FinishArgs a) {
+    const int b = blockIdx.x, o = a.noff[b], n = a.noff[b + 1] - o;
+    const bool nan = (*a.flags_dev & 1u) != 0;
+    if (nan && a.user_flags && b == 0 && threadIdx.x == 0) atomicOr(a.user_flags, 1u);
+    float m0 = 0.f, m1 = 0.f, m2 = 0.f;
+    if (!nan) {
+        for (int i = 0; i < n; ++i) { m0 += a.VEL[o + i]; m1 += a.VEL[a.N + o + i]; m2 += a.VEL[2 * (size_t)a.N + o + i]; }
+        m0 /= (float)n; m1 /= (float)n; m2 /= (float)n;
+    }
+    for (int i = threadIdx.x; i < n; i += 64) {
+        float* dst = a.OUT + (size_t)(o + i) * a.Dout;
+        dst[0] = nan ? 0.f : a.VEL[o + i] - m0;
+        dst[1] = nan ? 0.f : a.VEL[a.N + o + i] - m1;
+        dst[2] = nan ? 0.f : a.VEL[2 * (size_t)a.N + o + i] - m2;
+    }
+}
+
+// ================================================================================================
+// K7  sampler kernels (variational_diffusion.py:795-907, 1204-1278): one workgroup per molecule
+// ================================================================================================
+__device__ __forceinline__ void philox4x32_10(uint32_t (&c)[4], uint32_t k0, uint32_t k1) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c[0], p1 = (uint64_t)0xCD9E8D57u * c[2];
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0, n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1;
+        c[1] = (uint32_t)p1; c[3] = (uint32_t)p0; c[0] = n0; c[2] = n2;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+}
+
+// standard normal #col of node `node` for draw `draw` (Box-Muller on Philox4x32-10)
+__device__ __forceinline__ float philox_normal(uint64_t seed, uint32_t draw, uint32_t node, uint32_t col) {
+    uint32_t c[4] = {node, draw, col >> 1, 0x6c078965u};
+    philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
+    const float u1 = ((float)(c[0] >> 8) + 0.5f) * (1.0f / 16777216.0f);
+    const float u2 = ((float)(c[1] >> 8) + 0.5f) * (1.0f / 16777216.0f);
+    const float r = sqrtf(-2.0f * __logf(u1));
+    float s, co;
+    __sincosf(6.283185307179586f * u2, &s, &co);
+    return (col & 1) ? r * s : r * co;
+}
+
+struct StepArgs {
+    float* z;            // [N][D] in/out
+    const float* eps;    // [N][D] network output (null for init)
+    const float* noise;  // [N][D] or null -> Philox
+    const int* noff; int N, D;
+    float alpha_coef, c_eps, sigma;     // step: z/alpha_coef - c_eps*eps + sigma*noise ; final: alpha_coef*(z - c_eps*eps) + sigma*noise
+    uint64_t seed; uint32_t draw;
+    int mode;            // 0 = step, 1 = init (z = noise), 2 = final decode
+    // final decode
+    float* out; int num_atom_types, include_charges; float nv0, nv1, nv2, nb1, nb2;
+    uint32_t* user_flags; uint32_t* flags_dev;
+};
+
+__global__ __launch_bounds__(256) void k_fill(float* p, int n, float v) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+
+// whole-batch CoG re-projection if any molecule drifted (variational_diffusion.py:1389-1402)
+__global__ __launch_bounds__(64) void k_cog_fix(float* out, const int* noff, int D, const uint32_t* flags_dev, uint32_t* user_flags) {
+    if (!(*flags_dev & 4u)) return;
+    const int b = blockIdx.x, o = noff[b], n = noff[b + 1] - o;
+    if (user_flags && b == 0 && threadIdx.x == 0) atomicOr(user_flags, 4u);
+    float m[3] = {0.f, 0.f, 0.f};
+    for (int i = 0; i < n; ++i) { m[0] += out[(size_t)(o + i) * D]; m[1] += out[(size_t)(o + i) * D + 1]; m[2] += out[(size_t)(o + i) * D + 2]; }
+    m[0] /= (float)n; m[1] /= (float)n; m[2] /= (float)n;
+    __syncthreads();
+    for (int i = threadIdx.x; i < n; i += 64) {
+        float* d = out + (size_t)(o + i) * D;
+        d[0] -= m[0]; d[1] -= m[1]; d[2] -= m[2];
+    }
+}
+
+__global__ __launch_bounds__(64) void k_sample(StepArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float ns[];  // [n][D] noise, then results
+    const int b = blockIdx.x, o = a.noff[b], n = a.noff[b + 1] - o, D = a.D;
+    for (int idx = threadIdx.x; idx < n * D; idx += 64) {
+        const int i = idx / D, c = idx - i * D;
+        ns[idx] = a.noise ? a.noise[(size_t)(o + i) * D + c] : philox_normal(a.seed, a.draw, (uint32_t)(o + i), (uint32_t)c);
+    }
+    __syncthreads();
+    // CoM-free x-noise (sample_center_gravity_zero_gaussian_with_mask, :396-420)
+    float m[3] = {0.f, 0.f, 0.f};
+    for (int i = 0; i < n; ++i) { m[0] += ns[i * D]; m[1] += ns[i * D + 1]; m[2] += ns[i * D + 2]; }
+    m[0] /= (float)n; m[1] /= (float)n; m[2] /= (float)n;
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < n * D; idx += 64) {
+        const int i = idx / D, c = idx - i * D;
+        float e = ns[idx];
+        if (c < 3) e -= m[c];
+        float v;
+        if (a.mode == 1) {
+            v = e;
+        } else {
+            const size_t gi = (size_t)(o + i) * D + c;
+            // mu = z / alpha_ts - (sigma2_ts / alpha_ts / sigma_t) * eps ; zs = mu + sigma * noise   (:1247-1263)
+            // final: mu = 1/alpha_0 * (z0 - sigma_0 * eps) ; xh = mu + sigma_x * noise          (:571, :878-886)
+            v = (a.mode == 0) ? (a.z[gi] / a.alpha_coef - a.c_eps * a.eps[gi]) + a.sigma * e
+                              : a.alpha_coef * (a.z[gi] - a.c_eps * a.eps[gi]) + a.sigma * e;
+        }
+        ns[idx] = v;
+    }
+    __syncthreads();
+    if (a.mode == 0) {  // project x back to zero CoM (:1266-1277)
+        float s[3] = {0.f, 0.f, 0.f};
+        for (int i = 0; i < n; ++i) { s[0] += ns[i * D]; s[1] += ns[i * D + 1]; s[2] += ns[i * D + 2]; }
+        s[0] /= (float)n; s[1] /= (float)n; s[2] /= (float)n;
+        for (int idx = threadIdx.x; idx < n * D; idx += 64) {
+            const int i = idx / D, c = idx - i * D;
+            a.z[(size_t)(o + i) * D + c] = ns[idx] - (c < 3 ? s[c] : 0.f);
+        }
+    } else if (a.mode == 1) {
+        for (int idx = threadIdx.x; idx < n * D; idx += 64) {
+            const int i = idx / D, c = idx - i * D;
+            a.z[(size_t)(o + i) * D + c] = ns[idx];
+        }
+    } else {
+        // unnormalize (:735-757), argmax one-hot / rounded charge (:902-905), CoG drift re-projection (:1389-1402)
+        float s[3] = {0.f, 0.f, 0.f};
+        for (int i = 0; i < n; ++i) { s[0] += ns[i * D] * a.nv0; s[1] += ns[i * D + 1] * a.nv0; s[2] += ns[i * D + 2] * a.nv0; }
+        const bool drift = fmaxf(fabsf(s[0]), fmaxf(fabsf(s[1]), fabsf(s[2]))) > 5e-2f;
+        if (drift && threadIdx.x == 0) atomicOr(a.flags_dev, 4u);
+        for (int i = threadIdx.x; i < n; i += 64) {
+            float* dst = a.out + (size_t)(o + i) * D;
+            const float* src = ns + i * D;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) dst[c] = src[c] * a.nv0;
+            int best = 0;
+            float bv = src[3] * a.nv1 + a.nb1;
+            for (int c = 1; c < a.num_atom_types; ++c) {
+                const float v = src[3 + c] * a.nv1 + a.nb1;
+                if (v > bv) { bv = v; best = c; }
+            }
+            for (int c = 0; c < a.num_atom_types; ++c) dst[3 + c] = (c == best) ? 1.f : 0.f;
+            if (a.include_charges) dst[3 + a.num_atom_types] = rintf(src[3 + a.num_atom_types] * a.nv2 + a.nb2);
+        }
+    }
+}

@@ -1,0 +1,169 @@
+"""Whole-model plug point: ``_target_`` stand-ins for the reference LightningModules.
+
+Boundary only (plug point 2): the constructor keywords, ``load_from_checkpoint``, ``.to(device)``,
+``.dataset_info``, ``.ddpm.num_nodes_distribution.sample(n)``, ``.sample(...)`` and ``.generate_molecules(...)`` that
+``src/mol_gen_sample.py:81-182`` and ``src/mol_gen_eval_conditional_qm9.py:101-109`` use of
+``src/models/qm9_mol_gen_ddpm.py`` / ``geom_mol_gen_ddpm.py``.  Training / validation hooks, metrics and RDKit
+post-processing are out of scope; ``generate_molecules`` returns raw (positions, atom-type indices, charges) per
+molecule and hands them to an optional ``molecule_builder`` (the reference's ``build_molecule``) when given.
+"""
+from __future__ import annotations
+
+import io
+import pickle
+from typing import Any, Callable, Dict, List, Optional, Tuple
+
+import torch
+from torch import nn
+
+from .config import cfg_get, dataset_info as _dataset_info
+from .gcpnet import GCPNetDynamics
+from .variational_diffusion import EquivariantVariationalDiffusion
+
+
+class _Dummy:
+    """Placeholder for globals (omegaconf containers, functools.partial(torch.optim.AdamW), ...) found in the
+    ``hyper_parameters`` of a Lightning checkpoint; only ``state_dict`` is used."""
+
+    def __init__(self, *a, **k):
+        pass
+
+    def __setstate__(self, state):
+        pass
+
+    def __call__(self, *a, **k):
+        return _Dummy()
+
+
+class _StateDictUnpickler(pickle.Unpickler):
+    _SAFE_PREFIXES = ("torch", "collections", "numpy", "builtins", "_codecs")
+
+    def find_class(self, module, name):
+        if module.split(".")[0] in self._SAFE_PREFIXES:
+            try:
+                return super().find_class(module, name)
+            except Exception:
+                return _Dummy
+        return _Dummy
+
+
+class _PickleShim:
+    Unpickler = _StateDictUnpickler
+    __name__ = "pickle"
+
+    @staticmethod
+    def load(f, **kw):
+        return _StateDictUnpickler(f, **kw).load()
+
+
+def load_lightning_state_dict(path: str) -> Dict[str, torch.Tensor]:
+    """Reads ``state_dict`` from a reference ``*.ckpt`` without needing omegaconf / lightning importable."""
+    try:
+        ckpt = torch.load(path, map_location="cpu", weights_only=False, pickle_module=_PickleShim)
+    except TypeError:
+        ckpt = torch.load(path, map_location="cpu", pickle_module=_PickleShim)
+    return ckpt["state_dict"] if "state_dict" in ckpt else ckpt
+
+
+class _MoleculeGenerationDDPM(nn.Module):
+    _DATASETS: Dict[str, str] = {}
+
+    def __init__(self, optimizer: Any = None, scheduler: Any = None, model_cfg: Any = None, module_cfg: Any = None,
+                 layer_cfg: Any = None, diffusion_cfg: Any = None, dataloader_cfg: Any = None, path_cfg: Any = None, **kwargs):
+        super().__init__()
+        if cfg_get(diffusion_cfg, "dynamics_network", "gcpnet") != "gcpnet":
+            raise NotImplementedError("only dynamics_network=gcpnet is built (EGNN is the reference's ablation baseline)")
+        if cfg_get(diffusion_cfg, "ddpm_mode", "unconditional") not in ("unconditional", "inpainting"):
+            raise ValueError("unsupported ddpm_mode")
+        self.ddpm_mode = cfg_get(diffusion_cfg, "ddpm_mode", "unconditional")
+        self.T = int(cfg_get(diffusion_cfg, "num_timesteps"))
+        self.num_atom_types = int(cfg_get(dataloader_cfg, "num_atom_types"))
+        self.num_x_dims = int(cfg_get(dataloader_cfg, "num_x_dims", 3))
+        self.include_charges = bool(cfg_get(dataloader_cfg, "include_charges"))
+        self.condition_on_context = len(cfg_get(module_cfg, "conditioning", []) or []) > 0
+        name = str(cfg_get(dataloader_cfg, "dataset"))
+        if name not in self._DATASETS:
+            raise ValueError(f"dataset {name!r} not supported by {type(self).__name__}")
+        self.dataset_info = _dataset_info(self._DATASETS[name])
+        dynamics_network = GCPNetDynamics(model_cfg=model_cfg, module_cfg=module_cfg, layer_cfg=layer_cfg,
+                                          diffusion_cfg=diffusion_cfg, dataloader_cfg=dataloader_cfg)
+        self.ddpm = EquivariantVariationalDiffusion(dynamics_network=dynamics_network, diffusion_cfg=diffusion_cfg,
+                                                    dataloader_cfg=dataloader_cfg, dataset_info=self.dataset_info)
+        self.props_distr = None   # set by the conditional-evaluation driver (PropertiesDistribution needs training data)
+        self._init_kwargs = dict(model_cfg=model_cfg, module_cfg=module_cfg, layer_cfg=layer_cfg, diffusion_cfg=diffusion_cfg,
+                                 dataloader_cfg=dataloader_cfg, path_cfg=path_cfg)
+
+    @property
+    def device(self) -> torch.device:
+        return next(self.parameters()).device
+
+    # the reference calls ``model.load_from_checkpoint(...)`` on an instance (mol_gen_sample.py:113-122)
+    def load_from_checkpoint(self, checkpoint_path: str, map_location: Any = None, strict: bool = True, **kwargs):
+        init = dict(self._init_kwargs)
+        init.update({k: v for k, v in kwargs.items() if k in init})
+        model = type(self)(**init)
+        sd = load_lightning_state_dict(checkpoint_path)
+        sd = {k: v for k, v in sd.items() if k.startswith("ddpm.")}
+        missing, unexpected = model.load_state_dict(sd, strict=False)
+        bad = [k for k in missing if k.startswith("ddpm.dynamics_network.")]
+        if strict and (bad or [k for k in unexpected if k.startswith("ddpm.dynamics_network.")]):
+            raise RuntimeError(f"checkpoint does not match the dynamics network: missing {bad[:4]} unexpected {unexpected[:4]}")
+        if map_location is not None:
+            model = model.to(map_location)
+        return model
+
+    @torch.inference_mode()
+    def sample(self, num_samples: int, num_nodes: Optional[torch.Tensor] = None, node_mask: Optional[torch.Tensor] = None,
+               context: Optional[torch.Tensor] = None, fix_noise: bool = False, num_timesteps: Optional[int] = None,
+               **kw) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor]:
+        """qm9_mol_gen_ddpm.py:591-633."""
+        if num_nodes is None:
+            num_nodes = self.ddpm.num_nodes_distribution.sample(num_samples)
+            assert int(num_nodes.max()) <= self.dataset_info.get("max_n_nodes", int(num_nodes.max()))
+        if self.condition_on_context:
+            if context is None:
+                if self.props_distr is None:
+                    raise ValueError("context required (no props_distr attached)")
+                context = self.props_distr.sample_batch(num_nodes)
+        else:
+            context = None
+        xh, batch_index, _ = self.ddpm.mol_gen_sample(num_samples=num_samples, num_nodes=num_nodes, node_mask=node_mask,
+                                                      context=context, fix_noise=fix_noise, fix_self_conditioning_noise=fix_noise,
+                                                      device=self.device, num_timesteps=num_timesteps, **kw)
+        x = xh[:, : self.num_x_dims]
+        one_hot = xh[:, self.num_x_dims:-1] if self.include_charges else xh[:, self.num_x_dims:]
+        charges = xh[:, -1:] if self.include_charges else torch.zeros(0, device=self.device)
+        return x, one_hot, charges, batch_index
+
+    @torch.inference_mode()
+    def generate_molecules(self, ddpm_mode: str = "unconditional", num_samples: int = 1, num_nodes: Optional[torch.Tensor] = None,
+                           sanitize: bool = False, largest_frag: bool = False, add_hydrogens: bool = False,
+                           sample_chain: bool = False, relax_iter: int = 0, num_timesteps: Optional[int] = None,
+                           node_mask: Optional[torch.Tensor] = None, context: Optional[torch.Tensor] = None,
+                           num_resamplings: int = 1, jump_length: int = 1,
+                           molecule_builder: Optional[Callable[[torch.Tensor, torch.Tensor, Dict[str, Any]], Any]] = None,
+                           **kw) -> List[Any]:
+        """qm9_mol_gen_ddpm.py:1063-1243 up to (not including) the RDKit post-processing."""
+        if ddpm_mode != "unconditional" or sample_chain:
+            raise NotImplementedError("only ddpm_mode='unconditional' without chains is built")
+        x, one_hot, charges, batch_index = self.sample(num_samples, num_nodes=num_nodes, node_mask=node_mask, context=context,
+                                                       num_timesteps=num_timesteps, **kw)
+        atom_types = one_hot.argmax(dim=-1)
+        counts = torch.unique_consecutive(batch_index, return_counts=True)[1].tolist()
+        mols, o = [], 0
+        for n in counts:
+            pos, at = x[o:o + n].cpu(), atom_types[o:o + n].cpu()
+            ch = charges[o:o + n].cpu() if self.include_charges else None
+            mols.append(molecule_builder(pos, at, self.dataset_info) if molecule_builder is not None else (pos, at, ch))
+            o += n
+        return mols
+
+
+class QM9MoleculeGenerationDDPM(_MoleculeGenerationDDPM):
+    """``_target_`` stand-in for src.models.qm9_mol_gen_ddpm.QM9MoleculeGenerationDDPM."""
+    _DATASETS = {"QM9": "qm9", "QM9_second_half": "qm9_second_half"}
+
+
+class GEOMMoleculeGenerationDDPM(_MoleculeGenerationDDPM):
+    """``_target_`` stand-in for src.models.geom_mol_gen_ddpm.GEOMMoleculeGenerationDDPM."""
+    _DATASETS = {"GEOM": "geom"}

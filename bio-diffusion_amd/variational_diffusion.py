@@ -1,0 +1,278 @@
+"""Ancestral DDPM sampler around the MI355X dynamics network.
+
+Mirror of the *sampling subset* of ``src/models/components/variational_diffusion.py``:
+``PredefinedNoiseSchedule`` (:206-255), ``EquivariantVariationalDiffusion`` with ``sigma/alpha/SNR`` (:318-338),
+``sigma_and_alpha_t_given_s`` (:342-367), ``sample_combined_position_feature_noise`` (:795-819),
+``sample_normal`` (:822-837), ``sample_p_zs_given_zt`` (:1204-1278), ``sample_p_xh_given_z0`` (:840-907) and
+``mol_gen_sample`` (:1282-1412), plus ``NumNodesDistribution`` (src/models/__init__.py:264-308).
+Training (loss), inpainting and guided optimisation are out of scope.
+
+Two ways to take a step:
+  * ``sample_p_zs_given_zt`` -- the reference's method signature, torch ops on the device for the O(N) algebra
+    and the HIP dynamics forward for the network call (used by the teacher-forced parity tests);
+  * ``mol_gen_sample`` -- the production loop: ``gcdm_sample_init / gcdm_sample_step / gcdm_sample_final``
+    (one fused HIP kernel per step after the network kernels; noise from a tape or on-device Philox;
+    host-side asserts replaced by a device flag word read once at the end).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import logging
+from typing import Any, Callable, Dict, Optional, Tuple, Union
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from . import _native
+from .config import AttrDict, cfg_get
+
+log = logging.getLogger(__name__)
+
+
+def num_nodes_to_batch_index(num_samples: int, num_nodes, device) -> torch.Tensor:
+    """src/models/components/__init__.py:314-321."""
+    assert isinstance(num_nodes, int) or len(num_nodes) == num_samples
+    idx = torch.arange(num_samples, device=device)
+    return torch.repeat_interleave(idx, num_nodes if isinstance(num_nodes, int) else num_nodes.to(device))
+
+
+def inflate_batch_array(array: torch.Tensor, target: torch.Tensor) -> torch.Tensor:
+    """src/models/__init__.py:80-86."""
+    return array.view((array.shape[0],) + (1,) * (len(target.shape) - 1))
+
+
+def _segment_mean_sub(x: torch.Tensor, batch_index: torch.Tensor, num_graphs: int, mask: torch.Tensor) -> torch.Tensor:
+    """centralize(..., edm=True) (components/__init__.py:45-98) without torch_scatter."""
+    mf = mask.to(x.dtype)
+    cnt = torch.zeros(num_graphs, dtype=x.dtype, device=x.device).index_add_(0, batch_index, mf).unsqueeze(-1)
+    s = torch.zeros(num_graphs, x.shape[1], dtype=x.dtype, device=x.device).index_add_(0, batch_index, x)
+    return x - (s / cnt)[batch_index] * mf.unsqueeze(-1)
+
+
+def polynomial_gamma(num_timesteps: int, noise_precision: float, power: float) -> np.ndarray:
+    """gamma table of the "polynomial_<power>" schedule in float64 (variational_diffusion.py:67-107, 237-246)."""
+    steps = num_timesteps + 1
+    x = np.linspace(0, steps, steps)
+    a2 = (1 - np.power(x / steps, power)) ** 2
+    a2 = np.concatenate([np.ones(1), a2], axis=0)
+    a2 = np.cumprod(np.clip(a2[1:] / a2[:-1], a_min=0.001, a_max=1.0), axis=0)
+    a2 = (1 - 2 * noise_precision) * a2 + noise_precision
+    return -(np.log(a2) - np.log(1 - a2))
+
+
+class PredefinedNoiseSchedule(nn.Module):
+    def __init__(self, noise_schedule: str, num_timesteps: int, noise_precision: float, verbose: bool = False, **kwargs):
+        super().__init__()
+        self.timesteps = num_timesteps
+        if "polynomial" not in noise_schedule:
+            raise NotImplementedError(f"noise schedule {noise_schedule!r} is not built (production: polynomial_2)")
+        splits = noise_schedule.split("_")
+        assert len(splits) == 2
+        g = polynomial_gamma(num_timesteps, float(noise_precision), float(splits[1]))
+        self.gamma = nn.Parameter(torch.tensor(g).float(), requires_grad=False)
+
+    def forward(self, t: torch.Tensor) -> torch.Tensor:
+        return self.gamma[torch.round(t * self.timesteps).long()]
+
+
+class NumNodesDistribution(nn.Module):
+    """src/models/__init__.py:264-308."""
+
+    def __init__(self, histogram: Dict[int, int], verbose: bool = False, eps: float = 1e-30):
+        super().__init__()
+        self.eps = eps
+        num_nodes, self.keys, prob = [], {}, []
+        for i, nodes in enumerate(histogram):
+            num_nodes.append(nodes)
+            self.keys[nodes] = i
+            prob.append(histogram[nodes])
+        self.register_buffer("num_nodes", torch.tensor(num_nodes))
+        self.register_buffer("prob", torch.tensor(prob))
+        self.prob = self.prob / torch.sum(self.prob)
+        self.m = torch.distributions.Categorical(self.prob)
+
+    def sample(self, n_samples: int = 1) -> torch.Tensor:
+        idx = self.m.sample((n_samples,))
+        return self.num_nodes[idx.to(self.num_nodes.device)]
+
+    def log_prob(self, batch_n_nodes: torch.Tensor) -> torch.Tensor:
+        idcs = torch.tensor([self.keys[i.item()] for i in batch_n_nodes], device=batch_n_nodes.device)
+        return torch.log(self.prob + self.eps)[idcs]
+
+
+class _Batch(AttrDict):
+    """Attribute bag with the three fields the dynamics network reads (stand-in for torch_geometric Batch)."""
+
+
+class EquivariantVariationalDiffusion(nn.Module):
+    def __init__(self, dynamics_network: nn.Module, diffusion_cfg: Any, dataloader_cfg: Any, dataset_info: Dict[str, Any]):
+        super().__init__()
+        assert cfg_get(diffusion_cfg, "parametrization", "eps") in ["eps"], "Epsilon is currently the only supported parametrization."
+        if cfg_get(diffusion_cfg, "noise_schedule") == "learned":
+            raise NotImplementedError("learned noise schedule (training) is out of scope")
+        self.diffusion_cfg = diffusion_cfg
+        self.diffusion_target = cfg_get(diffusion_cfg, "diffusion_target", "atom_types_and_coords")
+        self.num_atom_types = int(cfg_get(dataloader_cfg, "num_atom_types"))
+        self.num_x_dims = int(cfg_get(dataloader_cfg, "num_x_dims", 3))
+        self.include_charges = bool(cfg_get(dataloader_cfg, "include_charges"))
+        self.num_node_scalar_features = self.num_atom_types + int(self.include_charges)
+        self.T = int(cfg_get(diffusion_cfg, "num_timesteps"))
+        self.dynamics_network = dynamics_network
+        histogram = {int(k): int(v) for k, v in dataset_info["n_nodes"].items()}
+        self.num_nodes_distribution = NumNodesDistribution(histogram)
+        self.gamma = PredefinedNoiseSchedule(noise_schedule=cfg_get(diffusion_cfg, "noise_schedule"), num_timesteps=self.T,
+                                             noise_precision=float(cfg_get(diffusion_cfg, "noise_precision")))
+        self._gamma_uploaded = None
+
+    # ---- schedule algebra (:318-367) ---------------------------------------------------------------
+    @staticmethod
+    def sigma(gamma, target_tensor):
+        return inflate_batch_array(torch.sqrt(torch.sigmoid(gamma)), target_tensor)
+
+    @staticmethod
+    def alpha(gamma, target_tensor):
+        return inflate_batch_array(torch.sqrt(torch.sigmoid(-gamma)), target_tensor)
+
+    @staticmethod
+    def SNR(gamma):
+        return torch.exp(-gamma)
+
+    @staticmethod
+    def sigma_and_alpha_t_given_s(gamma_t, gamma_s, target_tensor):
+        sigma2_t_given_s = inflate_batch_array(-torch.expm1(F.softplus(gamma_s) - F.softplus(gamma_t)), target_tensor)
+        log_alpha2_t_given_s = F.logsigmoid(-gamma_t) - F.logsigmoid(-gamma_s)
+        alpha_t_given_s = inflate_batch_array(torch.exp(0.5 * log_alpha2_t_given_s), target_tensor)
+        return sigma2_t_given_s, torch.sqrt(sigma2_t_given_s), alpha_t_given_s
+
+    # ---- noise (:396-437, 795-837) -----------------------------------------------------------------
+    def sample_combined_position_feature_noise(self, batch_index, node_mask, generate_x_only: bool = False,
+                                               generator: Optional[torch.Generator] = None):
+        n, B = len(batch_index), int(batch_index.max().item()) + 1
+        dev = batch_index.device
+        z_x = torch.randn((n, self.num_x_dims), device=dev, generator=generator) * node_mask.float().unsqueeze(-1)
+        z_x = _segment_mean_sub(z_x, batch_index, B, node_mask)
+        if generate_x_only:
+            return z_x
+        z_h = torch.randn((n, self.num_node_scalar_features), device=dev, generator=generator) * node_mask.float().unsqueeze(-1)
+        return torch.cat([z_x, z_h], dim=-1)
+
+    def sample_normal(self, mu, sigma, batch_index, node_mask, fix_noise: bool = False, generate_x_only: bool = False,
+                      eps: Optional[torch.Tensor] = None):
+        if eps is None:
+            bi = torch.zeros_like(batch_index) if fix_noise else batch_index
+            eps = self.sample_combined_position_feature_noise(bi, node_mask, generate_x_only=generate_x_only)
+        return mu + sigma[batch_index] * eps
+
+    def compute_x_pred(self, zt, net_out, gamma_t, batch_index):
+        sigma_t = self.sigma(gamma_t, target_tensor=net_out)
+        alpha_t = self.alpha(gamma_t, target_tensor=net_out)
+        return 1.0 / alpha_t[batch_index] * (zt - sigma_t[batch_index] * net_out)
+
+    @staticmethod
+    def assert_mean_zero_with_mask(x, node_mask, eps: float = 1e-10):
+        largest_value = x.abs().max().item()
+        error = torch.sum(x, dim=0, keepdim=True).abs().max().item()
+        rel_error = error / (largest_value + eps)
+        assert rel_error < 1e-2, f"Mean is not zero, as relative_error {rel_error}"
+
+    # ---- one step with the reference's signature (:1204-1278) --------------------------------------
+    @torch.inference_mode()
+    def sample_p_zs_given_zt(self, s, t, z, batch_index, node_mask, batch=None, context=None, fix_noise: bool = False,
+                             generate_x_only: bool = False, self_condition: bool = False, xh_self_cond=None,
+                             noise: Optional[torch.Tensor] = None):
+        gamma_s, gamma_t = self.gamma(s), self.gamma(t)
+        sigma2_t_given_s, sigma_t_given_s, alpha_t_given_s = self.sigma_and_alpha_t_given_s(gamma_t, gamma_s, z)
+        sigma_s = self.sigma(gamma_s, target_tensor=z)
+        sigma_t = self.sigma(gamma_t, target_tensor=z)
+        if batch is None:
+            batch = _Batch(batch=batch_index, mask=node_mask, props_context=context)
+        _, eps_t = self.dynamics_network(batch, z, t[batch_index])
+        mu = z / alpha_t_given_s[batch_index] - (sigma2_t_given_s[batch_index] / alpha_t_given_s[batch_index] / sigma_t[batch_index]) * eps_t
+        sigma = sigma_t_given_s * sigma_s / sigma_t
+        if noise is not None:  # raw standard-normal draws [N,3+F] (x-part gets CoM-projected like the reference's sampler)
+            B = int(s.shape[0])
+            nx = _segment_mean_sub(noise[:, : self.num_x_dims] * node_mask.float().unsqueeze(-1), batch_index, B, node_mask)
+            noise = torch.cat([nx, noise[:, self.num_x_dims:] * node_mask.float().unsqueeze(-1)], dim=-1)
+        zs = self.sample_normal(mu, sigma, batch_index, node_mask, fix_noise=fix_noise, generate_x_only=generate_x_only, eps=noise)
+        zs_x = _segment_mean_sub(zs[:, : self.num_x_dims], batch_index, int(s.shape[0]), node_mask)
+        return zs_x if generate_x_only else torch.cat([zs_x, zs[:, self.num_x_dims:]], dim=-1)
+
+    # ---- production loop (:1282-1412) ---------------------------------------------------------------
+    def _native(self, device):
+        dyn = self.dynamics_network
+        if not hasattr(dyn, "_ensure_handle"):
+            raise RuntimeError("mol_gen_sample needs the bio-diffusion_amd GCPNetDynamics (HIP) as dynamics_network")
+        dyn._ensure_handle(torch.device(device))
+        dyn.sync_weights()
+        lib, h = dyn._lib, dyn._handle
+        if self._gamma_uploaded is not h:
+            g = self.gamma.gamma.detach().to("cpu", torch.float32).contiguous()
+            _native.check(lib, h, lib.gcdm_set_gamma(h, C.c_void_p(g.data_ptr()), g.numel()), "gcdm_set_gamma")
+            self._gamma_uploaded = h
+        return dyn, lib, h
+
+    @torch.inference_mode()
+    def mol_gen_sample(self, num_samples: int, num_nodes: torch.Tensor, device: Union[torch.device, str], return_frames: int = 1,
+                       num_timesteps: Optional[int] = None, node_mask: Optional[torch.Tensor] = None,
+                       context: Optional[torch.Tensor] = None, fix_noise: bool = False, generate_x_only: bool = False,
+                       fix_self_conditioning_noise: bool = False, norm_with_original_timesteps: bool = False,
+                       noise_fn: Optional[Callable[[int], torch.Tensor]] = None, seed: int = 1234,
+                       step_callback: Optional[Callable[[int, torch.Tensor], None]] = None
+                       ) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+        """Draw samples.  ``noise_fn(k)`` (optional) returns the k-th raw standard-normal draw [N,3+F] on ``device``
+        (k = 0 for z_T, then one per step, then one for the final decode: the reference's randn call order,
+        SURVEY A.5); without it noise comes from on-device Philox(seed)."""
+        if return_frames != 1 or fix_noise or generate_x_only or norm_with_original_timesteps:
+            raise NotImplementedError("mol_gen_sample (HIP): return_frames>1 / fix_noise / generate_x_only are not built")
+        num_timesteps = self.T if num_timesteps is None else num_timesteps
+        device = torch.device(device)
+        dyn, lib, h = self._native(device)
+        num_nodes = torch.as_tensor(num_nodes)
+        batch_index = num_nodes_to_batch_index(num_samples, num_nodes.to(device), device=device)
+        if node_mask is not None and not bool(node_mask.all()):
+            raise NotImplementedError("masked nodes are not built (sampling uses an all-True mask)")
+        node_mask = torch.ones_like(batch_index).bool()
+        dyn.plan(num_nodes.cpu())
+        N, D = int(batch_index.shape[0]), self.num_x_dims + self.num_node_scalar_features
+        ctx_ptr = None
+        if context is not None:
+            context = context.to(device, torch.float32)[batch_index].contiguous()
+            ctx_ptr = C.c_void_p(context.data_ptr())
+        elif dyn.condition_on_context:
+            raise ValueError("context required by a context-conditioned model")
+        stream = C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+        flags = torch.zeros(1, dtype=torch.int32, device=device)
+        fptr = C.c_void_p(flags.data_ptr())
+        z = torch.empty((N, D), dtype=torch.float32, device=device)
+        out = torch.empty_like(z)
+        k = 0
+
+        def nptr():
+            nonlocal k
+            if noise_fn is None:
+                k += 1
+                return None, None
+            nz = noise_fn(k).to(device, torch.float32).contiguous()
+            k += 1
+            return nz, C.c_void_p(nz.data_ptr())
+
+        keep, p = nptr()
+        _native.check(lib, h, lib.gcdm_sample_init(h, C.c_void_p(z.data_ptr()), p, C.c_uint64(seed), stream), "gcdm_sample_init")
+        for s in reversed(range(0, num_timesteps)):
+            keep, p = nptr()
+            st = lib.gcdm_sample_step(h, C.c_void_p(z.data_ptr()), ctx_ptr, s, num_timesteps, p, C.c_uint64(seed), fptr, stream)
+            _native.check(lib, h, st, "gcdm_sample_step")
+            if step_callback is not None:
+                step_callback(s, z)
+        keep, p = nptr()
+        st = lib.gcdm_sample_final(h, C.c_void_p(z.data_ptr()), ctx_ptr, p, C.c_uint64(seed), C.c_void_p(out.data_ptr()), fptr, stream)
+        _native.check(lib, h, st, "gcdm_sample_final")
+        fl = int(flags.item())   # the one host sync of the run
+        if fl & _native.FLAG_NAN_VEL:
+            log.warning("Detected NaN in `vel` -> GCPNet `vel` output was reset to zero for at least one time step.")
+        if fl & _native.FLAG_COG_DRIFT:
+            log.warning("CoG drift above 5e-2. Projected the positions down.")
+        self.last_flags = fl
+        return out, batch_index, node_mask

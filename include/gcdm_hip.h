@@ -1,0 +1,115 @@
+/*
+ * gcdm_hip.h -- C ABI of libgcdm_hip.so: the MI355X (gfx950) implementation of the GCDM denoising
+ * inner loop (GCPNet dynamics forward + one ancestral DDPM step).
+ *
+ * The library replaces, behind the reference's `dynamics_network` plug point, the body of
+ *   GCPNetDynamics.forward / atom_types_and_coords_forward   (src/models/components/gcpnet.py:1042-1232)
+ * and the per-step algebra of
+ *   EquivariantVariationalDiffusion.sample_p_zs_given_zt     (src/models/components/variational_diffusion.py:1204-1278)
+ *   EquivariantVariationalDiffusion.sample_p_xh_given_z0     (variational_diffusion.py:840-907)
+ * The reference has no FFI of its own (it is 100 % Python on torch ops + torch_scatter); the binding a
+ * maintainer adds is the ctypes stub shown in INTEGRATION.md (it is what bio-diffusion_amd/_native.py does).
+ *
+ * Conventions
+ *   - every entry point returns an int status: 0 = ok, <0 = error (gcdm_last_error() gives the text);
+ *     no C++ exception crosses the ABI;
+ *   - the caller owns every buffer it passes; the library owns only its handle, packed weights and workspace;
+ *   - pointers documented "device" are HIP device pointers valid on the handle's device; "host" are host pointers;
+ *   - all device work is enqueued on the `stream` argument (a hipStream_t passed as void*) and is asynchronous;
+ *   - one handle per device; a handle is not thread-safe;
+ *   - all tensors are fp32, row-major, node-major ([N, C]) unless stated otherwise.
+ */
+#ifndef GCDM_HIP_H
+#define GCDM_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GCDM_ABI_VERSION 1
+
+/* Bits of the device-side `flags` word (reproduce the reference's host-side checks without a sync). */
+#define GCDM_FLAG_NAN_VEL        0x1u  /* gcpnet.py:1213-1216: NaN seen in vel -> whole-batch vel zeroed   */
+#define GCDM_FLAG_MEAN_NOT_ZERO  0x2u  /* variational_diffusion.py:465-474 assert_mean_zero_with_mask fails  */
+#define GCDM_FLAG_COG_DRIFT      0x4u  /* variational_diffusion.py:1392-1402: CoG drift > 5e-2, re-projected  */
+
+typedef struct GcdmConfig {
+    int32_t abi_version;       /* must be GCDM_ABI_VERSION */
+    int32_t num_atom_types;    /* dataloader_cfg.num_atom_types (5 QM9 / 16 GEOM) */
+    int32_t include_charges;   /* dataloader_cfg.include_charges (0/1) */
+    int32_t num_context;       /* len(module_cfg.conditioning) */
+    int32_t condition_on_time; /* diffusion_cfg.condition_on_time (must be 1) */
+    int32_t num_layers;        /* model_cfg.num_encoder_layers (9 / 4) */
+    int32_t h_hidden_dim;      /* model_cfg.h_hidden_dim   (must be 256) */
+    int32_t chi_hidden_dim;    /* model_cfg.chi_hidden_dim (must be 32) */
+    int32_t e_hidden_dim;      /* model_cfg.e_hidden_dim   (64 / 16; multiple of 4, <= 64) */
+    int32_t xi_hidden_dim;     /* model_cfg.xi_hidden_dim  (16 / 8;  <= 16) */
+    int32_t bottleneck;        /* module_cfg.bottleneck == default_bottleneck (must be 4) */
+    int32_t num_timesteps;     /* diffusion_cfg.num_timesteps (T of the gamma table) */
+    float   node_positions_weight; /* module_cfg.node_positions_weight */
+    float   norm_values[3];    /* diffusion_cfg.norm_values */
+    float   norm_biases[3];    /* diffusion_cfg.norm_biases (null -> 0) */
+    int32_t device;            /* HIP device ordinal */
+} GcdmConfig;
+
+typedef struct gcdm_handle gcdm_handle;
+
+/* Creates a handle on cfg->device.  Replaces GCPNetDynamics.__init__ (gcpnet.py:934-1039). */
+int gcdm_create(const GcdmConfig* cfg, gcdm_handle** out);
+int gcdm_destroy(gcdm_handle* h);
+const char* gcdm_last_error(const gcdm_handle* h);   /* valid until the next call on h; h may be NULL */
+
+/* Weights, by REFERENCE state-dict key relative to the dynamics network, e.g.
+ * "interaction_layers.0.interaction.message_fusion.0.scalar_out.weight" (SURVEY.md App. A.3), host fp32,
+ * torch nn.Linear layout [out, in].  gcdm_finalize_weights() checks that every key/shape is present,
+ * re-packs into the MFMA fragment layout and uploads.  Replaces nn.Module.load_state_dict for this module. */
+int gcdm_set_weight(gcdm_handle* h, const char* key, const float* host_data, int64_t numel);
+int gcdm_finalize_weights(gcdm_handle* h);
+
+/* gamma lookup table [num_timesteps+1] (PredefinedNoiseSchedule.gamma, variational_diffusion.py:246-250), host fp32. */
+int gcdm_set_gamma(gcdm_handle* h, const float* host_gamma, int64_t numel);
+
+/* Batch topology: B molecules with num_nodes[b] atoms each, flat node order = molecule-major (the order
+ * `num_nodes_to_batch_index` produces, components/__init__.py:314-321).  Builds CSR offsets / tile lists once;
+ * topology is constant over the 1000 steps.  Replaces get_fully_connected_edge_index (gcpnet.py:1054-1066). */
+int gcdm_plan_batch(gcdm_handle* h, int32_t num_molecules, const int32_t* host_num_nodes);
+
+/* One epsilon prediction.  xh [N,3+F] device, t [N] device (the reference passes [N,1]), context [N,C] device or
+ * NULL, out [N,3+F] device, flags: device uint32 (OR-ed into) or NULL.  node_mask is all-True (mol_gen_sample.py:160).
+ * Replaces GCPNetDynamics.forward (gcpnet.py:1042-1052, 1069-1232). */
+int gcdm_forward(gcdm_handle* h, const float* xh, const float* t, const float* context, float* out,
+                 uint32_t* flags, void* stream);
+
+/* One ancestral step z_t -> z_s in place, s = s_index/num_steps, t = (s_index+1)/num_steps, including the network
+ * call.  noise: device [N,3+F] standard normal (x-part is CoM-projected inside, as the reference does) or NULL to
+ * draw Philox noise from (seed, s_index).  Replaces sample_p_zs_given_zt (variational_diffusion.py:1204-1278). */
+int gcdm_sample_step(gcdm_handle* h, float* z, const float* context, int32_t s_index, int32_t num_steps,
+                     const float* noise, uint64_t seed, uint32_t* flags, void* stream);
+
+/* Final decode x,h ~ p(x,h | z_0): out [N,3+F] = [x * norm_values[0] | one_hot(argmax) | round(charge)] device.
+ * Replaces sample_p_xh_given_z0 + the CoG re-projection (variational_diffusion.py:840-907, 1389-1412). */
+int gcdm_sample_final(gcdm_handle* h, const float* z0, const float* context, const float* noise, uint64_t seed,
+                      float* out, uint32_t* flags, void* stream);
+
+/* Draws z_T (variational_diffusion.py:795-819) into z [N,3+F] from `noise` (device) or Philox(seed). */
+int gcdm_sample_init(gcdm_handle* h, float* z, const float* noise, uint64_t seed, void* stream);
+
+/* Introspection for the parity tests: copies an internal buffer of the LAST forward to host (synchronises).
+ * names: "h","chi","x","agg","ep","alpha","frames","pq","hin","fbar","chi0".  Returns number of floats written
+ * (or needed if host_out is NULL), <0 on error.  Layouts are documented in DESIGN.md. */
+int64_t gcdm_debug_read(gcdm_handle* h, const char* name, float* host_out, int64_t capacity);
+/* Stops the next forward after `num_layers_to_run` interaction layers (-1 = all; test hook). */
+int gcdm_debug_set_layer_limit(gcdm_handle* h, int32_t num_layers_to_run);
+
+/* Sizes of the current plan. */
+int64_t gcdm_num_nodes(const gcdm_handle* h);
+int64_t gcdm_num_edges(const gcdm_handle* h);
+/* Executed / algorithmic FLOPs of one forward on the current plan. */
+double gcdm_forward_flops_executed(const gcdm_handle* h);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GCDM_HIP_H */

@@ -1,0 +1,145 @@
+"""CPU-only checks: module/state-dict parity with the reference layout, config surface, C-ABI exports,
+and a NumPy emulation of the MFMA operand mapping that the weight packing relies on."""
+import ctypes
+import importlib
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+import synth
+
+pkg = importlib.import_module("bio-diffusion_amd")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.parametrize("case,ds,cond", [("qm9", "qm9", ()), ("qm9cond", "qm9", ("alpha",)), ("geom", "geom", ())])
+def test_state_dict_matches_reference_layout(case, ds, cond):
+    cfgs = pkg.default_cfgs(ds, cond)
+    net = pkg.GCPNetDynamics(**cfgs)
+    d = synth.DATASET_DIMS[case]
+    want = synth.dynamics_shapes(d["S"], d["V"], d["Se"], d["Ve"], d["L"], synth.dims_h_in(d))
+    got = {k: tuple(v.shape) for k, v in net.state_dict().items()}
+    assert got == want
+    assert list(got) == list(want)          # registration order too
+    n_params = sum(int(np.prod(s)) for s in want.values())
+    assert n_params == {"qm9": 6213433, "qm9cond": 6213433, "geom": 2727387}[case]
+    net.load_state_dict(synth.make_weights(want, seed=1))
+
+
+@pytest.mark.needs_reference
+@pytest.mark.parametrize("ds,cond", [("qm9", ()), ("qm9", ("alpha",)), ("geom", ())])
+def test_state_dict_matches_imported_reference(ds, cond):
+    import ref_harness as rh
+    ref = rh.build_reference_dynamics(rh.load_reference_cfgs(ds, cond))
+    net = pkg.GCPNetDynamics(**pkg.default_cfgs(ds, cond))
+    a = {k: tuple(v.shape) for k, v in ref.state_dict().items()}
+    b = {k: tuple(v.shape) for k, v in net.state_dict().items()}
+    assert a == b and list(a) == list(b)
+    # config values: our defaults == the reference YAML tree
+    refc = rh.load_reference_cfgs(ds, cond)
+    ours = pkg.default_cfgs(ds, cond)
+    tree = pkg.load_cfg_tree(os.path.join(rh.REFERENCE_ROOT, "configs"), ds, cond)
+    for grp in ("model_cfg", "layer_cfg", "diffusion_cfg"):
+        for k, v in refc[grp].items():
+            if k in ours[grp] and not isinstance(v, dict):
+                assert ours[grp][k] == v, (grp, k)
+                assert tree[grp][k] == v, (grp, k)
+    for k in ("num_atom_types", "include_charges", "num_x_dims"):
+        assert ours["dataloader_cfg"][k] == refc["dataloader_cfg"][k]
+    for k in ("bottleneck", "vector_gate", "frame_gate", "norm_x_diff", "node_positions_weight"):
+        assert ours["module_cfg"][k] == refc["module_cfg"][k]
+    info = pkg.dataset_info("geom" if ds == "geom" else ("qm9_second_half" if cond else "qm9"))
+    rinfo = rh.dataset_info(ds, cond)
+    assert info["n_nodes"] == {int(k): int(v) for k, v in rinfo["n_nodes"].items()}
+    assert info["atom_decoder"] == rinfo["atom_decoder"] and info["max_n_nodes"] == rinfo["max_n_nodes"]
+
+
+def test_forward_refuses_cpu():
+    net = pkg.GCPNetDynamics(**pkg.default_cfgs("qm9"))
+    bi = torch.zeros(3, dtype=torch.long)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        net(dict(batch=bi, mask=torch.ones(3, dtype=torch.bool)), torch.zeros(3, 9), torch.zeros(3, 1))
+
+
+def test_gamma_and_ddpm_host_logic():
+    from oracle import gcdm_oracle as O
+    cfgs = pkg.default_cfgs("qm9")
+    ddpm = pkg.EquivariantVariationalDiffusion(pkg.GCPNetDynamics(**cfgs), cfgs["diffusion_cfg"], cfgs["dataloader_cfg"], pkg.dataset_info("qm9"))
+    assert torch.equal(ddpm.gamma.gamma, O.gamma_table(O.OracleConfig()))
+    n = ddpm.num_nodes_distribution.sample(64)
+    assert n.min() >= 3 and n.max() <= 29
+    keys = set(ddpm.state_dict())
+    assert {"gamma.gamma", "num_nodes_distribution.num_nodes", "num_nodes_distribution.prob"} <= keys
+    g = torch.Generator().manual_seed(0)
+    bi = torch.repeat_interleave(torch.arange(3), torch.tensor([4, 5, 3]))
+    z = ddpm.sample_combined_position_feature_noise(bi, torch.ones(12, dtype=torch.bool), generator=g)
+    for b in range(3):
+        assert z[bi == b, :3].sum(0).abs().max() < 1e-5
+
+
+def test_whole_model_plug_point_and_checkpoint_roundtrip(tmp_path):
+    cfgs = pkg.default_cfgs("geom")
+    model = pkg.GEOMMoleculeGenerationDDPM(optimizer=None, scheduler=None, **cfgs)
+    assert model.dataset_info["max_n_nodes"] == 181
+    sd = model.state_dict()
+    assert any(k.startswith("ddpm.dynamics_network.interaction_layers.3.") for k in sd)
+    path = os.path.join(tmp_path, "m.ckpt")
+    torch.save({"state_dict": sd, "hyper_parameters": {"x": 1}}, path)
+    m2 = model.load_from_checkpoint(checkpoint_path=path, map_location="cpu", **cfgs)
+    for k, v in m2.state_dict().items():
+        assert torch.equal(v, sd[k])
+
+
+def test_cabi_exports_every_declared_symbol():
+    native = pkg._native
+    if not os.path.exists(native.LIB_PATH):
+        pytest.skip("libgcdm_hip.so not built (run __graft_entry__.build())")
+    lib = ctypes.CDLL(native.LIB_PATH)
+    hdr = open(os.path.join(ROOT, "include", "gcdm_hip.h")).read()
+    declared = set(re.findall(r"\b(gcdm_[a-z_0-9]+)\s*\(", hdr))
+    assert declared == set(native.EXPORTS)
+    for name in declared:
+        assert hasattr(lib, name), name
+
+
+def test_mfma_operand_mapping_of_the_packing():
+    """Emulates v_mfma_f32_32x32x2_f32 lane semantics (cdna guide section 3) on the host-side packing formula:
+    D[i][j] = sum_k A[i][k] B[k][j], A: lane l holds A[l&31][l>>5], B: lane l holds B[l>>5][l&31],
+    C/D: lane l reg r holds D[(r&3) + 8(r>>2) + 4(l>>5)][l&31]."""
+    rng = np.random.default_rng(0)
+    M, K, T = 64, 24, 32
+    W = rng.standard_normal((M, K)).astype(np.float64)
+    X = rng.standard_normal((K, T)).astype(np.float64)
+    MT, G = M // 32, K // 8
+    packed = np.zeros((MT, G, 64, 4))
+    for mt in range(MT):
+        for g in range(G):
+            for lane in range(64):
+                for t in range(4):
+                    packed[mt, g, lane, t] = W[32 * mt + (lane & 31), 8 * g + 4 * (lane >> 5) + t]
+    xs4 = X.reshape(K // 4, 4, T).transpose(0, 2, 1)          # XS4[group][entity][4]
+    out = np.zeros((M, T))
+    for mt in range(MT):
+        acc = np.zeros((64, 16))
+        for g in range(G):
+            for t in range(4):
+                A = np.zeros((32, 2)); Bm = np.zeros((2, 32))
+                for lane in range(64):
+                    A[lane & 31, lane >> 5] = packed[mt, g, lane, t]
+                    Bm[lane >> 5, lane & 31] = xs4[2 * g + (lane >> 5), lane & 31, t]
+                Dm = A @ Bm
+                for lane in range(64):
+                    for r in range(16):
+                        acc[lane, r] += Dm[(r & 3) + 8 * (r >> 2) + 4 * (lane >> 5), lane & 31]
+        for lane in range(64):
+            for r in range(16):
+                out[32 * mt + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5), lane & 31] = acc[lane, r]
+    assert np.allclose(out, W @ X)
+    # accumulator registers 4q..4q+3 of a lane are exactly channel group 8 mt + 2 q + half
+    for lane in (0, 31, 32, 63):
+        for q in range(4):
+            ch = [(r & 3) + 8 * (r >> 2) + 4 * (lane >> 5) for r in range(4 * q, 4 * q + 4)]
+            assert ch == list(range(4 * (2 * q + (lane >> 5)), 4 * (2 * q + (lane >> 5)) + 4))
