@@ -1,0 +1,242 @@
+#!/usr/bin/env python
+"""bench.py -- throughput of the GCDM denoising hot path on MI355X.
+
+A "step" is ONE denoise step of the DDPM sampler over one batch of molecules: the GCPNet dynamics forward
+(HIP kernels) + the fused sampler update (noise from on-device Philox), i.e. one iteration of the loop at
+reference variational_diffusion.py:1335-1375.  Workload at N=1: BASELINE.json configs[1] -- QM9 unconditional,
+1024 molecules x 19 atoms per GPU (``--workload geom``: configs[3], 256 x 44 atoms).  For N>1 every rank samples
+its own 1024 (256) molecules (independent trajectories, no data-path collective; weak scaling); the final samples
+are gathered with one all_gather outside the timed region.
+
+    python bench.py --gpus 1 --steps 100 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port P bench.py --gpus 8 ...
+
+Prints ONE JSON line (rank 0).  ``value`` = molecules/s of a full 1000-step sample = molecules / (1001 network
+evaluations x measured s/step) over all ranks.  ``roofline`` is for the dominant kernel (fused edge-message kernel,
+one launch per interaction layer) timed with HIP events inside the library on the launch stream.
+``cpu_baseline`` times the CPU oracle (torch, all host cores) on a bounded sample of the same workload.
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes as C
+import importlib
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+PEAK_FP32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md, dense fp32 matrix peak
+NET_EVALS_PER_SAMPLE = 1001     # 1000 denoise steps + the t=0 decode
+
+WORKLOADS = {
+    "qm9": dict(dataset="qm9", cond=(), B=1024, n=19, name="QM9 unconditional, 1024 molecules x 19 atoms / GPU, 1000-step DDPM"),
+    "qm9cond": dict(dataset="qm9", cond=("alpha",), B=1024, n=19, name="QM9 alpha-conditional, 1024 x 19 / GPU, 1000-step DDPM"),
+    "geom": dict(dataset="geom", cond=(), B=256, n=44, name="GEOM-Drugs unconditional, 256 molecules x 44 atoms / GPU, 1000-step DDPM"),
+}
+
+
+def algorithmic_flops(N, E, dims):
+    """SURVEY A.4 closed form (2 x MAC of every nn.Linear as the reference evaluates them + 54 per scalarisation)."""
+    from oracle.gcdm_oracle import forward_flops, _gcp2_flops
+    S, V, Se, Ve, L, h_in = dims
+    total = forward_flops(N, E, S, V, Se, Ve, L, h_in)
+    edge_layer = _gcp2_flops(E, 2 * S + Se, 2 * V + Ve, S, V, 4) + 3 * _gcp2_flops(E, S, V, S, V, 4) + 2 * E * S
+    return total, edge_layer
+
+
+def cpu_baseline(dataset, cond, dims, seconds_budget=20.0):
+    """Oracle (CPU restatement pinned to the reference) on a bounded sample: B=16 molecules, a few denoise steps."""
+    import synth
+    from oracle import gcdm_oracle as O
+    case = "geom" if dataset == "geom" else ("qm9cond" if cond else "qm9")
+    d = synth.DATASET_DIMS[case]
+    n = 44 if dataset == "geom" else 19
+    Bc = 8 if dataset == "geom" else 16
+    threads = min(os.cpu_count() or 1, int(os.environ.get("GCDM_CPU_THREADS", "32")))
+    torch.set_num_threads(threads)     # very wide hosts: torch CPU ops on these sizes stop scaling (and thrash) past ~32 threads
+    W = synth.make_weights(synth.dynamics_shapes(d["S"], d["V"], d["Se"], d["Ve"], d["L"], synth.dims_h_in(d)), seed=0, scale_2d=0.25)
+    ocfg = O.OracleConfig(num_atom_types=d["num_atom_types"], include_charges=d["include_charges"], num_context=d["n_ctx"],
+                          num_layers=d["L"], norm_values=d["norm_values"])
+    nn_ = torch.full((Bc,), n, dtype=torch.long)
+    bi = O.num_nodes_to_batch_index(nn_)
+    mask = torch.ones(len(bi), dtype=torch.bool)
+    gam = O.gamma_table(ocfg)
+    noise = O.TapeNoise(1)
+    ctx = torch.randn(Bc, 1)[bi] if d["n_ctx"] else None
+    z = O.sample_combined_noise(noise, bi, Bc, mask, ocfg.num_node_scalar_features, torch.float32)
+    with torch.no_grad():
+        z, _ = O.sample_p_zs_given_zt(W, ocfg, gam, 0.999, 1.0, z, bi, Bc, mask, ctx, noise)   # warm-up
+        t0 = time.time()
+        steps = 0
+        while steps < 3 or (time.time() - t0 < seconds_budget and steps < 50):
+            s = 998 - steps
+            z, _ = O.sample_p_zs_given_zt(W, ocfg, gam, s / 1000, (s + 1) / 1000, z, bi, Bc, mask, ctx, noise)
+            steps += 1
+        dt = (time.time() - t0) / steps
+    return {"value": Bc / (dt * NET_EVALS_PER_SAMPLE), "unit": "molecules/s", "cores": torch.get_num_threads(), "kind": "port",
+            "ms_per_step": dt * 1e3,
+            "sample": f"CPU oracle (torch fp32), {Bc} molecules x {n} atoms, {steps} denoise steps timed, extrapolated x{NET_EVALS_PER_SAMPLE}"}
+
+
+def log(msg):
+    if os.environ.get("RANK", "0") == "0":
+        print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="qm9", choices=sorted(WORKLOADS))
+    ap.add_argument("--batch", type=int, default=0, help="molecules per GPU (default: the workload's)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if args.gpus > 1 or world > 1:
+        import torch.distributed as dist_
+        dist = dist_
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", rank=rank, world_size=world)   # "nccl" is RCCL on ROCm
+        assert world == args.gpus, f"launch with --nproc-per-node {args.gpus}"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    import synth
+    pkg = importlib.import_module("bio-diffusion_amd")
+    native = pkg._native
+    wl = WORKLOADS[args.workload]
+    B = args.batch or wl["B"]
+    case = "geom" if wl["dataset"] == "geom" else ("qm9cond" if wl["cond"] else "qm9")
+    d = synth.DATASET_DIMS[case]
+    cfgs = pkg.default_cfgs(wl["dataset"], wl["cond"])
+    torch.manual_seed(0)
+    net = pkg.GCPNetDynamics(**cfgs)
+    with torch.no_grad():   # default init, 2-D weights x0.25 keeps the free-running trajectory finite
+        for p in net.parameters():
+            if p.dim() == 2:
+                p.mul_(0.25)
+    net = net.to(dev)
+    ddpm = pkg.EquivariantVariationalDiffusion(net, cfgs["diffusion_cfg"], cfgs["dataloader_cfg"],
+                                               pkg.dataset_info("geom" if wl["dataset"] == "geom" else "qm9"))
+    dyn, lib, h = ddpm._native(dev)
+    num_nodes = torch.full((B,), wl["n"], dtype=torch.int32)
+    dyn.plan(num_nodes)
+    N, E = int(lib.gcdm_num_nodes(h)), int(lib.gcdm_num_edges(h))
+    D = 3 + d["num_atom_types"] + int(d["include_charges"])
+    z = torch.empty((N, D), dtype=torch.float32, device=dev)
+    out = torch.empty_like(z)
+    flags = torch.zeros(1, dtype=torch.int32, device=dev)
+    ctx = None
+    if d["n_ctx"]:
+        g = torch.Generator().manual_seed(2 + rank)
+        ctx = torch.randn((B, 1), generator=g).to(dev)[torch.repeat_interleave(torch.arange(B, device=dev), wl["n"])].contiguous()
+    cptr = C.c_void_p(ctx.data_ptr()) if ctx is not None else None
+    stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    seed = C.c_uint64(1234 + rank)
+    zp, fp = C.c_void_p(z.data_ptr()), C.c_void_p(flags.data_ptr())
+    T = 1000
+
+    def step(s):
+        st = lib.gcdm_sample_step(h, zp, cptr, s, T, None, seed, fp, stream)
+        if st < 0:
+            native.check(lib, h, st, "gcdm_sample_step")
+
+    log(f"plan: N={N} E={E} cpu_count={os.cpu_count()}")
+    native.check(lib, h, lib.gcdm_sample_init(h, zp, None, seed, stream), "gcdm_sample_init")
+    s_idx = T - 1
+    for _ in range(args.warmup):
+        step(s_idx)
+        s_idx -= 1
+
+    def barrier():
+        torch.cuda.synchronize(dev)
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize(dev)
+
+    barrier()
+    log("warm-up done")
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step(max(s_idx, 0))
+        s_idx -= 1
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    ms_per_step = elapsed / args.steps * 1e3
+    log(f"timed region: {ms_per_step:.3f} ms/step")
+
+    # dominant-kernel timing (HIP events on the launch stream, separate un-timed steps)
+    lib.gcdm_profile_enable(h, 1)
+    tot, cnt = 0.0, 0
+    for _ in range(3):
+        step(max(s_idx, 0))
+        s_idx -= 1
+        ms, nl = C.c_double(), C.c_int32()
+        native.check(lib, h, lib.gcdm_profile_edge_kernel_ms(h, C.byref(ms), C.byref(nl)), "gcdm_profile_edge_kernel_ms")
+        tot += ms.value
+        cnt += nl.value
+    lib.gcdm_profile_enable(h, 0)
+    edge_ms = tot / max(cnt, 1)
+
+    # finish the sample properly once (decode) so the path is exercised end to end, and gather like a real run would
+    native.check(lib, h, lib.gcdm_sample_final(h, zp, cptr, None, seed, C.c_void_p(out.data_ptr()), fp, stream), "gcdm_sample_final")
+    torch.cuda.synchronize(dev)
+    gather_ms = 0.0
+    if dist is not None:
+        tg = time.perf_counter()
+        bufs = [torch.empty_like(out) for _ in range(world)]
+        dist.all_gather(bufs, out)
+        torch.cuda.synchronize(dev)
+        gather_ms = (time.perf_counter() - tg) * 1e3
+    finite = bool(torch.isfinite(out).all().item())
+    fl = int(flags.item())
+
+    if rank == 0:
+        dims = (d["S"], d["V"], d["Se"], d["Ve"], d["L"], synth.dims_h_in(d))
+        alg_total, alg_edge_layer = algorithmic_flops(N, E, dims)
+        exe_total = float(lib.gcdm_forward_flops_executed(h))
+        achieved = alg_edge_layer / (edge_ms * 1e-3) / 1e12
+        res = {
+            "metric": "molecules/sec (1000-step DDPM sample)", "value": world * B / (ms_per_step * 1e-3 * NET_EVALS_PER_SAMPLE),
+            "unit": "molecules/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": wl["name"], "molecules_per_gpu": B, "atoms_per_molecule": wl["n"], "nodes_per_gpu": N,
+                       "edges_per_gpu": E, "noise": "on-device Philox", "weights": "default init, 2-D x0.25 (SURVEY 8d)",
+                       "value_definition": f"molecules / ({NET_EVALS_PER_SAMPLE} x measured s/step)", "parallelism": f"shard{world}",
+                       "final_gather_ms": gather_ms, "outputs_finite": finite, "flags": fl,
+                       "step_tflops_algorithmic": alg_total / (ms_per_step * 1e-3) / 1e12,
+                       "step_tflops_executed": exe_total / (ms_per_step * 1e-3) / 1e12},
+            "roofline": {"bound": "mfma", "kernel": "k_edge_msg", "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": None, "avg_launch_ms": edge_ms,
+                         "algorithmic_flop_per_launch": alg_edge_layer, "launches_per_step": d["L"]},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            log("cpu baseline ...")
+            res["cpu_baseline"] = cpu_baseline(wl["dataset"], wl["cond"], dims)
+            log("cpu baseline done")
+        print(json.dumps(res))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -31,6 +31,7 @@ EXPORTS = [
     "gcdm_create", "gcdm_destroy", "gcdm_last_error", "gcdm_set_weight", "gcdm_finalize_weights", "gcdm_set_gamma",
     "gcdm_plan_batch", "gcdm_forward", "gcdm_sample_step", "gcdm_sample_final", "gcdm_sample_init", "gcdm_debug_read",
     "gcdm_debug_set_layer_limit", "gcdm_num_nodes", "gcdm_num_edges", "gcdm_forward_flops_executed",
+    "gcdm_profile_enable", "gcdm_profile_edge_kernel_ms",
 ]
 
 _lib: Optional[C.CDLL] = None
@@ -76,6 +77,8 @@ def load() -> C.CDLL:
     lib.gcdm_num_nodes.restype = C.c_int64
     lib.gcdm_num_edges.argtypes = [H]
     lib.gcdm_num_edges.restype = C.c_int64
+    lib.gcdm_profile_enable.argtypes = [H, C.c_int32]
+    lib.gcdm_profile_edge_kernel_ms.argtypes = [H, C.POINTER(C.c_double), C.POINTER(C.c_int32)]
     lib.gcdm_forward_flops_executed.argtypes = [H]
     lib.gcdm_forward_flops_executed.restype = C.c_double
     for name in EXPORTS:

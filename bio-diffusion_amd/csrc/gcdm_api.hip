@@ -49,10 +49,15 @@ struct gcdm_handle {
     float* ws = nullptr;  // workspace pool
     size_t ws_floats = 0;
     float *X0 = nullptr, *XC = nullptr, *FBAR = nullptr, *CHI0 = nullptr, *HIN4 = nullptr, *H4 = nullptr, *CHI = nullptr, *PQ4 = nullptr,
-          *VDI = nullptr, *VDJ = nullptr, *AGG = nullptr, *VEL = nullptr, *EPS = nullptr, *TBUF = nullptr, *EP4 = nullptr, *AL = nullptr, *U = nullptr, *FR = nullptr;
+          *VDI = nullptr, *VDJ = nullptr, *AGG = nullptr, *VEL = nullptr, *EPS = nullptr, *TBUF = nullptr, *EP4 = nullptr, *AL = nullptr, *U = nullptr, *FR = nullptr, *PROF = nullptr;
     uint32_t* d_flags = nullptr;
     int layer_limit = -1;
     bool attr_set = false;
+    // profiling (HIP events around the k_edge_msg launches of one forward)
+    bool profile = false;
+    bool profile_phases = false;     // enable == 2: in-kernel phase time stamps (debug_read("phase"))
+    std::vector<hipEvent_t> ev;      // 2 per layer
+    int ev_used = 0;
 };
 
 namespace {
@@ -257,6 +262,7 @@ int gcdm_destroy(gcdm_handle* h) {
     if (!h) return 0;
     (void)hipSetDevice(h->cfg.device);
     free_plan(h);
+    for (auto& e : h->ev) (void)hipEventDestroy(e);
     if (h->wpool) (void)hipFree(h->wpool);
     if (h->d_flags) (void)hipFree(h->d_flags);
     delete h;
@@ -437,14 +443,14 @@ int gcdm_plan_batch(gcdm_handle* h, int32_t B, const int32_t* nn) {
     const size_t oX0 = take(3 * n), oXC = take(3 * n), oFB = take(9 * n), oC0 = take(6 * n), oHIN = take(4 * h->FinG * n), oH4 = take(GCDM_S * n),
                  oCHI = take(96 * n), oPQ = take(512 * n), oVDI = take((size_t)(h->H0 + 3) * 3 * n), oVDJ = take((size_t)(h->H0 + 3) * 3 * n),
                  oAGG = take(GCDM_AGGW * n), oVEL = take(3 * n), oEPS = take((size_t)h->D * n), oT = take(n), oEP = take((size_t)h->Se * e),
-                 oAL = take((size_t)h->Ve * e), oU = take(3 * e), oFR = take(9 * e);
+                 oAL = take((size_t)h->Ve * e), oU = take(3 * e), oFR = take(9 * e), oPROF = take(((e + ET - 1) / ET) * 192);
     h->ws_floats = off;
     HIP_OK(h, hipMalloc(&h->ws, off * sizeof(float)));
     HIP_OK(h, hipMemset(h->ws, 0, off * sizeof(float)));
     float* w = h->ws;
     h->X0 = w + oX0; h->XC = w + oXC; h->FBAR = w + oFB; h->CHI0 = w + oC0; h->HIN4 = w + oHIN; h->H4 = w + oH4; h->CHI = w + oCHI;
     h->PQ4 = w + oPQ; h->VDI = w + oVDI; h->VDJ = w + oVDJ; h->AGG = w + oAGG; h->VEL = w + oVEL; h->EPS = w + oEPS; h->TBUF = w + oT; h->EP4 = w + oEP;
-    h->AL = w + oAL; h->U = w + oU; h->FR = w + oFR;
+    h->AL = w + oAL; h->U = w + oU; h->FR = w + oFR; h->PROF = w + oPROF;
     h->B = B; h->N = N; h->E = E; h->max_n = max_n;
     return 0;
 }
@@ -505,8 +511,11 @@ int gcdm_forward(gcdm_handle* h, const float* xh, const float* t, const float* c
         ma.w0 = d.w0; ma.G0 = d.G0; ma.wddE = d.wddE; ma.wg0 = d.wg0; ma.bg0 = d.bg0; ma.wup0 = d.wup0;
         for (int k = 0; k < 3; ++k) ma.mk[k] = d.mk[k];
         ma.wa = d.wa; ma.ba = d.ba;
-        if (h->Se == 64) hipLaunchKernelGGL((k_edge_msg<64, 16>), dim3(tiles), dim3(256), EK_LDS_BYTES, st, ma);
-        else hipLaunchKernelGGL((k_edge_msg<16, 8>), dim3(tiles), dim3(256), EK_LDS_BYTES, st, ma);
+        ma.prof = h->profile_phases ? h->PROF : nullptr;
+        if (h->profile) HIP_OK(h, hipEventRecord(h->ev[2 * l], st));
+        if (h->Se == 64) hipLaunchKernelGGL((k_edge_msg<64, 16>), dim3(tiles), dim3(EK_THREADS), EK_LDS_BYTES, st, ma);
+        else hipLaunchKernelGGL((k_edge_msg<16, 8>), dim3(tiles), dim3(EK_THREADS), EK_LDS_BYTES, st, ma);
+        if (h->profile) { HIP_OK(h, hipEventRecord(h->ev[2 * l + 1], st)); h->ev_used = l + 1; }
         na.ff = d.ff; na.pos = d.pos;
         set_next(l + 1);   // next layer's msg0 halves, or the output projection after the last layer
         hipLaunchKernelGGL(k_node<false>, dim3(ngrid), dim3(256), NK_LDS_BYTES, st, na);
@@ -598,6 +607,33 @@ int gcdm_sample_final(gcdm_handle* h, const float* z0, const float* context, con
     return 0;
 }
 
+int gcdm_profile_enable(gcdm_handle* h, int32_t enable) {
+    if (!h) return -1;
+    HIP_OK(h, hipSetDevice(h->cfg.device));
+    if (enable && h->ev.empty()) {
+        h->ev.resize(2 * (size_t)h->L);
+        for (auto& e : h->ev) HIP_OK(h, hipEventCreate(&e));
+    }
+    h->profile = enable != 0;
+    h->profile_phases = enable == 2;
+    h->ev_used = 0;
+    return 0;
+}
+
+int gcdm_profile_edge_kernel_ms(gcdm_handle* h, double* total_ms, int32_t* launches) {
+    if (!h || !total_ms || !launches) return fail(h, "gcdm_profile_edge_kernel_ms: bad argument");
+    double tot = 0.0;
+    for (int l = 0; l < h->ev_used; ++l) {
+        HIP_OK(h, hipEventSynchronize(h->ev[2 * l + 1]));
+        float ms = 0.f;
+        HIP_OK(h, hipEventElapsedTime(&ms, h->ev[2 * l], h->ev[2 * l + 1]));
+        tot += ms;
+    }
+    *total_ms = tot;
+    *launches = h->ev_used;
+    return 0;
+}
+
 int64_t gcdm_debug_read(gcdm_handle* h, const char* name, float* host_out, int64_t capacity) {
     if (!h || !name || !h->N) return fail(h, "gcdm_debug_read: bad argument / no plan");
     const int64_t n = h->N, e = h->E;
@@ -620,6 +656,7 @@ int64_t gcdm_debug_read(gcdm_handle* h, const char* name, float* host_out, int64
     else if (k == "fbar") { p = h->FBAR; cnt = 9 * n; }
     else if (k == "chi0") { p = h->CHI0; cnt = 6 * n; }
     else if (k == "vel") { p = h->VEL; cnt = 3 * n; }
+    else if (k == "phase") { p = h->PROF; cnt = ((e + ET - 1) / ET) * 192; }
     else return fail(h, "gcdm_debug_read: unknown buffer " + k);
     if (!host_out) return cnt;
     if (capacity < cnt) return fail(h, "gcdm_debug_read: capacity too small");

@@ -28,7 +28,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 #define MFMA32(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
 
-__device__ __forceinline__ float fast_sigmoid(float x) { return __frcp_rn(1.0f + __expf(-x)); }
+__device__ __forceinline__ float fast_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 __device__ __forceinline__ float fast_silu(float x) { return x * fast_sigmoid(x); }
 
 // ------------------------------------------------------------------------------------------------
@@ -53,29 +53,70 @@ struct GcpW {
 // tile GEMM:  acc[m][n] += Wpacked(M-tiles mt0..mt0+MT-1) . XS4(groups gbase .. gbase+2G-1)
 // ------------------------------------------------------------------------------------------------
 template <int MT, int NT>
+__device__ __forceinline__ void gemm_group(f32x16 (&acc)[MT][NT], const v4f (&a)[MT], const v4f (&b)[NT]) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int n = 0; n < NT; ++n) acc[m][n] = MFMA32(a[m][t], b[n][t], acc[m][n]);
+}
+
+template <int MT, int NT, int PD = 4>
 __device__ __forceinline__ void tile_gemm(f32x16 (&acc)[MT][NT], const v4f* __restrict__ wp, int G,
                                           const v4f* xs4, int TP, int lane) {
+    // A (weights) streams L2 -> VGPR through a ring of R = PD+1 statically indexed register sets: the load of k-group
+    // g+PD is issued before the MFMAs of group g, so the compiler's counted s_waitcnt leaves PD groups in flight.
+    // B (activations) is read from LDS one group ahead (two alternating register sets).  The main loop is branch-free
+    // (whole rings only); the remainder runs as a straight-line tail.
+    constexpr int R = PD + 1;
+    static_assert(R % 2 == 1 || true, "");
     const v4f* wl = wp + lane;
     const v4f* sl = xs4 + (lane >> 5) * TP + (lane & 31);
     const int wstride = G * 64;
-    v4f a_cur[MT], a_nxt[MT];
+    const int last = G - 1;
+    v4f a[R][MT];
+    v4f b[2][NT];
 #pragma unroll
-    for (int m = 0; m < MT; ++m) a_cur[m] = wl[m * wstride];
-    for (int g = 0; g < G; ++g) {
-        const int gn = (g + 1 < G) ? g + 1 : g;
+    for (int r = 0; r < PD; ++r) {
+        const int gl = min(r, last);
 #pragma unroll
-        for (int m = 0; m < MT; ++m) a_nxt[m] = wl[m * wstride + gn * 64];
-        v4f b[NT];
+        for (int m = 0; m < MT; ++m) a[r][m] = wl[m * wstride + gl * 64];
+    }
 #pragma unroll
-        for (int n = 0; n < NT; ++n) b[n] = sl[(2 * g) * TP + n * 32];
+    for (int n = 0; n < NT; ++n) b[0][n] = sl[n * 32];
+    int g0 = 0;
+    for (; g0 + 2 * R <= G; g0 += 2 * R) {   // two rings per trip so that the B double buffer index is static too
 #pragma unroll
-        for (int t = 0; t < 4; ++t)
+        for (int r = 0; r < 2 * R; ++r) {
+            const int g = g0 + r;
+            const int gl = min(g + PD, last);
 #pragma unroll
-            for (int m = 0; m < MT; ++m)
+            for (int m = 0; m < MT; ++m) a[(r + PD) % R][m] = wl[m * wstride + gl * 64];
+            const int gb = min(g + 1, last);
 #pragma unroll
-                for (int n = 0; n < NT; ++n) acc[m][n] = MFMA32(a_cur[m][t], b[n][t], acc[m][n]);
+            for (int n = 0; n < NT; ++n) b[(r + 1) & 1][n] = sl[(2 * gb) * TP + n * 32];
+            __builtin_amdgcn_sched_barrier(0);   // keep the prefetches ABOVE this group's MFMAs (the scheduler sinks them otherwise)
+            gemm_group<MT, NT>(acc, a[r % R], b[r & 1]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
 #pragma unroll
-        for (int m = 0; m < MT; ++m) a_cur[m] = a_nxt[m];
+    for (int r = 0; r < 2 * R - 1; ++r) {
+        const int g = g0 + r;
+        if (g < G) {
+            if (r + PD < 2 * R - 1) {
+                const int gl = min(g + PD, last);
+#pragma unroll
+                for (int m = 0; m < MT; ++m) a[(r + PD) % R][m] = wl[m * wstride + gl * 64];
+            }
+            const int gb = min(g + 1, last);
+#pragma unroll
+            for (int n = 0; n < NT; ++n) b[(r + 1) & 1][n] = sl[(2 * gb) * TP + n * 32];
+            __builtin_amdgcn_sched_barrier(0);
+            gemm_group<MT, NT>(acc, a[r % R], b[r & 1]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
     }
 }
 
@@ -113,20 +154,20 @@ __device__ __forceinline__ void gate_partial(f32x16 (&gacc)[NT], const f32x16 (&
 
 // PG[wave][c][e] <- gacc  (c = 8*(r>>2) + 4*half + (r&3))
 template <int NT>
-__device__ __forceinline__ void store_gate_partial(float* PG, const f32x16 (&gacc)[NT], int TP, int wave, int lane) {
+__device__ __forceinline__ void store_gate_partial(float* PG, const f32x16 (&gacc)[NT], int TP, int slot, int lane, int col0 = 0) {
     const int half = lane >> 5, l31 = lane & 31;
 #pragma unroll
     for (int n = 0; n < NT; ++n)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int c = (r & 3) + 8 * (r >> 2) + 4 * half;
-            PG[(wave * 32 + c) * TP + 32 * n + l31] = gacc[n][r];
+            PG[(slot * 32 + c) * TP + col0 + 32 * n + l31] = gacc[n][r];
         }
 }
 
 // XS4[gbase + own groups][e] (+)= acc
 template <int MT, int NT, bool ADD>
-__device__ __forceinline__ void store_state(v4f* xs4, int gbase, const f32x16 (&acc)[MT][NT], int TP, int mt0, int lane) {
+__device__ __forceinline__ void store_state(v4f* xs4, int gbase, const f32x16 (&acc)[MT][NT], int TP, int mt0, int lane, int col0 = 0) {
     const int half = lane >> 5, l31 = lane & 31;
 #pragma unroll
     for (int m = 0; m < MT; ++m)
@@ -134,7 +175,7 @@ __device__ __forceinline__ void store_state(v4f* xs4, int gbase, const f32x16 (&
         for (int n = 0; n < NT; ++n)
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const int idx = (gbase + 8 * (mt0 + m) + 2 * q + half) * TP + 32 * n + l31;
+                const int idx = (gbase + 8 * (mt0 + m) + 2 * q + half) * TP + col0 + 32 * n + l31;
                 v4f v = {acc[m][n][4 * q], acc[m][n][4 * q + 1], acc[m][n][4 * q + 2], acc[m][n][4 * q + 3]};
                 if (ADD) v += xs4[idx];
                 xs4[idx] = v;
@@ -156,31 +197,43 @@ __device__ __forceinline__ void apply_silu(f32x16 (&acc)[MT][NT]) {
 //   vh = W_down v ; n = sqrt(sum_xyz vh^2 + 1e-8) + 1e-8 ; u = W_frames v ; q[3k+r] = F[r,:].u[:,k]
 // rows hh of [W_down; W_frames] are split over the PARTS threads that share an entity.
 // ------------------------------------------------------------------------------------------------
-template <int T>
-__device__ __forceinline__ void gcp2_pre(const float* __restrict__ wdd, int H, int V_in, const float* VV, int vch0,
-                                         const float* FR, float* XSf, int gN, int gQ, int gEnd, float* VH, int e,
-                                         int part) {
-    constexpr int TP = T + 1, PARTS = 256 / T;
+template <int T, int H, int V_IN, int NTHR = 256>
+__device__ __forceinline__ void gcp2_pre(const float* __restrict__ wdd, const float* VV, int vch0, const float* FR, float* XSf,
+                                         int gN, int gQ, int gEnd, float* VH, int e, int part) {
+    constexpr int TP = T + 1, PARTS = NTHR / T, ROWS = H + 3, NH = (ROWS + PARTS - 1) / PARTS;
+    // each thread owns rows hh = part + PARTS*i of [W_down; W_frames]; the V_IN input vectors are read from LDS once
+    float ax[NH], ay[NH], az[NH];
+    const float* wrow[NH];
+#pragma unroll
+    for (int i = 0; i < NH; ++i) {
+        ax[i] = ay[i] = az[i] = 0.f;
+        const int hh = part + PARTS * i;
+        wrow[i] = wdd + (hh < ROWS ? hh : ROWS - 1) * V_IN;
+    }
+    const float* vp = VV + (vch0 * 3) * TP + e;
+#pragma unroll 8
+    for (int c = 0; c < V_IN; ++c) {
+        const float vx = vp[0], vy = vp[TP], vz = vp[2 * TP];
+        vp += 3 * TP;
+#pragma unroll
+        for (int i = 0; i < NH; ++i) {
+            const float wc = wrow[i][c];
+            ax[i] += wc * vx; ay[i] += wc * vy; az[i] += wc * vz;
+        }
+    }
     float f[9];
 #pragma unroll
     for (int r = 0; r < 9; ++r) f[r] = FR[r * TP + e];
-    for (int hh = part; hh < H + 3; hh += PARTS) {
-        const float* w = wdd + hh * V_in;
-        const float* vp = VV + (vch0 * 3) * TP + e;
-        float vx = 0.f, vy = 0.f, vz = 0.f;
-        for (int c = 0; c < V_in; ++c) {
-            const float wc = w[c];
-            vx += wc * vp[0];
-            vy += wc * vp[TP];
-            vz += wc * vp[2 * TP];
-            vp += 3 * TP;
-        }
+#pragma unroll
+    for (int i = 0; i < NH; ++i) {
+        const int hh = part + PARTS * i;
+        const float vx = ax[i], vy = ay[i], vz = az[i];
         if (hh < H) {
             XSf[((gN + (hh >> 2)) * TP + e) * 4 + (hh & 3)] = sqrtf(vx * vx + vy * vy + vz * vz + 1e-8f) + 1e-8f;
             VH[(hh * 3 + 0) * TP + e] = vx;
             VH[(hh * 3 + 1) * TP + e] = vy;
             VH[(hh * 3 + 2) * TP + e] = vz;
-        } else {
+        } else if (hh < ROWS) {
             const int k = hh - H;
 #pragma unroll
             for (int r = 0; r < 3; ++r) {
@@ -197,10 +250,17 @@ __device__ __forceinline__ void gcp2_pre(const float* __restrict__ wdd, int H, i
 }
 
 // vector output: v'[c] = (W_up vh)[c] * sigmoid(gate[c])  (gcpnet.py:388-411); channels split over PARTS threads
-template <int T, typename StoreFn>
+template <int T, int H, int NTHR = 256, typename StoreFn>
 __device__ __forceinline__ void vec_finish(const float* PG, const float* __restrict__ bg, const float* __restrict__ wup,
-                                           int H, int V_out, const float* VH, int e, int part, StoreFn store) {
-    constexpr int TP = T + 1, PARTS = 256 / T;
+                                           int V_out, const float* VH, int e, int part, StoreFn store) {
+    constexpr int TP = T + 1, PARTS = NTHR / T;
+    float hx[H], hy[H], hz[H];
+#pragma unroll
+    for (int h = 0; h < H; ++h) {
+        hx[h] = VH[(h * 3 + 0) * TP + e];
+        hy[h] = VH[(h * 3 + 1) * TP + e];
+        hz[h] = VH[(h * 3 + 2) * TP + e];
+    }
     for (int c = part; c < V_out; c += PARTS) {
         float g = bg[c];
 #pragma unroll
@@ -208,11 +268,10 @@ __device__ __forceinline__ void vec_finish(const float* PG, const float* __restr
         const float sg = fast_sigmoid(g);
         float ox = 0.f, oy = 0.f, oz = 0.f;
         const float* wu = wup + c * H;
+#pragma unroll
         for (int h = 0; h < H; ++h) {
             const float wv = wu[h];
-            ox += wv * VH[(h * 3 + 0) * TP + e];
-            oy += wv * VH[(h * 3 + 1) * TP + e];
-            oz += wv * VH[(h * 3 + 2) * TP + e];
+            ox += wv * hx[h]; oy += wv * hy[h]; oz += wv * hz[h];
         }
         store(c, ox * sg, oy * sg, oz * sg);
     }
@@ -403,9 +462,15 @@ struct EdgeMsgArgs {
     // msg1..3
     GcpW mk[3];
     const float* wa; float ba;   // scalar_message_attention
+    float* prof;                 // optional [tiles][8 waves][24] phase time stamps (shader cycles since kernel start)
 };
 
-constexpr int ET = 64, ETP = 65;
+#define STAMP(i)                                                                                        \
+    do {                                                                                                \
+        if (a.prof && lane == 0) a.prof[((size_t)blockIdx.x * 8 + wave) * 24 + (i)] = (float)(__builtin_amdgcn_s_memtime() - t_start); \
+    } while (0)
+
+constexpr int ET = 64, ETP = 65, EK_THREADS = 512;
 constexpr int EK_XS_GROUPS = 72;
 constexpr int EK_OFF_XS = 0;
 constexpr int EK_OFF_VV = EK_OFF_XS + EK_XS_GROUPS * ETP * 16;
@@ -416,7 +481,7 @@ constexpr int EK_OFF_META = EK_OFF_FR + 9 * ETP * 4;
 constexpr int EK_LDS_BYTES = EK_OFF_META + (64 + 64 + 66 + 64 + 4) * 4;
 
 template <int SE, int VE>
-__global__ __launch_bounds__(256) void k_edge_msg(EdgeMsgArgs a) {
+__global__ __launch_bounds__(EK_THREADS) void k_edge_msg(EdgeMsgArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     v4f* XS4 = (v4f*)(smem + EK_OFF_XS);
     float* XSf = (float*)XS4;
@@ -435,12 +500,14 @@ __global__ __launch_bounds__(256) void k_edge_msg(EdgeMsgArgs a) {
     constexpr int SEG = SE / 4;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int e = lane, part = wave;  // T = 64: entity = lane, the 4 waves are the 4 "parts"
+    const int e = lane, part = wave;  // T = 64: entity = lane, the 8 waves are the 8 "parts" of the VALU phases
+    constexpr int PARTS = EK_THREADS / ET;
     const int E = a.E, N = a.N;
     const int e0 = blockIdx.x * ET;
     const int nvalid = min(ET, E - e0);
     const int eid = min(e0 + e, E - 1);
     const int ni = a.EROW[eid], nj = a.ECOL[eid];
+    const uint64_t t_start = a.prof ? __builtin_amdgcn_s_memtime() : 0;
 
     // ---- P0: tile metadata + row segments (wave 0) -------------------------------------------
     if (wave == 0) {
@@ -466,27 +533,42 @@ __global__ __launch_bounds__(256) void k_edge_msg(EdgeMsgArgs a) {
 #pragma unroll
             for (int r = 0; r < 9; ++r) FR[r * ETP + e] = fr[r];
         }
-        for (int g = part; g < SEG; g += 4) XS4[g * ETP + e] = a.EP4[(size_t)g * E + eid];
+        for (int g = part; g < SEG; g += PARTS) XS4[g * ETP + e] = a.EP4[(size_t)g * E + eid];
         float al[VE];
 #pragma unroll
         for (int c = 0; c < VE; ++c) al[c] = a.AL[(size_t)c * E + eid];
         const float u0 = a.U[eid], u1 = a.U[(size_t)E + eid], u2 = a.U[2 * (size_t)E + eid];
         constexpr int gN = SEG, gQ = SEG + H0G;
-        for (int hh = part; hh < H0 + 3; hh += 4) {
-            const float* w = a.wddE + hh * VE;
-            float beta = 0.f;
+        constexpr int ROWS0 = H0 + 3, NH0 = (ROWS0 + PARTS - 1) / PARTS;
+        // all node-side gathers of this thread's rows are issued before the first use (static unroll)
+        float gi[NH0][3], gj[NH0][3], beta[NH0];
 #pragma unroll
-            for (int c = 0; c < VE; ++c) beta += w[c] * al[c];
+        for (int i = 0; i < NH0; ++i) {
+            const int hh = min(part + PARTS * i, ROWS0 - 1);
             const size_t r0 = (size_t)(hh * 3) * N;
-            const float vx = a.VDI[r0 + ni] + beta * u0 + a.VDJ[r0 + nj];
-            const float vy = a.VDI[r0 + N + ni] + beta * u1 + a.VDJ[r0 + N + nj];
-            const float vz = a.VDI[r0 + 2 * (size_t)N + ni] + beta * u2 + a.VDJ[r0 + 2 * (size_t)N + nj];
+#pragma unroll
+            for (int x = 0; x < 3; ++x) {
+                gi[i][x] = a.VDI[r0 + (size_t)x * N + ni];
+                gj[i][x] = a.VDJ[r0 + (size_t)x * N + nj];
+            }
+            const float* w = a.wddE + hh * VE;
+            float bsum = 0.f;
+#pragma unroll
+            for (int c = 0; c < VE; ++c) bsum += w[c] * al[c];
+            beta[i] = bsum;
+        }
+#pragma unroll
+        for (int i = 0; i < NH0; ++i) {
+            const int hh = part + PARTS * i;
+            const float vx = gi[i][0] + beta[i] * u0 + gj[i][0];
+            const float vy = gi[i][1] + beta[i] * u1 + gj[i][1];
+            const float vz = gi[i][2] + beta[i] * u2 + gj[i][2];
             if (hh < H0) {
                 XSf[((gN + (hh >> 2)) * ETP + e) * 4 + (hh & 3)] = sqrtf(vx * vx + vy * vy + vz * vz + 1e-8f) + 1e-8f;
                 VH[(hh * 3 + 0) * ETP + e] = vx;
                 VH[(hh * 3 + 1) * ETP + e] = vy;
                 VH[(hh * 3 + 2) * ETP + e] = vz;
-            } else {
+            } else if (hh < ROWS0) {
                 const int k = hh - H0;
 #pragma unroll
                 for (int r = 0; r < 3; ++r) {
@@ -501,18 +583,20 @@ __global__ __launch_bounds__(256) void k_edge_msg(EdgeMsgArgs a) {
             for (int g = gQ + 3; g < 2 * a.G0; ++g) XS4[g * ETP + e] = (v4f){0.f, 0.f, 0.f, 0.f};
         }
     }
+    STAMP(1);
     __syncthreads();
+    STAMP(2);
 
     const int half = lane >> 5, l31 = lane & 31;
-    const int mt0 = 2 * wave;  // this wave's two M-tiles (64 output channels), both N-tiles
-    f32x16 acc[2][2];
-    f32x16 gacc[2];
+    const int mt0 = 2 * (wave & 3);   // this wave's two M-tiles (64 output channels) ...
+    const int col0 = 32 * (wave >> 2);  // ... of one N-tile (32 of the 64 edges); waves w and w+4 share the weight stream via L1
+    f32x16 acc[2][1];
+    f32x16 gacc[1];
 
     // ---- P2: msg0 GEMM.  acc starts from the node-level halves P_i + Q_j of scalar_out -----------
     {
-#pragma unroll
-        for (int n = 0; n < 2; ++n) {
-            const int ri = m_row[32 * n + l31], cj = m_col[32 * n + l31];
+        {
+            const int ri = m_row[col0 + l31], cj = m_col[col0 + l31];
 #pragma unroll
             for (int m = 0; m < 2; ++m)
 #pragma unroll
@@ -521,70 +605,89 @@ __global__ __launch_bounds__(256) void k_edge_msg(EdgeMsgArgs a) {
                     const v4f p = a.PQ4[(size_t)g * N + ri];
                     const v4f qq = a.PQ4[(size_t)(64 + g) * N + cj];
 #pragma unroll
-                    for (int t = 0; t < 4; ++t) acc[m][n][4 * q + t] = p[t] + qq[t];
+                    for (int t = 0; t < 4; ++t) acc[m][0][4 * q + t] = p[t] + qq[t];
                 }
         }
-        tile_gemm<2, 2>(acc, a.w0 + (size_t)mt0 * a.G0 * 64, a.G0, XS4, ETP, lane);
-        apply_silu<2, 2>(acc);
+        STAMP(3);
+        tile_gemm<2, 1>(acc, a.w0 + (size_t)mt0 * a.G0 * 64, a.G0, XS4 + col0, ETP, lane);
+        STAMP(4);
+        apply_silu<2, 1>(acc);
+        STAMP(5);
 #pragma unroll
-        for (int n = 0; n < 2; ++n)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) gacc[n][r] = 0.f;
-        gate_partial<2, 2>(gacc, acc, a.wg0, mt0, lane);
-        store_gate_partial<2>(PG, gacc, ETP, wave, lane);
+        for (int r = 0; r < 16; ++r) gacc[0][r] = 0.f;
+        gate_partial<2, 1>(gacc, acc, a.wg0, mt0, lane);
+        store_gate_partial<1>(PG, gacc, ETP, wave & 3, lane, col0);
+        STAMP(6);
     }
     __syncthreads();
+    STAMP(7);
     // ---- P3: m.s = silu(p) ; m.v = (W_up vh) * sigmoid(gate) -------------------------------------
-    store_state<2, 2, false>(XS4, 0, acc, ETP, mt0, lane);
-    vec_finish<ET>(PG, a.bg0, a.wup0, H0, GCDM_V, VH, e, part, [&](int c, float ox, float oy, float oz) {
+    store_state<2, 1, false>(XS4, 0, acc, ETP, mt0, lane, col0);
+    vec_finish<ET, H0, EK_THREADS>(PG, a.bg0, a.wup0, GCDM_V, VH, e, part, [&](int c, float ox, float oy, float oz) {
         VV[(c * 3 + 0) * ETP + e] = ox;
         VV[(c * 3 + 1) * ETP + e] = oy;
         VV[(c * 3 + 2) * ETP + e] = oz;
     });
+    STAMP(8);
     __syncthreads();
+    STAMP(9);
 
     // ---- residual message GCP2s k = 1..3 (gcpnet.py:698-701) ------------------------------------
     for (int k = 0; k < 3; ++k) {
         const GcpW& w = a.mk[k];
-        gcp2_pre<ET>(w.wdd, w.H, GCDM_V, VV, 0, FR, XSf, GCDM_SG, GCDM_SG + 2, 2 * w.G, VH, e, part);
+        gcp2_pre<ET, 8, GCDM_V, EK_THREADS>(w.wdd, VV, 0, FR, XSf, GCDM_SG, GCDM_SG + 2, 2 * w.G, VH, e, part);
+        if (k == 0) STAMP(10);
         __syncthreads();
-        acc_init_bias<2, 2>(acc, w.b, mt0, lane);
-        tile_gemm<2, 2>(acc, w.w + (size_t)mt0 * w.G * 64, w.G, XS4, ETP, lane);
-        apply_silu<2, 2>(acc);
+        if (k == 0) STAMP(11);
+        acc_init_bias<2, 1>(acc, w.b, mt0, lane);
+        tile_gemm<2, 1>(acc, w.w + (size_t)mt0 * w.G * 64, w.G, XS4 + col0, ETP, lane);
+        if (k == 0) STAMP(12);
+        apply_silu<2, 1>(acc);
+        if (k == 0) STAMP(13);
 #pragma unroll
-        for (int n = 0; n < 2; ++n)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) gacc[n][r] = 0.f;
-        gate_partial<2, 2>(gacc, acc, w.wg, mt0, lane);
-        store_gate_partial<2>(PG, gacc, ETP, wave, lane);
+        for (int r = 0; r < 16; ++r) gacc[0][r] = 0.f;
+        gate_partial<2, 1>(gacc, acc, w.wg, mt0, lane);
+        store_gate_partial<1>(PG, gacc, ETP, wave & 3, lane, col0);
+        if (k == 0) STAMP(14);
         __syncthreads();
-        store_state<2, 2, true>(XS4, 0, acc, ETP, mt0, lane);
-        vec_finish<ET>(PG, w.bg, w.wup, w.H, GCDM_V, VH, e, part, [&](int c, float ox, float oy, float oz) {
+        if (k == 0) STAMP(15);
+        store_state<2, 1, true>(XS4, 0, acc, ETP, mt0, lane, col0);
+        vec_finish<ET, 8, EK_THREADS>(PG, w.bg, w.wup, GCDM_V, VH, e, part, [&](int c, float ox, float oy, float oz) {
             VV[(c * 3 + 0) * ETP + e] += ox;
             VV[(c * 3 + 1) * ETP + e] += oy;
             VV[(c * 3 + 2) * ETP + e] += oz;
         });
+        if (k == 0) STAMP(16);
         __syncthreads();
+        if (k == 0) STAMP(17);
     }
+    STAMP(18);
 
     // ---- scalar message attention (gcpnet.py:709-711): att = sigmoid(w_a . m.s + b_a) -----------
     {
         float s = 0.f;
-        for (int g = part * 16; g < part * 16 + 16; ++g) {
+        constexpr int GPP = GCDM_SG / PARTS;
+        for (int g = part * GPP; g < part * GPP + GPP; ++g) {
             const v4f wv = *(const v4f*)(a.wa + 4 * g);
             const v4f x = XS4[g * ETP + e];
             s += wv[0] * x[0] + wv[1] * x[1] + wv[2] * x[2] + wv[3] * x[3];
         }
         PG[part * ETP + e] = s;
         __syncthreads();
-        if (wave == 0) m_att[e] = fast_sigmoid(PG[e] + PG[ETP + e] + PG[2 * ETP + e] + PG[3 * ETP + e] + a.ba);
+        if (wave == 0) {
+            float s2 = a.ba;
+#pragma unroll
+            for (int q = 0; q < PARTS; ++q) s2 += PG[q * ETP + e];
+            m_att[e] = fast_sigmoid(s2);
+        }
         __syncthreads();
     }
+    STAMP(19);
     // ---- aggregation: agg_i = sum_j [m.s * att | m.v]  over the row segments of this tile --------
     {
         const int nseg = m_misc[0];
         constexpr int UNITS = GCDM_SG + 3 * GCDM_V;  // 64 float4 scalar groups + 96 vector floats
-        for (int wk = tid; wk < nseg * UNITS; wk += 256) {
+        for (int wk = tid; wk < nseg * UNITS; wk += EK_THREADS) {
             const int sg = wk / UNITS, un = wk - sg * UNITS;
             const int st = m_seg[sg], en = m_seg[sg + 1];
             const int node = m_row[st];
@@ -608,6 +711,7 @@ __global__ __launch_bounds__(256) void k_edge_msg(EdgeMsgArgs a) {
             }
         }
     }
+    STAMP(20);
 }
 
 // ================================================================================================
@@ -688,7 +792,7 @@ __global__ __launch_bounds__(256) void k_node(NodeArgs a) {
         __syncthreads();
         const GcpW& w = a.emb;
         const int gN = a.FinG, gQ = gN + (w.H + 3) / 4;
-        gcp2_pre<NT_>(w.wdd, w.H, 2, VV, 0, FR, XSf, gN, gQ, 2 * w.G, VH, e, part);
+        gcp2_pre<NT_, 32, 2>(w.wdd, VV, 0, FR, XSf, gN, gQ, 2 * w.G, VH, e, part);
         __syncthreads();
         acc_init_bias<2, 1>(acc, w.b, mt0, lane);
         tile_gemm<2, 1>(acc, w.w + (size_t)mt0 * w.G * 64, w.G, XS4, NTP, lane);
@@ -698,7 +802,7 @@ __global__ __launch_bounds__(256) void k_node(NodeArgs a) {
         store_gate_partial<1>(PG, gacc, NTP, wave, lane);
         __syncthreads();
         store_state<2, 1, false>(XS4, HB, acc, NTP, mt0, lane);
-        vec_finish<NT_>(PG, w.bg, w.wup, w.H, GCDM_V, VH, e, part, [&](int c, float ox, float oy, float oz) {
+        vec_finish<NT_, 32>(PG, w.bg, w.wup, GCDM_V, VH, e, part, [&](int c, float ox, float oy, float oz) {
             VV[((CB + c) * 3 + 0) * NTP + e] = ox;
             VV[((CB + c) * 3 + 1) * NTP + e] = oy;
             VV[((CB + c) * 3 + 2) * NTP + e] = oz;
@@ -720,7 +824,7 @@ __global__ __launch_bounds__(256) void k_node(NodeArgs a) {
         {
             const GcpW& w = a.ff;
             const int gN = 2 * GCDM_SG, gQ = gN + (w.H + 3) / 4;
-            gcp2_pre<NT_>(w.wdd, w.H, 2 * GCDM_V, VV, 0, FR, XSf, gN, gQ, 2 * w.G, VH, e, part);
+            gcp2_pre<NT_, 16, 2 * GCDM_V>(w.wdd, VV, 0, FR, XSf, gN, gQ, 2 * w.G, VH, e, part);
             __syncthreads();
             acc_init_bias<2, 1>(acc, w.b, mt0, lane);
             tile_gemm<2, 1>(acc, w.w + (size_t)mt0 * w.G * 64, w.G, XS4, NTP, lane);
@@ -735,7 +839,7 @@ __global__ __launch_bounds__(256) void k_node(NodeArgs a) {
             store_gate_partial<1>(PG, gacc, NTP, wave, lane);
             __syncthreads();
             store_state<2, 1, true>(XS4, HB, acc, NTP, mt0, lane);  // h <- h + ff.s (gcpnet.py:907)
-            vec_finish<NT_>(PG, w.bg, w.wup, w.H, GCDM_V, VH, e, part, [&](int c, float ox, float oy, float oz) {
+            vec_finish<NT_, 16>(PG, w.bg, w.wup, GCDM_V, VH, e, part, [&](int c, float ox, float oy, float oz) {
                 VV[((CB + c) * 3 + 0) * NTP + e] += ox;
                 VV[((CB + c) * 3 + 1) * NTP + e] += oy;
                 VV[((CB + c) * 3 + 2) * NTP + e] += oz;
@@ -746,7 +850,7 @@ __global__ __launch_bounds__(256) void k_node(NodeArgs a) {
         {
             const GcpW& w = a.pos;
             const int gN = 2 * GCDM_SG, gQ = gN + (w.H + 3) / 4;
-            gcp2_pre<NT_>(w.wdd, w.H, GCDM_V, VV, CB, FR, XSf, gN, gQ, HB + 2 * w.G, VH, e, part);
+            gcp2_pre<NT_, 8, GCDM_V>(w.wdd, VV, CB, FR, XSf, gN, gQ, HB + 2 * w.G, VH, e, part);
             __syncthreads();
             acc_init_bias<2, 1>(acc, w.b, mt0, lane);
             tile_gemm<2, 1>(acc, w.w + (size_t)mt0 * w.G * 64, w.G, XS4 + HB * NTP, NTP, lane);
@@ -755,7 +859,7 @@ __global__ __launch_bounds__(256) void k_node(NodeArgs a) {
             gate_partial<2, 1>(gacc, acc, w.wg, mt0, lane);
             store_gate_partial<1>(PG, gacc, NTP, wave, lane);
             __syncthreads();
-            vec_finish<NT_>(PG, w.bg, w.wup, w.H, 1, VH, e, part, [&](int c, float ox, float oy, float oz) {
+            vec_finish<NT_, 8>(PG, w.bg, w.wup, 1, VH, e, part, [&](int c, float ox, float oy, float oz) {
                 XP[0 * NTP + e] += ox * a.pos_weight;
                 XP[1 * NTP + e] += oy * a.pos_weight;
                 XP[2 * NTP + e] += oz * a.pos_weight;
@@ -808,7 +912,7 @@ __global__ __launch_bounds__(256) void k_node(NodeArgs a) {
         // ---- scalar projection GCP2 (S, V) -> (F+1+C, 0), bottleneck 1, no activation (gcpnet.py:1191-1197)
         const GcpW& w = a.proj;
         const int gN = 2 * GCDM_SG, gQ = gN + (w.H + 3) / 4;
-        gcp2_pre<NT_>(w.wdd, w.H, GCDM_V, VV, CB, FR, XSf, gN, gQ, HB + 2 * w.G, VH, e, part);
+        gcp2_pre<NT_, 32, GCDM_V>(w.wdd, VV, CB, FR, XSf, gN, gQ, HB + 2 * w.G, VH, e, part);
         __syncthreads();
         if (wave == 0) {
             f32x16 qacc[1][1];

@@ -103,6 +103,12 @@ int64_t gcdm_debug_read(gcdm_handle* h, const char* name, float* host_out, int64
 /* Stops the next forward after `num_layers_to_run` interaction layers (-1 = all; test hook). */
 int gcdm_debug_set_layer_limit(gcdm_handle* h, int32_t num_layers_to_run);
 
+/* Measurement hook: when enabled, every forward brackets each launch of the dominant kernel (the fused edge-message
+ * kernel, one launch per interaction layer) with HIP events on `stream`; gcdm_profile_edge_kernel_ms() synchronises on
+ * them and returns the summed duration and the launch count of the LAST forward. */
+int gcdm_profile_enable(gcdm_handle* h, int32_t enable);
+int gcdm_profile_edge_kernel_ms(gcdm_handle* h, double* total_ms, int32_t* launches);
+
 /* Sizes of the current plan. */
 int64_t gcdm_num_nodes(const gcdm_handle* h);
 int64_t gcdm_num_edges(const gcdm_handle* h);

@@ -1,0 +1,247 @@
+"""Parity of the HIP path (through the C ABI) with the CPU oracle and the reference's golden vectors.  MI355X only.
+
+Tolerance (BASELINE.json north_star): 1e-4 on output coordinates / features.  Where a synthetic net drives
+activations far above O(1) the same bar is applied relative to the output scale (the reference's own
+fp32-vs-fp64 gap scales the same way).
+"""
+import ctypes as C
+import importlib
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import synth
+from oracle import gcdm_oracle as O
+
+pytestmark = pytest.mark.gpu
+pkg = importlib.import_module("bio-diffusion_amd")
+TOL = 1e-4
+
+
+def _dims(case):
+    return synth.DATASET_DIMS[case]
+
+
+def _ocfg(case):
+    d = _dims(case)
+    return O.OracleConfig(num_atom_types=d["num_atom_types"], include_charges=d["include_charges"], num_context=d["n_ctx"],
+                          num_layers=d["L"], norm_values=d["norm_values"])
+
+
+def _net(case, seed=17, scale=1.0):
+    d = _dims(case)
+    ds = "geom" if case == "geom" else "qm9"
+    cond = ("alpha",) if d["n_ctx"] else ()
+    cfgs = pkg.default_cfgs(ds, cond)
+    net = pkg.GCPNetDynamics(**cfgs)
+    W = synth.make_weights(synth.dynamics_shapes(d["S"], d["V"], d["Se"], d["Ve"], d["L"], synth.dims_h_in(d)), seed=seed, scale_2d=scale)
+    net.load_state_dict(W)
+    return net.cuda(), W, cfgs
+
+
+def _fwd(net, xh, t, bi, ctx=None):
+    dev = torch.device("cuda")
+    batch = dict(batch=bi.to(dev), mask=torch.ones(len(bi), dtype=torch.bool, device=dev), props_context=None if ctx is None else ctx.to(dev))
+    _, out = net(batch, xh.to(dev), t.to(dev))
+    torch.cuda.synchronize()
+    return out.cpu()
+
+
+def test_native_library_is_loaded():
+    net, _, _ = _net("geom")
+    net._ensure_handle(torch.device("cuda"))
+    maps = open("/proc/self/maps").read()
+    assert "libgcdm_hip.so" in maps
+
+
+@pytest.mark.parametrize("case", ["qm9", "qm9cond", "geom"])
+def test_forward_matches_reference_golden(case, golden_dir):
+    """Full-width production architecture vs the outputs of the REFERENCE itself (tests/golden/dyn_full_*.npz)."""
+    g = np.load(os.path.join(golden_dir, f"dyn_full_{case}.npz"))
+    net, W, _ = _net(case, seed=int(g["weight_seed"]))
+    nn_ = torch.tensor(g["num_nodes"])
+    bi = O.num_nodes_to_batch_index(nn_)
+    ctx = torch.tensor(g["ctx"]) if "ctx" in g.files else None
+    out = _fwd(net, torch.tensor(g["xh"]), torch.tensor(g["t"]), bi, ctx)
+    assert (out - torch.tensor(g["out32"])).abs().max().item() <= TOL
+    assert (out - torch.tensor(g["out64"])).abs().max().item() <= TOL
+    # internal state after the last layer (layouts: DESIGN.md section 2)
+    N = len(bi)
+    h = net.debug_read("h").view(64, N, 4).permute(1, 0, 2).reshape(N, 256)
+    chi = net.debug_read("chi").view(32, 3, N).permute(2, 0, 1)
+    assert (h - torch.tensor(g["h_last"])).abs().max().item() <= TOL
+    assert (chi - torch.tensor(g["chi_last"])).abs().max().item() <= TOL
+    assert net.read_flags() == 0
+
+
+@pytest.mark.parametrize("case,num_nodes", [
+    ("qm9", [1]), ("qm9", [2, 1, 1, 3]), ("qm9", [29] * 7 + [3]), ("qm9", [64, 65, 63, 1, 130]),
+    ("geom", [44] * 5), ("geom", [181, 3, 90]), ("qm9cond", [19] * 9),
+])
+def test_forward_matches_oracle_ragged(case, num_nodes):
+    """Edge cases of the tiling: single atoms, rows shorter / equal / longer than the 64-edge tile, rows spanning 3+ tiles
+    (atomic accumulation), last tile partially filled, molecule sizes at the dataset maxima (29 / 181)."""
+    d = _dims(case)
+    net, W, _ = _net(case, seed=23, scale=0.5)
+    xh, t, bi, nn_, ctx = synth.make_inputs(num_nodes, synth.dims_feat(d), seed=31, t_value=0.63, n_ctx=d["n_ctx"])
+    ref = O.dynamics_forward(W, _ocfg(case), xh, t, bi, None, ctx)
+    out = _fwd(net, xh, t, bi, ctx)
+    scale = max(1.0, ref.abs().max().item())
+    assert torch.isfinite(out).all()
+    assert (out - ref).abs().max().item() <= TOL * scale
+
+
+def test_forward_input_validation():
+    net, _, _ = _net("qm9")
+    d = _dims("qm9")
+    xh, t, bi, nn_, _ = synth.make_inputs([4, 5], synth.dims_feat(d))
+    dev = torch.device("cuda")
+    mask = torch.ones(len(bi), dtype=torch.bool, device=dev)
+    with pytest.raises(ValueError):
+        net(dict(batch=bi.to(dev), mask=mask), xh[:, :-1].to(dev), t.to(dev))
+    mask2 = mask.clone(); mask2[0] = False
+    bi2 = bi.clone().to(dev)
+    with pytest.raises(NotImplementedError):
+        net(dict(batch=bi2, mask=mask2), xh.to(dev), t.to(dev))
+    with pytest.raises(NotImplementedError):
+        net(dict(batch=bi.to(dev), mask=mask), xh.to(dev), t.to(dev), xh_self_cond=xh.to(dev))
+
+
+def _raw_noise(seed, N, F):
+    """One draw in the reference's randn order: x-part [N,3] then h-part [N,F] (variational_diffusion.py:804-817)."""
+    tape = O.TapeNoise(seed)
+    return torch.cat((tape(N, 3), tape(N, F)), dim=-1)
+
+
+@pytest.mark.parametrize("case", ["qm9", "geom", "qm9cond"])
+def test_teacher_forced_sampler_steps(case):
+    """One ancestral step z_t -> z_s from the same z_t and the same noise: fused C-ABI step, the reference-signature
+    Python method, and the oracle agree (contract (ii))."""
+    d = _dims(case)
+    net, W, cfgs = _net(case, seed=41, scale=0.25)
+    ocfg = _ocfg(case)
+    ds = "geom" if case == "geom" else "qm9"
+    ddpm = pkg.EquivariantVariationalDiffusion(net, cfgs["diffusion_cfg"], cfgs["dataloader_cfg"], pkg.dataset_info(ds)).cuda()
+    dev = torch.device("cuda")
+    dyn, lib, h = ddpm._native(dev)
+    nn_ = torch.tensor([6, 19, 9, 3])
+    B = len(nn_)
+    bi = O.num_nodes_to_batch_index(nn_)
+    N, F = len(bi), ocfg.num_node_scalar_features
+    mask = torch.ones(N, dtype=torch.bool)
+    gam = O.gamma_table(ocfg)
+    g = torch.Generator().manual_seed(3)
+    ctx_b = torch.randn((B, 1), generator=g) if d["n_ctx"] else None
+    ctx = None if ctx_b is None else ctx_b[bi]
+    dyn.plan(nn_)
+    for s in (999, 500, 1, 0):
+        gz = torch.Generator().manual_seed(100 + s)
+        z = torch.randn((N, 3 + F), generator=gz) * (1.0 if s > 100 else 0.3)
+        z[:, :3] = O.centralize(z[:, :3], bi, B, mask)
+        want, eps = O.sample_p_zs_given_zt(W, ocfg, gam, s / 1000, (s + 1) / 1000, z, bi, B, mask, ctx, O.TapeNoise(300 + s))
+        raw = _raw_noise(300 + s, N, F).to(dev)
+        # (a) fused step through the C ABI
+        zc = z.to(dev).contiguous()
+        cdev = None if ctx is None else ctx.to(dev).contiguous()
+        st = lib.gcdm_sample_step(h, C.c_void_p(zc.data_ptr()), None if cdev is None else C.c_void_p(cdev.data_ptr()), s, 1000,
+                                  C.c_void_p(raw.data_ptr()), C.c_uint64(0), None, C.c_void_p(torch.cuda.current_stream().cuda_stream))
+        assert st == 0, lib.gcdm_last_error(h)
+        torch.cuda.synchronize()
+        scale = max(1.0, want.abs().max().item())
+        assert (zc.cpu() - want).abs().max().item() <= TOL * scale, f"fused step s={s}"
+        # (b) reference-signature method (torch algebra + HIP forward)
+        zs = ddpm.sample_p_zs_given_zt(s=torch.full((B, 1), s / 1000, device=dev), t=torch.full((B, 1), (s + 1) / 1000, device=dev),
+                                       z=z.to(dev), batch_index=bi.to(dev), node_mask=mask.to(dev), context=cdev, noise=raw)
+        assert (zs.cpu() - want).abs().max().item() <= TOL * scale, f"python step s={s}"
+        # x stays CoM-free
+        for b in range(B):
+            assert zc.cpu()[bi == b, :3].sum(0).abs().max().item() < 1e-4 * scale
+
+
+@pytest.mark.parametrize("case", ["qm9", "geom"])
+def test_free_running_sampling_short(case):
+    """mol_gen_sample (init + T' steps + final decode) on the same noise tape as the oracle: continuous outputs within the
+    relative bar, discrete outputs (one-hot atom types, rounded charges) identical (contract (iii)/(iv))."""
+    d = _dims(case)
+    net, W, cfgs = _net(case, seed=43, scale=0.25)
+    ocfg = _ocfg(case)
+    ds = "geom" if case == "geom" else "qm9"
+    ddpm = pkg.EquivariantVariationalDiffusion(net, cfgs["diffusion_cfg"], cfgs["dataloader_cfg"], pkg.dataset_info(ds)).cuda()
+    nn_ = torch.tensor([7, 19, 4, 12])
+    N, F = int(nn_.sum()), ocfg.num_node_scalar_features
+    Tp = 10
+    want, bi = O.mol_gen_sample(W, ocfg, nn_, O.TapeNoise(1234), num_timesteps=Tp)
+    tape = O.TapeNoise(1234)
+    draws = [torch.cat((tape(N, 3), tape(N, F)), dim=-1) for _ in range(Tp + 2)]
+    out, bi2, _ = ddpm.mol_gen_sample(num_samples=len(nn_), num_nodes=nn_, device="cuda", num_timesteps=Tp, noise_fn=lambda k: draws[k])
+    out = out.cpu()
+    assert torch.equal(bi2.cpu(), bi)
+    scale = max(1.0, want[:, :3].abs().max().item())
+    assert (out[:, :3] - want[:, :3]).abs().max().item() <= TOL * scale
+    assert torch.equal(out[:, 3:], want[:, 3:])
+    assert (ddpm.last_flags & 1) == 0
+
+
+def test_philox_noise_statistics_and_determinism():
+    net, W, cfgs = _net("qm9", seed=45, scale=0.25)
+    ddpm = pkg.EquivariantVariationalDiffusion(net, cfgs["diffusion_cfg"], cfgs["dataloader_cfg"], pkg.dataset_info("qm9")).cuda()
+    dev = torch.device("cuda")
+    dyn, lib, h = ddpm._native(dev)
+    nn_ = torch.full((512,), 19)
+    dyn.plan(nn_)
+    N = int(nn_.sum())
+    stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    z1 = torch.empty((N, 9), device=dev); z2 = torch.empty((N, 9), device=dev); z3 = torch.empty((N, 9), device=dev)
+    for z, seed in ((z1, 7), (z2, 7), (z3, 8)):
+        assert lib.gcdm_sample_init(h, C.c_void_p(z.data_ptr()), None, C.c_uint64(seed), stream) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(z1, z2) and not torch.equal(z1, z3)
+    hpart = z1[:, 3:]
+    assert abs(hpart.mean().item()) < 0.02 and abs(hpart.std().item() - 1.0) < 0.02
+    assert abs(torch.mean(hpart ** 4).item() - 3.0) < 0.15              # normal kurtosis
+    xs = z1[:, :3].view(512, 19, 3).sum(1)
+    assert xs.abs().max().item() < 1e-5                                  # CoM-free x-noise
+    assert abs(z1[:, :3].std().item() - math.sqrt(18 / 19)) < 0.02
+
+
+# ---- BASELINE.json full sizes: size-independent properties ------------------------------------------------------
+def _rot(seed=0):
+    g = torch.Generator().manual_seed(seed)
+    q, r = torch.linalg.qr(torch.randn(3, 3, generator=g, dtype=torch.float64))
+    q = q * torch.sign(torch.diagonal(r))
+    if torch.det(q) < 0:
+        q[:, 0] = -q[:, 0]
+    return q.float()
+
+
+@pytest.mark.parametrize("case,B,n", [("qm9", 1024, 19), ("geom", 256, 44)])
+def test_full_size_properties(case, B, n):
+    """At the benchmark configurations (C2 / C4): (1) run-to-run determinism, (2) per-molecule zero CoM of vel,
+    (3) SE(3) equivariance (rotation + translation; reflections are not a symmetry of the frames),
+    (4) batch-composition independence: a molecule's output in the 1024-batch equals its output in the 3-molecule flat
+    batch of itself and its two neighbours (which fixes the flat-batch orientation context) -- exercises tile boundaries,
+    and (5) agreement with the CPU oracle on a 3-molecule slice."""
+    d = _dims(case)
+    net, W, _ = _net(case, seed=51, scale=0.5)
+    xh, t, bi, nn_, _ = synth.make_inputs([n] * B, synth.dims_feat(d), seed=77, t_value=0.41)
+    out = _fwd(net, xh, t, bi)
+    out2 = _fwd(net, xh, t, bi)
+    assert torch.isfinite(out).all()
+    assert torch.equal(out, out2)                                        # (1)  n <= 64: rows split over at most 2 tiles
+    scale = max(1.0, out.abs().max().item())
+    assert out[:, :3].view(B, n, 3).sum(1).abs().max().item() <= 1e-4 * scale   # (2)
+    R = _rot(5)
+    xr = xh.clone()
+    xr[:, :3] = xh[:, :3] @ R.T + torch.tensor([0.3, -1.1, 2.0])
+    outr = _fwd(net, xr, t, bi)
+    assert (outr[:, :3] - out[:, :3] @ R.T).abs().max().item() <= TOL * scale      # (3)
+    assert (outr[:, 3:] - out[:, 3:]).abs().max().item() <= TOL * scale
+    for b in (1, B // 2, B - 2):                                                  # (4) + (5)
+        lo, hi = (b - 1) * n, (b + 2) * n
+        sub = _fwd(net, xh[lo:hi], t[lo:hi], bi[lo:hi] - (b - 1))
+        assert (sub[n:2 * n] - out[b * n:(b + 1) * n]).abs().max().item() <= TOL * scale
+        ref = O.dynamics_forward(W, _ocfg(case), xh[lo:hi], t[lo:hi], bi[lo:hi] - (b - 1))
+        assert (sub - ref).abs().max().item() <= TOL * scale
