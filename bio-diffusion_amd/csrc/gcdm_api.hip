@@ -5,6 +5,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
@@ -52,6 +53,7 @@ struct gcdm_handle {
           *VDI = nullptr, *VDJ = nullptr, *AGG = nullptr, *VEL = nullptr, *EPS = nullptr, *TBUF = nullptr, *EP4 = nullptr, *AL = nullptr, *U = nullptr, *FR = nullptr, *PROF = nullptr;
     uint32_t* d_flags = nullptr;
     int layer_limit = -1;
+    int edge_tile = 64;              // 64: one 8-wave workgroup per CU; 32: two 4-wave workgroups per CU (env GCDM_EDGE_TILE)
     bool attr_set = false;
     // profiling (HIP events around the k_edge_msg launches of one forward)
     bool profile = false;
@@ -252,6 +254,7 @@ int gcdm_create(const GcdmConfig* cfg, gcdm_handle** out) {
     h->Ve = cfg->xi_hidden_dim;
     h->L = cfg->num_layers;
     h->H0 = (2 * GCDM_V + h->Ve) / 4;
+    if (const char* et = getenv("GCDM_EDGE_TILE")) h->edge_tile = (atoi(et) == 32) ? 32 : 64;
     HIP_OK(h, hipSetDevice(cfg->device));
     HIP_OK(h, hipMalloc(&h->d_flags, sizeof(uint32_t)));
     HIP_OK(h, hipMemset(h->d_flags, 0, sizeof(uint32_t)));
@@ -393,7 +396,8 @@ int gcdm_finalize_weights(gcdm_handle* h) {
         d.wpq = (const v4f*)(base + o.wpq); d.bpq = base + o.bpq; d.wddI = base + o.wddI; d.wddJ = base + o.wddJ;
     }
     if (!h->attr_set) {
-        if (set_lds_attr(h, k_edge_msg<64, 16>, EK_LDS_BYTES) || set_lds_attr(h, k_edge_msg<16, 8>, EK_LDS_BYTES) ||
+        if (set_lds_attr(h, k_edge_msg<64, 16, 64>, EdgeGeo<64>::LDS_BYTES) || set_lds_attr(h, k_edge_msg<16, 8, 64>, EdgeGeo<64>::LDS_BYTES) ||
+            set_lds_attr(h, k_edge_msg<64, 16, 32>, EdgeGeo<32>::LDS_BYTES) || set_lds_attr(h, k_edge_msg<16, 8, 32>, EdgeGeo<32>::LDS_BYTES) ||
             set_lds_attr(h, k_node<true>, NK_LDS_BYTES) || set_lds_attr(h, k_node<false>, NK_LDS_BYTES))
             return -1;
         h->attr_set = true;
@@ -443,7 +447,7 @@ int gcdm_plan_batch(gcdm_handle* h, int32_t B, const int32_t* nn) {
     const size_t oX0 = take(3 * n), oXC = take(3 * n), oFB = take(9 * n), oC0 = take(6 * n), oHIN = take(4 * h->FinG * n), oH4 = take(GCDM_S * n),
                  oCHI = take(96 * n), oPQ = take(512 * n), oVDI = take((size_t)(h->H0 + 3) * 3 * n), oVDJ = take((size_t)(h->H0 + 3) * 3 * n),
                  oAGG = take(GCDM_AGGW * n), oVEL = take(3 * n), oEPS = take((size_t)h->D * n), oT = take(n), oEP = take((size_t)h->Se * e),
-                 oAL = take((size_t)h->Ve * e), oU = take(3 * e), oFR = take(9 * e), oPROF = take(((e + ET - 1) / ET) * 192);
+                 oAL = take((size_t)h->Ve * e), oU = take(3 * e), oFR = take(9 * e), oPROF = take(((e + 31) / 32) * 192);
     h->ws_floats = off;
     HIP_OK(h, hipMalloc(&h->ws, off * sizeof(float)));
     HIP_OK(h, hipMemset(h->ws, 0, off * sizeof(float)));
@@ -501,6 +505,7 @@ int gcdm_forward(gcdm_handle* h, const float* xh, const float* t, const float* c
     const int ngrid = (N + NT_ - 1) / NT_;
     set_next(0);
     hipLaunchKernelGGL(k_node<true>, dim3(ngrid), dim3(256), NK_LDS_BYTES, st, na);
+    const int ET = h->edge_tile;
     const int tiles = (E + ET - 1) / ET;
     for (int l = 0; l < L; ++l) {
         const LayerDev& d = h->layers[l];
@@ -513,8 +518,13 @@ int gcdm_forward(gcdm_handle* h, const float* xh, const float* t, const float* c
         ma.wa = d.wa; ma.ba = d.ba;
         ma.prof = h->profile_phases ? h->PROF : nullptr;
         if (h->profile) HIP_OK(h, hipEventRecord(h->ev[2 * l], st));
-        if (h->Se == 64) hipLaunchKernelGGL((k_edge_msg<64, 16>), dim3(tiles), dim3(EK_THREADS), EK_LDS_BYTES, st, ma);
-        else hipLaunchKernelGGL((k_edge_msg<16, 8>), dim3(tiles), dim3(EK_THREADS), EK_LDS_BYTES, st, ma);
+        if (ET == 64) {
+            if (h->Se == 64) hipLaunchKernelGGL((k_edge_msg<64, 16, 64>), dim3(tiles), dim3(EdgeGeo<64>::THREADS), EdgeGeo<64>::LDS_BYTES, st, ma);
+            else hipLaunchKernelGGL((k_edge_msg<16, 8, 64>), dim3(tiles), dim3(EdgeGeo<64>::THREADS), EdgeGeo<64>::LDS_BYTES, st, ma);
+        } else {
+            if (h->Se == 64) hipLaunchKernelGGL((k_edge_msg<64, 16, 32>), dim3(tiles), dim3(EdgeGeo<32>::THREADS), EdgeGeo<32>::LDS_BYTES, st, ma);
+            else hipLaunchKernelGGL((k_edge_msg<16, 8, 32>), dim3(tiles), dim3(EdgeGeo<32>::THREADS), EdgeGeo<32>::LDS_BYTES, st, ma);
+        }
         if (h->profile) { HIP_OK(h, hipEventRecord(h->ev[2 * l + 1], st)); h->ev_used = l + 1; }
         na.ff = d.ff; na.pos = d.pos;
         set_next(l + 1);   // next layer's msg0 halves, or the output projection after the last layer
@@ -656,7 +666,7 @@ int64_t gcdm_debug_read(gcdm_handle* h, const char* name, float* host_out, int64
     else if (k == "fbar") { p = h->FBAR; cnt = 9 * n; }
     else if (k == "chi0") { p = h->CHI0; cnt = 6 * n; }
     else if (k == "vel") { p = h->VEL; cnt = 3 * n; }
-    else if (k == "phase") { p = h->PROF; cnt = ((e + ET - 1) / ET) * 192; }
+    else if (k == "phase") { p = h->PROF; cnt = ((e + h->edge_tile - 1) / h->edge_tile) * 192; }
     else return fail(h, "gcdm_debug_read: unknown buffer " + k);
     if (!host_out) return cnt;
     if (capacity < cnt) return fail(h, "gcdm_debug_read: capacity too small");

@@ -470,38 +470,48 @@ struct EdgeMsgArgs {
         if (a.prof && lane == 0) a.prof[((size_t)blockIdx.x * 8 + wave) * 24 + (i)] = (float)(__builtin_amdgcn_s_memtime() - t_start); \
     } while (0)
 
-constexpr int ET = 64, ETP = 65, EK_THREADS = 512;
-constexpr int EK_XS_GROUPS = 72;
-constexpr int EK_OFF_XS = 0;
-constexpr int EK_OFF_VV = EK_OFF_XS + EK_XS_GROUPS * ETP * 16;
-constexpr int EK_OFF_VH = EK_OFF_VV + 96 * ETP * 4;
-constexpr int EK_OFF_PG = EK_OFF_VH + 60 * ETP * 4;
-constexpr int EK_OFF_FR = EK_OFF_PG + 4 * 32 * ETP * 4;
-constexpr int EK_OFF_META = EK_OFF_FR + 9 * ETP * 4;
-constexpr int EK_LDS_BYTES = EK_OFF_META + (64 + 64 + 66 + 64 + 4) * 4;
+// Tile geometry.  T = 64: one 8-wave workgroup per CU (152 KB LDS).  T = 32: 4-wave workgroups of 77 KB, two per CU,
+// which run out of phase so that one's VALU phases overlap the other's MFMA phases (weights are then streamed twice).
+template <int T>
+struct EdgeGeo {
+    static constexpr int TP = T + 1;
+    static constexpr int THREADS = (T == 64) ? 512 : 256;
+    static constexpr int PARTS = THREADS / T;      // threads sharing one entity in the VALU phases (8)
+    static constexpr int XS_GROUPS = 72;
+    static constexpr int OFF_XS = 0;
+    static constexpr int OFF_VV = OFF_XS + XS_GROUPS * TP * 16;
+    static constexpr int OFF_VH = OFF_VV + 96 * TP * 4;
+    static constexpr int OFF_PG = OFF_VH + 60 * TP * 4;
+    static constexpr int OFF_FR = OFF_PG + 4 * 32 * TP * 4;
+    static constexpr int OFF_META = OFF_FR + 9 * TP * 4;
+    static constexpr int LDS_BYTES = OFF_META + (T + T + (T + 2) + T + 4) * 4;
+};
 
-template <int SE, int VE>
-__global__ __launch_bounds__(EK_THREADS) void k_edge_msg(EdgeMsgArgs a) {
+template <int SE, int VE, int ET>
+__global__ __launch_bounds__(EdgeGeo<ET>::THREADS) void k_edge_msg(EdgeMsgArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    v4f* XS4 = (v4f*)(smem + EK_OFF_XS);
+    using Geo = EdgeGeo<ET>;
+    constexpr int ETP = Geo::TP, EK_THREADS = Geo::THREADS, PARTS = Geo::PARTS;
+    v4f* XS4 = (v4f*)(smem + Geo::OFF_XS);
     float* XSf = (float*)XS4;
-    float* VV = (float*)(smem + EK_OFF_VV);
-    float* VH = (float*)(smem + EK_OFF_VH);
-    float* PG = (float*)(smem + EK_OFF_PG);
-    float* FR = (float*)(smem + EK_OFF_FR);
-    int* m_row = (int*)(smem + EK_OFF_META);
-    int* m_col = m_row + 64;
-    int* m_seg = m_col + 64;   // [66] segment starts (+ end sentinel)
-    float* m_att = (float*)(m_seg + 66);
-    int* m_misc = (int*)(m_att + 64);  // [0] = nseg
+    float* VV = (float*)(smem + Geo::OFF_VV);
+    float* VH = (float*)(smem + Geo::OFF_VH);
+    float* PG = (float*)(smem + Geo::OFF_PG);
+    float* FR = (float*)(smem + Geo::OFF_FR);
+    int* m_row = (int*)(smem + Geo::OFF_META);
+    int* m_col = m_row + ET;
+    int* m_seg = m_col + ET;   // [ET+2] segment starts (+ end sentinel)
+    float* m_att = (float*)(m_seg + ET + 2);
+    int* m_misc = (int*)(m_att + ET);  // [0] = nseg
 
     constexpr int H0 = (2 * GCDM_V + VE) / 4;       // bottleneck 4
     constexpr int H0G = (H0 + 3) / 4;
     constexpr int SEG = SE / 4;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int e = lane, part = wave;  // T = 64: entity = lane, the 8 waves are the 8 "parts" of the VALU phases
-    constexpr int PARTS = EK_THREADS / ET;
+    // VALU phases: entity e, and which of the PARTS co-operating threads this is (T = 64: entity = lane, part = wave)
+    const int e = (ET == 64) ? lane : (tid & (ET - 1));
+    const int part = (ET == 64) ? wave : (tid / ET);
     const int E = a.E, N = a.N;
     const int e0 = blockIdx.x * ET;
     const int nvalid = min(ET, E - e0);
@@ -511,14 +521,14 @@ __global__ __launch_bounds__(EK_THREADS) void k_edge_msg(EdgeMsgArgs a) {
 
     // ---- P0: tile metadata + row segments (wave 0) -------------------------------------------
     if (wave == 0) {
-        m_row[e] = ni;
-        m_col[e] = nj;
+        const bool own = lane < ET;    // T = 32: lanes 32..63 of wave 0 are part 1 of the same entities
+        if (own) { m_row[e] = ni; m_col[e] = nj; }
         const int prev = __shfl_up(ni, 1);
-        const bool start = (e < nvalid) && (e == 0 || prev != ni);
+        const bool start = own && (e < nvalid) && (e == 0 || prev != ni);
         const unsigned long long mask = __ballot(start);
-        const int sid = __popcll(mask & ((2ull << e) - 1ull)) - 1;
+        const int sid = __popcll(mask & ((2ull << lane) - 1ull)) - 1;
         if (start) m_seg[sid] = e;
-        if (e == 0) {
+        if (lane == 0) {
             const int ns = __popcll(mask);
             m_seg[ns] = nvalid;
             m_misc[0] = ns;
@@ -529,7 +539,7 @@ __global__ __launch_bounds__(EK_THREADS) void k_edge_msg(EdgeMsgArgs a) {
         float fr[9];
 #pragma unroll
         for (int r = 0; r < 9; ++r) fr[r] = a.FR[(size_t)r * E + eid];
-        if (wave == 0) {
+        if (part == 0) {
 #pragma unroll
             for (int r = 0; r < 9; ++r) FR[r * ETP + e] = fr[r];
         }
@@ -674,7 +684,7 @@ __global__ __launch_bounds__(EK_THREADS) void k_edge_msg(EdgeMsgArgs a) {
         }
         PG[part * ETP + e] = s;
         __syncthreads();
-        if (wave == 0) {
+        if (part == 0) {
             float s2 = a.ba;
 #pragma unroll
             for (int q = 0; q < PARTS; ++q) s2 += PG[q * ETP + e];
