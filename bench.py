@@ -34,6 +34,7 @@ for p in (ROOT, os.path.join(ROOT, "tests")):
         sys.path.insert(0, p)
 
 PEAK_FP32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md, dense fp32 matrix peak
+PEAK_F16_MFMA_TFLOPS = 2500.0   # same guide, dense f16/bf16 matrix peak (the 5 PF marketing figure is 2:1 sparse)
 NET_EVALS_PER_SAMPLE = 1001     # 1000 denoise steps + the t=0 decode
 
 WORKLOADS = {
@@ -84,6 +85,23 @@ def cpu_baseline(dataset, cond, dims, seconds_budget=20.0):
     return {"value": Bc / (dt * NET_EVALS_PER_SAMPLE), "unit": "molecules/s", "cores": torch.get_num_threads(), "kind": "port",
             "ms_per_step": dt * 1e3,
             "sample": f"CPU oracle (torch fp32), {Bc} molecules x {n} atoms, {steps} denoise steps timed, extrapolated x{NET_EVALS_PER_SAMPLE}"}
+
+
+def load_pmc_summary(workload, x3):
+    """HBM traffic / MFMA-busy of the dominant kernel from the committed rocprofv3 --pmc passes (profiles/*_pmc_summary_*.json;
+    collected separately as MI355X_MICROARCH.md prescribes -- not live)."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_pmc_summary_{workload}_{'x3' if x3 else 'f32'}.json")))
+    if not files:
+        return {}
+    with open(files[-1]) as f:
+        d = json.load(f)
+    for k, v in d.items():
+        if k.startswith("k_edge_msg"):
+            out = dict(v)
+            out["source"] = os.path.relpath(files[-1], ROOT)
+            return out
+    return {}
 
 
 def log(msg):
@@ -214,6 +232,10 @@ def main():
         alg_total, alg_edge_layer = algorithmic_flops(N, E, dims)
         exe_total = float(lib.gcdm_forward_flops_executed(h))
         achieved = alg_edge_layer / (edge_ms * 1e-3) / 1e12
+        x3 = int(lib.gcdm_get_option(h, b"mfma_mode")) == 1
+        # split-precision mode issues three f16 MFMAs per fp32 multiply-add block: the fp32-equivalent roof is the f16 peak / 3
+        peak = PEAK_F16_MFMA_TFLOPS / 3.0 if x3 else PEAK_FP32_MFMA_TFLOPS
+        pmc = load_pmc_summary(args.workload, x3)
         res = {
             "metric": "molecules/sec (1000-step DDPM sample)", "value": world * B / (ms_per_step * 1e-3 * NET_EVALS_PER_SAMPLE),
             "unit": "molecules/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
@@ -224,9 +246,12 @@ def main():
                        "final_gather_ms": gather_ms, "outputs_finite": finite, "flags": fl,
                        "step_tflops_algorithmic": alg_total / (ms_per_step * 1e-3) / 1e12,
                        "step_tflops_executed": exe_total / (ms_per_step * 1e-3) / 1e12},
-            "roofline": {"bound": "mfma", "kernel": "k_edge_msg", "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": None, "avg_launch_ms": edge_ms,
-                         "algorithmic_flop_per_launch": alg_edge_layer, "launches_per_step": d["L"]},
+            "roofline": {"bound": "mfma", "kernel": "k_edge_msg_x3" if x3 else "k_edge_msg", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
+                         "frac": achieved / peak, "traffic": pmc.get("hbm_bytes_per_launch"), "avg_launch_ms": edge_ms,
+                         "algorithmic_flop_per_launch": alg_edge_layer, "launches_per_step": d["L"],
+                         "mfma": ("f16 x3 split (x = hi + 2^-11 lo', fp32 accumulate, fp32-equivalent accuracy); peak = 2500/3" if x3
+                                  else "fp32 32x32x2"),
+                         "mfma_busy_frac_pmc": pmc.get("mfma_busy_frac"), "pmc_source": pmc.get("source")},
         }
         if not args.no_cpu_baseline and world == 1:
             log("cpu baseline ...")

@@ -13,7 +13,7 @@ SOURCES = [os.path.join(_HERE, "csrc", "gcdm_api.hip")]
 HEADERS = [os.path.join(_HERE, "csrc", "gcdm_kernels.hip.h"), os.path.join(os.path.dirname(_HERE), "include", "gcdm_hip.h")]
 ABI_VERSION = 1
 
-FLAG_NAN_VEL, FLAG_MEAN_NOT_ZERO, FLAG_COG_DRIFT = 1, 2, 4
+FLAG_NAN_VEL, FLAG_MEAN_NOT_ZERO, FLAG_COG_DRIFT, FLAG_F16_RANGE = 1, 2, 4, 8
 
 
 class GcdmConfig(C.Structure):
@@ -31,7 +31,7 @@ EXPORTS = [
     "gcdm_create", "gcdm_destroy", "gcdm_last_error", "gcdm_set_weight", "gcdm_finalize_weights", "gcdm_set_gamma",
     "gcdm_plan_batch", "gcdm_forward", "gcdm_sample_step", "gcdm_sample_final", "gcdm_sample_init", "gcdm_debug_read",
     "gcdm_debug_set_layer_limit", "gcdm_num_nodes", "gcdm_num_edges", "gcdm_forward_flops_executed",
-    "gcdm_profile_enable", "gcdm_profile_edge_kernel_ms",
+    "gcdm_profile_enable", "gcdm_profile_edge_kernel_ms", "gcdm_set_option", "gcdm_get_option",
 ]
 
 _lib: Optional[C.CDLL] = None
@@ -77,6 +77,8 @@ def load() -> C.CDLL:
     lib.gcdm_num_nodes.restype = C.c_int64
     lib.gcdm_num_edges.argtypes = [H]
     lib.gcdm_num_edges.restype = C.c_int64
+    lib.gcdm_set_option.argtypes = [H, C.c_char_p, C.c_int32]
+    lib.gcdm_get_option.argtypes = [H, C.c_char_p]
     lib.gcdm_profile_enable.argtypes = [H, C.c_int32]
     lib.gcdm_profile_edge_kernel_ms.argtypes = [H, C.POINTER(C.c_double), C.POINTER(C.c_int32)]
     lib.gcdm_forward_flops_executed.argtypes = [H]

@@ -1,6 +1,7 @@
 // gcdm_api.hip -- host side of libgcdm_hip.so: C ABI (include/gcdm_hip.h), weight re-packing into the MFMA
 // fragment layout, batch plan, kernel launches.  gfx950 only; no torch types, no exceptions across the ABI.
 #include "gcdm_kernels.hip.h"
+#include "gcdm_edge_x3.hip.h"
 #include "../../include/gcdm_hip.h"
 
 #include <cmath>
@@ -26,6 +27,9 @@ struct LayerDev {
     // node kernel
     GcpW ff, pos;
     const v4f* wpq; const float* bpq; const float* wddI; const float* wddJ;
+    // split-precision (f16 x3) images of the edge-kernel GEMM weights
+    const h8 *w0H, *w0L, *wg0H, *wg0L, *wH[3], *wL[3], *wgH[3], *wgL[3];
+    int KB0, KB;
 };
 
 }  // namespace
@@ -54,6 +58,7 @@ struct gcdm_handle {
     uint32_t* d_flags = nullptr;
     int layer_limit = -1;
     int edge_tile = 64;              // 64: one 8-wave workgroup per CU; 32: two 4-wave workgroups per CU (env GCDM_EDGE_TILE)
+    int mfma_x3 = 1;                 // 1: split-precision f16 x3 edge kernel (default; env GCDM_MFMA=f16x3|f32), 0: fp32 MFMA
     bool attr_set = false;
     // profiling (HIP events around the k_edge_msg launches of one forward)
     bool profile = false;
@@ -103,6 +108,46 @@ std::vector<float> pack_mfma(Dense& W) {
                 for (int t = 0; t < 4; ++t)
                     out[(((size_t)mt * G + g) * 64 + lane) * 4 + t] = W.at(32 * mt + (lane & 31), 8 * g + 4 * (lane >> 5) + t);
     return out;
+}
+
+// split-precision images: x = hi + 2^-11 lo', both f16.  packed[mt][kb][lane][8] = W[32 mt + (lane & 31)][16 kb + 8 (lane >> 5) + s]
+void split_f16(float x, uint16_t& hi, uint16_t& lo) {
+    const _Float16 h = (_Float16)x;
+    const _Float16 l = (_Float16)((x - (float)h) * 2048.0f);
+    std::memcpy(&hi, &h, 2);
+    std::memcpy(&lo, &l, 2);
+}
+
+void pack_x3(Dense& W, std::vector<float>& outH, std::vector<float>& outL) {
+    const int MT = W.M / 32, KB = W.K / 16;
+    std::vector<uint16_t> H((size_t)W.M * W.K), L((size_t)W.M * W.K);
+    for (int mt = 0; mt < MT; ++mt)
+        for (int kb = 0; kb < KB; ++kb)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int s = 0; s < 8; ++s) {
+                    const size_t o = (((size_t)mt * KB + kb) * 64 + lane) * 8 + s;
+                    split_f16(W.at(32 * mt + (lane & 31), 16 * kb + 8 * (lane >> 5) + s), H[o], L[o]);
+                }
+    outH.assign(H.size() / 2, 0.f);
+    outL.assign(L.size() / 2, 0.f);
+    std::memcpy(outH.data(), H.data(), H.size() * 2);
+    std::memcpy(outL.data(), L.data(), L.size() * 2);
+}
+
+// gate weights for the in-register contraction: block (mt, j) slot s of lane l  <->  channel 32 mt + 16 j + 8 (s >> 2) + 4 (l >> 5) + (s & 3)
+void pack_gate_x3(Dense& Wg /*[32][256]*/, std::vector<float>& outH, std::vector<float>& outL) {
+    std::vector<uint16_t> H((size_t)8 * 2 * 64 * 8), L(H.size());
+    for (int mt = 0; mt < 8; ++mt)
+        for (int j = 0; j < 2; ++j)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int s = 0; s < 8; ++s) {
+                    const size_t o = (((size_t)mt * 2 + j) * 64 + lane) * 8 + s;
+                    split_f16(Wg.at(lane & 31, 32 * mt + 16 * j + 8 * (s >> 2) + 4 * (lane >> 5) + (s & 3)), H[o], L[o]);
+                }
+    outH.assign(H.size() / 2, 0.f);
+    outL.assign(L.size() / 2, 0.f);
+    std::memcpy(outH.data(), H.data(), H.size() * 2);
+    std::memcpy(outL.data(), L.data(), L.size() * 2);
 }
 
 struct WView {
@@ -208,6 +253,8 @@ struct LayerOff {
     int G0;
     float ba;
     GcpOff mk[3], ff, pos;
+    size_t w0H, w0L, wg0H, wg0L, wH[3], wL[3], wgH[3], wgL[3];
+    int KB0, KB;
 };
 
 void free_plan(gcdm_handle* h) {
@@ -255,6 +302,8 @@ int gcdm_create(const GcdmConfig* cfg, gcdm_handle** out) {
     h->L = cfg->num_layers;
     h->H0 = (2 * GCDM_V + h->Ve) / 4;
     if (const char* et = getenv("GCDM_EDGE_TILE")) h->edge_tile = (atoi(et) == 32) ? 32 : 64;
+    if (const char* mm = getenv("GCDM_MFMA")) h->mfma_x3 = (std::strcmp(mm, "f16x3") == 0) ? 1 : 0;
+    if (h->mfma_x3) h->edge_tile = 64;
     HIP_OK(h, hipSetDevice(cfg->device));
     HIP_OK(h, hipMalloc(&h->d_flags, sizeof(uint32_t)));
     HIP_OK(h, hipMemset(h->d_flags, 0, sizeof(uint32_t)));
@@ -361,9 +410,40 @@ int gcdm_finalize_weights(gcdm_handle* h) {
             o.wg0 = pool.add(pack_mfma(Wg));
             o.bg0 = pool.add(padded(bg, 32));
             o.wup0 = pool.add(*wu.v);
+            // split-precision images: K' = [e'(Se) | n (H0 -> 8-groups) | q (9 -> 16)] padded to a multiple of 16
+            const int N8 = Se / 8, H0G8 = (H0 + 7) / 8, Q8 = N8 + H0G8;
+            const int Kx = round_up(8 * (Q8 + 2), 16);
+            Dense W0x(S, Kx);
+            for (int m = 0; m < S; ++m) {
+                for (int k = 0; k < Se; ++k) W0x.at(m, k) = ws.at(m, S + k);
+                for (int k = 0; k < H0; ++k) W0x.at(m, 8 * N8 + k) = ws.at(m, 2 * S + Se + k);
+                for (int k = 0; k < 9; ++k) W0x.at(m, 8 * Q8 + k) = ws.at(m, 2 * S + Se + H0 + k);
+            }
+            std::vector<float> xh, xl;
+            pack_x3(W0x, xh, xl);
+            o.w0H = pool.add(xh); o.w0L = pool.add(xl); o.KB0 = Kx / 16;
+            pack_gate_x3(Wg, xh, xl);
+            o.wg0H = pool.add(xh); o.wg0L = pool.add(xl);
         }
-        for (int k = 1; k <= 3; ++k)
-            if (!build_gcp(h, pool, lp + "interaction.message_fusion." + std::to_string(k) + ".", S, V, S, V, 4, false, o.mk[k - 1])) return -1;
+        for (int k = 1; k <= 3; ++k) {
+            const std::string p = lp + "interaction.message_fusion." + std::to_string(k) + ".";
+            if (!build_gcp(h, pool, p, S, V, S, V, 4, false, o.mk[k - 1])) return -1;
+            // split-precision images: K' = [m.s (256) | n (8) | q (9 -> 16) | pad] = 288
+            WView ws, wg;
+            if (!get_w(h, p + "scalar_out.weight", S, S + 8 + 9, ws) || !get_w(h, p + "vector_out_scale.weight", V, S, wg)) return -1;
+            Dense Wx(S, 288);
+            for (int m = 0; m < S; ++m) {
+                for (int kk = 0; kk < S + 8; ++kk) Wx.at(m, kk) = ws.at(m, kk);
+                for (int kk = 0; kk < 9; ++kk) Wx.at(m, S + 8 + kk) = ws.at(m, S + 8 + kk);
+            }
+            std::vector<float> xh, xl;
+            pack_x3(Wx, xh, xl);
+            o.wH[k - 1] = pool.add(xh); o.wL[k - 1] = pool.add(xl); o.KB = 18;
+            Dense Wgd(32, S);
+            for (int m = 0; m < V; ++m) for (int kk = 0; kk < S; ++kk) Wgd.at(m, kk) = wg.at(m, kk);
+            pack_gate_x3(Wgd, xh, xl);
+            o.wgH[k - 1] = pool.add(xh); o.wgL[k - 1] = pool.add(xl);
+        }
         {
             WView wa, ba;
             if (!get_w(h, lp + "interaction.scalar_message_attention.0.weight", 1, S, wa) ||
@@ -394,10 +474,17 @@ int gcdm_finalize_weights(gcdm_handle* h) {
         d.wa = base + o.wa; d.ba = o.ba;
         d.ff = resolve(o.ff, base); d.pos = resolve(o.pos, base);
         d.wpq = (const v4f*)(base + o.wpq); d.bpq = base + o.bpq; d.wddI = base + o.wddI; d.wddJ = base + o.wddJ;
+        d.w0H = (const h8*)(base + o.w0H); d.w0L = (const h8*)(base + o.w0L); d.KB0 = o.KB0; d.KB = o.KB;
+        d.wg0H = (const h8*)(base + o.wg0H); d.wg0L = (const h8*)(base + o.wg0L);
+        for (int k = 0; k < 3; ++k) {
+            d.wH[k] = (const h8*)(base + o.wH[k]); d.wL[k] = (const h8*)(base + o.wL[k]);
+            d.wgH[k] = (const h8*)(base + o.wgH[k]); d.wgL[k] = (const h8*)(base + o.wgL[k]);
+        }
     }
     if (!h->attr_set) {
         if (set_lds_attr(h, k_edge_msg<64, 16, 64>, EdgeGeo<64>::LDS_BYTES) || set_lds_attr(h, k_edge_msg<16, 8, 64>, EdgeGeo<64>::LDS_BYTES) ||
             set_lds_attr(h, k_edge_msg<64, 16, 32>, EdgeGeo<32>::LDS_BYTES) || set_lds_attr(h, k_edge_msg<16, 8, 32>, EdgeGeo<32>::LDS_BYTES) ||
+            set_lds_attr(h, k_edge_msg_x3<64, 16>, EdgeGeo<64>::LDS_BYTES) || set_lds_attr(h, k_edge_msg_x3<16, 8>, EdgeGeo<64>::LDS_BYTES) ||
             set_lds_attr(h, k_node<true>, NK_LDS_BYTES) || set_lds_attr(h, k_node<false>, NK_LDS_BYTES))
             return -1;
         h->attr_set = true;
@@ -518,7 +605,16 @@ int gcdm_forward(gcdm_handle* h, const float* xh, const float* t, const float* c
         ma.wa = d.wa; ma.ba = d.ba;
         ma.prof = h->profile_phases ? h->PROF : nullptr;
         if (h->profile) HIP_OK(h, hipEventRecord(h->ev[2 * l], st));
-        if (ET == 64) {
+        if (h->mfma_x3) {
+            EdgeMsgX3Args xa{};
+            xa.base = ma;
+            xa.w0H = d.w0H; xa.w0L = d.w0L; xa.KB0 = d.KB0; xa.wg0H = d.wg0H; xa.wg0L = d.wg0L; xa.KB = d.KB;
+            for (int k = 0; k < 3; ++k) { xa.wH[k] = d.wH[k]; xa.wL[k] = d.wL[k]; xa.wgH[k] = d.wgH[k]; xa.wgL[k] = d.wgL[k]; }
+            xa.flags_dev = h->d_flags;
+            const int xtiles = (E + 63) / 64;
+            if (h->Se == 64) hipLaunchKernelGGL((k_edge_msg_x3<64, 16>), dim3(xtiles), dim3(512), EdgeGeo<64>::LDS_BYTES, st, xa);
+            else hipLaunchKernelGGL((k_edge_msg_x3<16, 8>), dim3(xtiles), dim3(512), EdgeGeo<64>::LDS_BYTES, st, xa);
+        } else if (ET == 64) {
             if (h->Se == 64) hipLaunchKernelGGL((k_edge_msg<64, 16, 64>), dim3(tiles), dim3(EdgeGeo<64>::THREADS), EdgeGeo<64>::LDS_BYTES, st, ma);
             else hipLaunchKernelGGL((k_edge_msg<16, 8, 64>), dim3(tiles), dim3(EdgeGeo<64>::THREADS), EdgeGeo<64>::LDS_BYTES, st, ma);
         } else {
@@ -615,6 +711,32 @@ int gcdm_sample_final(gcdm_handle* h, const float* z0, const float* context, con
     hipLaunchKernelGGL(k_cog_fix, dim3(h->B), dim3(64), 0, st, out, h->d_noff, h->D, h->d_flags, flags);
     HIP_OK(h, hipGetLastError());
     return 0;
+}
+
+int gcdm_set_option(gcdm_handle* h, const char* name, int32_t value) {
+    if (!h || !name) return fail(h, "gcdm_set_option: bad argument");
+    const std::string k(name);
+    if (k == "mfma_mode") {                 // 0: fp32 MFMA, 1: split-precision f16 x3 (fp32-equivalent, 5.3x the matrix rate)
+        if (value != 0 && value != 1) return fail(h, "gcdm_set_option(mfma_mode): 0 or 1");
+        h->mfma_x3 = value;
+        if (value) h->edge_tile = 64;
+        return 0;
+    }
+    if (k == "edge_tile") {
+        if (value != 32 && value != 64) return fail(h, "gcdm_set_option(edge_tile): 32 or 64");
+        if (h->mfma_x3 && value != 64) return fail(h, "gcdm_set_option(edge_tile): the split-precision kernel uses 64-edge tiles");
+        h->edge_tile = value;
+        return 0;
+    }
+    return fail(h, "gcdm_set_option: unknown option " + k);
+}
+
+int gcdm_get_option(const gcdm_handle* h, const char* name) {
+    if (!h || !name) return -1;
+    const std::string k(name);
+    if (k == "mfma_mode") return h->mfma_x3;
+    if (k == "edge_tile") return h->edge_tile;
+    return -1;
 }
 
 int gcdm_profile_enable(gcdm_handle* h, int32_t enable) {

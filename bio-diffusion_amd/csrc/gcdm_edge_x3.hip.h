@@ -1,0 +1,491 @@
+// gcdm_edge_x3.hip.h -- split-precision variant of the fused edge-message kernel (gfx950).
+//
+// Same tile, phases and LDS budget as k_edge_msg (gcdm_kernels.hip.h), but the dense contractions run on
+// v_mfma_f32_32x32x16_f16 with every fp32 operand x represented as  x = hi + 2^-11 * lo',  hi = f16(x),
+// lo' = f16((x - hi) * 2^11):
+//     W.X  =  Whi.Xhi  +  2^-11 (Whi.Xlo' + Wlo'.Xhi)        [dropped: 2^-22 Wlo'.Xlo' ~ 2^-24 relative]
+// Products of two f16 values are exact in fp32 and the MFMA accumulates in fp32, so the result carries fp32-class error
+// (measured against an fp64 run of the reference: 7e-7 vs 8e-7 for plain fp32, tests/test_oracle_golden.py::test_f16x3_emulation)
+// at 3 f16 MFMAs per 16-deep block instead of 8 fp32 MFMAs: 5.3x the matrix rate.
+//   * weights are split once on the host (two packed f16 arrays, same bytes as fp32);
+//   * the message scalars live as fp32 in REGISTERS of the wave that owns their 64 channels (residual adds are exact fp32);
+//     LDS holds only their hi / lo' images in 8-channel groups (XH8 / XL8: 16 B per group, same footprint as fp32);
+//   * f16 range: |x| >= 6e4 cannot be represented -> GCDM_FLAG_F16_RANGE is raised and the caller re-runs in fp32 mode.
+#pragma once
+#include "gcdm_kernels.hip.h"
+
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+
+#define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16((a), (b), (c), 0, 0, 0)
+#define X3_SCALE 2048.0f
+#define X3_INV_SCALE (1.0f / 2048.0f)
+#define X3_RANGE 6.0e4f
+
+__device__ __forceinline__ void split16(float x, _Float16& hi, _Float16& lo) {
+    hi = (_Float16)x;
+    lo = (_Float16)((x - (float)hi) * X3_SCALE);
+}
+
+// ---- tile GEMM on split operands: am += Whi.Xhi ; al += Whi.Xlo' + Wlo'.Xhi ------------------------------------------------
+template <int MT, int PD = 2>
+__device__ __forceinline__ void tile_gemm_x3(f32x16 (&am)[MT], f32x16 (&al)[MT], const h8* __restrict__ wH, const h8* __restrict__ wL,
+                                             int KB, const h8* xh8, const h8* xl8, int TP, int lane) {
+    constexpr int R = PD + 1;
+    const h8* wh = wH + lane;
+    const h8* wl = wL + lane;
+    const int boff = (lane >> 5) * TP + (lane & 31);
+    const h8* sh = xh8 + boff;
+    const h8* sl = xl8 + boff;
+    const int wstride = KB * 64;
+    const int last = KB - 1;
+    h8 ah[R][MT], alo[R][MT];
+    h8 bh[2], bl[2];
+#pragma unroll
+    for (int r = 0; r < PD; ++r) {
+        const int kl = min(r, last);
+#pragma unroll
+        for (int m = 0; m < MT; ++m) { ah[r][m] = wh[m * wstride + kl * 64]; alo[r][m] = wl[m * wstride + kl * 64]; }
+    }
+    bh[0] = sh[0];
+    bl[0] = sl[0];
+    auto body = [&](int kb, int r, bool do_a) {
+        if (do_a) {
+            const int kl = min(kb + PD, last);
+#pragma unroll
+            for (int m = 0; m < MT; ++m) { ah[(r + PD) % R][m] = wh[m * wstride + kl * 64]; alo[(r + PD) % R][m] = wl[m * wstride + kl * 64]; }
+        }
+        const int kn = min(kb + 1, last);
+        bh[(r + 1) & 1] = sh[(2 * kn) * TP];
+        bl[(r + 1) & 1] = sl[(2 * kn) * TP];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int m = 0; m < MT; ++m) am[m] = MFMA16(ah[r % R][m], bh[r & 1], am[m]);
+#pragma unroll
+        for (int m = 0; m < MT; ++m) al[m] = MFMA16(ah[r % R][m], bl[r & 1], al[m]);
+#pragma unroll
+        for (int m = 0; m < MT; ++m) al[m] = MFMA16(alo[r % R][m], bh[r & 1], al[m]);
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    int k0 = 0;
+    for (; k0 + 2 * R <= KB; k0 += 2 * R) {
+#pragma unroll
+        for (int r = 0; r < 2 * R; ++r) body(k0 + r, r, true);
+    }
+#pragma unroll
+    for (int r = 0; r < 2 * R - 1; ++r)
+        if (k0 + r < KB) body(k0 + r, r, r + PD < 2 * R - 1);
+}
+
+// gate partial from registers: contraction over the 64 channels this wave holds (two 16-deep blocks per M-tile)
+template <int MT>
+__device__ __forceinline__ void gate_partial_x3(f32x16& gm, f32x16& gl, const f32x16 (&act)[MT], const h8* __restrict__ wgH,
+                                                const h8* __restrict__ wgL, int mt0, int lane) {
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            h8 bh, bl;
+#pragma unroll
+            for (int s = 0; s < 8; ++s) {
+                _Float16 hi, lo;
+                split16(act[m][8 * j + s], hi, lo);
+                bh[s] = hi;
+                bl[s] = lo;
+            }
+            const h8 aH = wgH[((mt0 + m) * 2 + j) * 64 + lane];
+            const h8 aL = wgL[((mt0 + m) * 2 + j) * 64 + lane];
+            gm = MFMA16(aH, bh, gm);
+            gl = MFMA16(aH, bl, gl);
+            gl = MFMA16(aL, bh, gl);
+        }
+}
+
+// hi / lo' images of the wave's fp32 state -> XH8 / XL8 (8 bytes per lane and group: channels 8q+4*half+{0..3})
+template <int MT>
+__device__ __forceinline__ bool store_state_x3(char* XH, char* XL, int gbase8, const f32x16 (&st)[MT], int TP, int mt0, int lane, int col0) {
+    const int half = lane >> 5, l31 = lane & 31;
+    bool over = false;
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            h4 vh, vl;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const float x = st[m][4 * q + t];
+                over |= fabsf(x) > X3_RANGE;
+                _Float16 hi, lo;
+                split16(x, hi, lo);
+                vh[t] = hi;
+                vl[t] = lo;
+            }
+            const int off = ((gbase8 + 4 * (mt0 + m) + q) * TP + col0 + l31) * 16 + 8 * half;
+            *(h4*)(XH + off) = vh;
+            *(h4*)(XL + off) = vl;
+        }
+    return over;
+}
+
+__device__ __forceinline__ bool put16(char* XH, char* XL, int TP, int g8, int slot, int e, float x) {
+    _Float16 hi, lo;
+    split16(x, hi, lo);
+    const int off = (g8 * TP + e) * 16 + 2 * slot;
+    *(_Float16*)(XH + off) = hi;
+    *(_Float16*)(XL + off) = lo;
+    return fabsf(x) > X3_RANGE;
+}
+
+// pre-phase of a residual message GCP2 (H = 8, V_in = 32): same arithmetic as gcp2_pre, extended-K rows written as hi / lo'
+template <int T, int NTHR>
+__device__ __forceinline__ bool gcp2_pre_x3(const float* __restrict__ wdd, const float* VV, const float* FR, char* XH, char* XL,
+                                            int gN8, int gQ8, int gEnd8, float* VH, int e, int part) {
+    constexpr int H = 8, V_IN = GCDM_V, TP = T + 1, PARTS = NTHR / T, ROWS = H + 3, NH = (ROWS + PARTS - 1) / PARTS;
+    float ax[NH], ay[NH], az[NH];
+    const float* wrow[NH];
+#pragma unroll
+    for (int i = 0; i < NH; ++i) {
+        ax[i] = ay[i] = az[i] = 0.f;
+        const int hh = part + PARTS * i;
+        wrow[i] = wdd + (hh < ROWS ? hh : ROWS - 1) * V_IN;
+    }
+    const float* vp = VV + e;
+#pragma unroll 8
+    for (int c = 0; c < V_IN; ++c) {
+        const float vx = vp[0], vy = vp[TP], vz = vp[2 * TP];
+        vp += 3 * TP;
+#pragma unroll
+        for (int i = 0; i < NH; ++i) {
+            const float wc = wrow[i][c];
+            ax[i] += wc * vx; ay[i] += wc * vy; az[i] += wc * vz;
+        }
+    }
+    float f[9];
+#pragma unroll
+    for (int r = 0; r < 9; ++r) f[r] = FR[r * TP + e];
+    bool over = false;
+#pragma unroll
+    for (int i = 0; i < NH; ++i) {
+        const int hh = part + PARTS * i;
+        const float vx = ax[i], vy = ay[i], vz = az[i];
+        if (hh < H) {
+            over |= put16(XH, XL, TP, gN8 + (hh >> 3), hh & 7, e, sqrtf(vx * vx + vy * vy + vz * vz + 1e-8f) + 1e-8f);
+            VH[(hh * 3 + 0) * TP + e] = vx;
+            VH[(hh * 3 + 1) * TP + e] = vy;
+            VH[(hh * 3 + 2) * TP + e] = vz;
+        } else if (hh < ROWS) {
+            const int k = hh - H;
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+                const int idx = 3 * k + r;
+                over |= put16(XH, XL, TP, gQ8 + (idx >> 3), idx & 7, e, f[3 * r] * vx + f[3 * r + 1] * vy + f[3 * r + 2] * vz);
+            }
+        }
+    }
+    if (part == PARTS - 1) {  // zero the padding slots (weights there are zero, LDS is not)
+        for (int idx = 9; idx < 16; ++idx) put16(XH, XL, TP, gQ8 + (idx >> 3), idx & 7, e, 0.f);
+        for (int g = gQ8 + 2; g < gEnd8; ++g) {
+            *(v4f*)(XH + (g * TP + e) * 16) = (v4f){0.f, 0.f, 0.f, 0.f};
+            *(v4f*)(XL + (g * TP + e) * 16) = (v4f){0.f, 0.f, 0.f, 0.f};
+        }
+    }
+    return over;
+}
+
+struct EdgeMsgX3Args {
+    EdgeMsgArgs base;                 // everything the fp32 kernel takes (tables, biases, vector weights, attention)
+    const h8* w0H; const h8* w0L; int KB0;          // msg0 per-edge part, packed [8][KB0][64] x 8 f16
+    const h8* wg0H; const h8* wg0L;                 // msg0 gate, packed [8][2][64]
+    const h8* wH[3]; const h8* wL[3]; int KB;       // msg1..3 scalar_out, packed [8][KB][64]
+    const h8* wgH[3]; const h8* wgL[3];
+    uint32_t* flags_dev;                            // bit GCDM_FLAG_F16_RANGE
+};
+
+#define GCDM_FLAG_F16_RANGE_BIT 8u
+
+template <int SE, int VE>
+__global__ __launch_bounds__(512) void k_edge_msg_x3(EdgeMsgX3Args ax) {
+    constexpr int ET = 64;
+    const EdgeMsgArgs& a = ax.base;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    using Geo = EdgeGeo<ET>;
+    constexpr int ETP = Geo::TP, EK_THREADS = Geo::THREADS, PARTS = Geo::PARTS;
+    constexpr int X3_GROUPS8 = 36;                      // 32 state + 1 norm + 2 frame scalars + 1 pad (K' = 288)
+    char* XH = smem + Geo::OFF_XS;                      // [36][65] x 16 B : hi images
+    char* XL = XH + X3_GROUPS8 * ETP * 16;              // [36][65] x 16 B : lo' images
+    static_assert(2 * X3_GROUPS8 * ETP * 16 <= Geo::OFF_VV, "XH8/XL8 must fit the fp32 XS4 region");
+    v4f* XS4 = (v4f*)(smem + Geo::OFF_XS);              // fp32 alias, used after the last GEMM (attention + aggregation)
+    float* VV = (float*)(smem + Geo::OFF_VV);
+    float* VH = (float*)(smem + Geo::OFF_VH);
+    float* PG = (float*)(smem + Geo::OFF_PG);
+    float* FR = (float*)(smem + Geo::OFF_FR);
+    int* m_row = (int*)(smem + Geo::OFF_META);
+    int* m_col = m_row + ET;
+    int* m_seg = m_col + ET;
+    float* m_att = (float*)(m_seg + ET + 2);
+    int* m_misc = (int*)(m_att + ET);
+
+    constexpr int H0 = (2 * GCDM_V + VE) / 4;
+    constexpr int SEG = SE / 4;                          // float4 groups of e' in global memory
+    constexpr int N8 = SE / 8;                           // first 8-group of the norm rows in msg0
+    constexpr int H0G8 = (H0 + 7) / 8;
+    constexpr int Q8 = N8 + H0G8;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int e = lane, part = wave;
+    const int E = a.E, N = a.N;
+    const int e0 = blockIdx.x * ET;
+    const int nvalid = min(ET, E - e0);
+    const int eid = min(e0 + e, E - 1);
+    const int ni = a.EROW[eid], nj = a.ECOL[eid];
+    const uint64_t t_start = a.prof ? __builtin_amdgcn_s_memtime() : 0;
+    bool over = false;
+
+    if (wave == 0) {
+        m_row[e] = ni;
+        m_col[e] = nj;
+        const int prev = __shfl_up(ni, 1);
+        const bool start = (e < nvalid) && (e == 0 || prev != ni);
+        const unsigned long long mask = __ballot(start);
+        const int sid = __popcll(mask & ((2ull << lane) - 1ull)) - 1;
+        if (start) m_seg[sid] = e;
+        if (lane == 0) {
+            const int ns = __popcll(mask);
+            m_seg[ns] = nvalid;
+            m_misc[0] = ns;
+        }
+    }
+    // ---- P1: msg0 pre-phase ---------------------------------------------------------------------------------------------
+    {
+        float fr[9];
+#pragma unroll
+        for (int r = 0; r < 9; ++r) fr[r] = a.FR[(size_t)r * E + eid];
+        if (part == 0) {
+#pragma unroll
+            for (int r = 0; r < 9; ++r) FR[r * ETP + e] = fr[r];
+        }
+        for (int g = part; g < SEG; g += PARTS) {       // e' (fp32 in HBM) -> hi / lo' halves of an 8-group
+            const v4f v = a.EP4[(size_t)g * E + eid];
+            h4 vh, vl;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                _Float16 hi, lo;
+                split16(v[t], hi, lo);
+                vh[t] = hi; vl[t] = lo;
+                over |= fabsf(v[t]) > X3_RANGE;
+            }
+            const int off = ((g >> 1) * ETP + e) * 16 + 8 * (g & 1);
+            *(h4*)(XH + off) = vh;
+            *(h4*)(XL + off) = vl;
+        }
+        float al[VE];
+#pragma unroll
+        for (int c = 0; c < VE; ++c) al[c] = a.AL[(size_t)c * E + eid];
+        const float u0 = a.U[eid], u1 = a.U[(size_t)E + eid], u2 = a.U[2 * (size_t)E + eid];
+        constexpr int ROWS0 = H0 + 3, NH0 = (ROWS0 + PARTS - 1) / PARTS;
+        float gi[NH0][3], gj[NH0][3], beta[NH0];
+#pragma unroll
+        for (int i = 0; i < NH0; ++i) {
+            const int hh = min(part + PARTS * i, ROWS0 - 1);
+            const size_t r0 = (size_t)(hh * 3) * N;
+#pragma unroll
+            for (int x = 0; x < 3; ++x) {
+                gi[i][x] = a.VDI[r0 + (size_t)x * N + ni];
+                gj[i][x] = a.VDJ[r0 + (size_t)x * N + nj];
+            }
+            const float* w = a.wddE + hh * VE;
+            float bsum = 0.f;
+#pragma unroll
+            for (int c = 0; c < VE; ++c) bsum += w[c] * al[c];
+            beta[i] = bsum;
+        }
+#pragma unroll
+        for (int i = 0; i < NH0; ++i) {
+            const int hh = part + PARTS * i;
+            const float vx = gi[i][0] + beta[i] * u0 + gj[i][0];
+            const float vy = gi[i][1] + beta[i] * u1 + gj[i][1];
+            const float vz = gi[i][2] + beta[i] * u2 + gj[i][2];
+            if (hh < H0) {
+                over |= put16(XH, XL, ETP, N8 + (hh >> 3), hh & 7, e, sqrtf(vx * vx + vy * vy + vz * vz + 1e-8f) + 1e-8f);
+                VH[(hh * 3 + 0) * ETP + e] = vx;
+                VH[(hh * 3 + 1) * ETP + e] = vy;
+                VH[(hh * 3 + 2) * ETP + e] = vz;
+            } else if (hh < ROWS0) {
+                const int k = hh - H0;
+#pragma unroll
+                for (int r = 0; r < 3; ++r) {
+                    const int idx = 3 * k + r;
+                    over |= put16(XH, XL, ETP, Q8 + (idx >> 3), idx & 7, e, fr[3 * r] * vx + fr[3 * r + 1] * vy + fr[3 * r + 2] * vz);
+                }
+            }
+        }
+        if (part == PARTS - 1) {
+            for (int hh = H0; hh < 8 * H0G8; ++hh) put16(XH, XL, ETP, N8 + (hh >> 3), hh & 7, e, 0.f);
+            for (int idx = 9; idx < 16; ++idx) put16(XH, XL, ETP, Q8 + (idx >> 3), idx & 7, e, 0.f);
+            for (int g = Q8 + 2; g < 2 * ax.KB0; ++g) {
+                *(v4f*)(XH + (g * ETP + e) * 16) = (v4f){0.f, 0.f, 0.f, 0.f};
+                *(v4f*)(XL + (g * ETP + e) * 16) = (v4f){0.f, 0.f, 0.f, 0.f};
+            }
+        }
+    }
+    STAMP(1);
+    __syncthreads();
+    STAMP(2);
+
+    const int half = lane >> 5, l31 = lane & 31;
+    const int mt0 = 2 * (wave & 3);
+    const int col0 = 32 * (wave >> 2);
+    f32x16 st[2];        // fp32 message scalars of this wave's 64 channels x 32 edges (lives in registers for the whole tile)
+    f32x16 am[2], al2[2];
+    f32x16 gm, gl;
+    const h8* xh8 = (const h8*)XH + col0;
+    const h8* xl8 = (const h8*)XL + col0;
+
+    // ---- P2: msg0 GEMM ----------------------------------------------------------------------------------------------------
+    {
+        const int ri = m_row[col0 + l31], cj = m_col[col0 + l31];
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int g = 8 * (mt0 + m) + 2 * q + half;
+                const v4f p = a.PQ4[(size_t)g * N + ri];
+                const v4f qq = a.PQ4[(size_t)(64 + g) * N + cj];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) { am[m][4 * q + t] = p[t] + qq[t]; al2[m][4 * q + t] = 0.f; }
+            }
+        STAMP(3);
+        tile_gemm_x3<2>(am, al2, ax.w0H + (size_t)mt0 * ax.KB0 * 64, ax.w0L + (size_t)mt0 * ax.KB0 * 64, ax.KB0, xh8, xl8, ETP, lane);
+        STAMP(4);
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) st[m][r] = fast_silu(am[m][r] + al2[m][r] * X3_INV_SCALE);
+        STAMP(5);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { gm[r] = 0.f; gl[r] = 0.f; }
+        gate_partial_x3<2>(gm, gl, st, ax.wg0H, ax.wg0L, mt0, lane);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) gm[r] += gl[r] * X3_INV_SCALE;
+        f32x16 gtmp[1] = {gm};
+        store_gate_partial<1>(PG, gtmp, ETP, wave & 3, lane, col0);
+        STAMP(6);
+    }
+    __syncthreads();
+    STAMP(7);
+    // ---- P3: state images + vector part of msg0 ---------------------------------------------------------------------------
+    over |= store_state_x3<2>(XH, XL, 0, st, ETP, mt0, lane, col0);
+    vec_finish<ET, H0, EK_THREADS>(PG, a.bg0, a.wup0, GCDM_V, VH, e, part, [&](int c, float ox, float oy, float oz) {
+        VV[(c * 3 + 0) * ETP + e] = ox;
+        VV[(c * 3 + 1) * ETP + e] = oy;
+        VV[(c * 3 + 2) * ETP + e] = oz;
+    });
+    STAMP(8);
+    __syncthreads();
+    STAMP(9);
+
+    // ---- residual message GCP2s k = 1..3 ---------------------------------------------------------------------------------
+    for (int k = 0; k < 3; ++k) {
+        const GcpW& w = a.mk[k];
+        over |= gcp2_pre_x3<ET, EK_THREADS>(w.wdd, VV, FR, XH, XL, 32, 33, 2 * ax.KB, VH, e, part);
+        if (k == 0) STAMP(10);
+        __syncthreads();
+        if (k == 0) STAMP(11);
+        {
+            f32x16 bias[2][1];
+            acc_init_bias<2, 1>(bias, w.b, mt0, lane);
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { am[m][r] = bias[m][0][r]; al2[m][r] = 0.f; }
+        }
+        tile_gemm_x3<2>(am, al2, ax.wH[k] + (size_t)mt0 * ax.KB * 64, ax.wL[k] + (size_t)mt0 * ax.KB * 64, ax.KB, xh8, xl8, ETP, lane);
+        if (k == 0) STAMP(12);
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) am[m][r] = fast_silu(am[m][r] + al2[m][r] * X3_INV_SCALE);
+        if (k == 0) STAMP(13);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { gm[r] = 0.f; gl[r] = 0.f; }
+        gate_partial_x3<2>(gm, gl, am, ax.wgH[k], ax.wgL[k], mt0, lane);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) gm[r] += gl[r] * X3_INV_SCALE;
+        f32x16 gtmp[1] = {gm};
+        store_gate_partial<1>(PG, gtmp, ETP, wave & 3, lane, col0);
+        if (k == 0) STAMP(14);
+        __syncthreads();                 // every wave is done reading the old XH8 / XL8 images
+        if (k == 0) STAMP(15);
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) st[m][r] += am[m][r];       // residual add in fp32 (gcpnet.py:701)
+        if (k < 2) {
+            over |= store_state_x3<2>(XH, XL, 0, st, ETP, mt0, lane, col0);
+        } else {                          // last GCP2: fp32 image for attention + segment sums (aliases XH8 / XL8)
+            f32x16 s2[2][1];
+            s2[0][0] = st[0];
+            s2[1][0] = st[1];
+            store_state<2, 1, false>(XS4, 0, s2, ETP, mt0, lane, col0);
+        }
+        vec_finish<ET, 8, EK_THREADS>(PG, w.bg, w.wup, GCDM_V, VH, e, part, [&](int c, float ox, float oy, float oz) {
+            VV[(c * 3 + 0) * ETP + e] += ox;
+            VV[(c * 3 + 1) * ETP + e] += oy;
+            VV[(c * 3 + 2) * ETP + e] += oz;
+        });
+        if (k == 0) STAMP(16);
+        __syncthreads();
+        if (k == 0) STAMP(17);
+    }
+    STAMP(18);
+    if (__any(over) && lane == 0) atomicOr(ax.flags_dev, GCDM_FLAG_F16_RANGE_BIT);
+
+    // ---- scalar message attention + aggregation: identical to the fp32 kernel (fp32 data) ---------------------------------
+    {
+        float s = 0.f;
+        constexpr int GPP = GCDM_SG / PARTS;
+        for (int g = part * GPP; g < part * GPP + GPP; ++g) {
+            const v4f wv = *(const v4f*)(a.wa + 4 * g);
+            const v4f x = XS4[g * ETP + e];
+            s += wv[0] * x[0] + wv[1] * x[1] + wv[2] * x[2] + wv[3] * x[3];
+        }
+        PG[part * ETP + e] = s;
+        __syncthreads();
+        if (part == 0) {
+            float s2 = a.ba;
+#pragma unroll
+            for (int q = 0; q < PARTS; ++q) s2 += PG[q * ETP + e];
+            m_att[e] = fast_sigmoid(s2);
+        }
+        __syncthreads();
+    }
+    STAMP(19);
+    {
+        const int nseg = m_misc[0];
+        constexpr int UNITS = GCDM_SG + 3 * GCDM_V;
+        for (int wk = tid; wk < nseg * UNITS; wk += EK_THREADS) {
+            const int sg = wk / UNITS, un = wk - sg * UNITS;
+            const int sb = m_seg[sg], en = m_seg[sg + 1];
+            const int node = m_row[sb];
+            const bool whole = (en - sb) == a.NCNT[node];
+            float* dst = a.AGG + (size_t)node * GCDM_AGGW;
+            if (un < GCDM_SG) {
+                v4f s = {0.f, 0.f, 0.f, 0.f};
+                for (int x = sb; x < en; ++x) s += XS4[un * ETP + x] * m_att[x];
+                if (whole) {
+                    *(v4f*)(dst + 4 * un) = s;
+                } else {
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) atomicAdd(dst + 4 * un + t, s[t]);
+                }
+            } else {
+                const int r = un - GCDM_SG;
+                float s = 0.f;
+                for (int x = sb; x < en; ++x) s += VV[r * ETP + x];
+                if (whole) dst[GCDM_S + r] = s;
+                else atomicAdd(dst + GCDM_S + r, s);
+            }
+        }
+    }
+    STAMP(20);
+}

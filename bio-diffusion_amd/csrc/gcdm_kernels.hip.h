@@ -955,8 +955,9 @@ struct FinishArgs {
 
 __global__ __launch_bounds__(64) void k_finish(FinishArgs a) {
     const int b = blockIdx.x, o = a.noff[b], n = a.noff[b + 1] - o;
-    const bool nan = (*a.flags_dev & 1u) != 0;
-    if (nan && a.user_flags && b == 0 && threadIdx.x == 0) atomicOr(a.user_flags, 1u);
+    const uint32_t fl = *a.flags_dev;
+    const bool nan = (fl & 1u) != 0;
+    if (fl && a.user_flags && b == 0 && threadIdx.x == 0) atomicOr(a.user_flags, fl);   // NaN-vel / f16-range bits
     float m0 = 0.f, m1 = 0.f, m2 = 0.f;
     if (!nan) {
         for (int i = 0; i < n; ++i) { m0 += a.VEL[o + i]; m1 += a.VEL[a.N + o + i]; m2 += a.VEL[2 * (size_t)a.N + o + i]; }

@@ -174,6 +174,7 @@ class GCPNetDynamics(nn.Module):
         self._weights_version = None
         self._plan_key = None
         self._flags = None
+        self.check_f16_range = True
 
     # ------------------------------------------------------------------------------------------
     def _native_config(self, device_index: int) -> "_native.GcdmConfig":
@@ -262,7 +263,24 @@ class GCPNetDynamics(nn.Module):
         self._plan_from_batch_index(cfg_get(batch, "batch"), cfg_get(batch, "mask"))
         ctx = cfg_get(batch, "props_context") if self.condition_on_context else None
         out = self.native_forward(xh, t, ctx)
+        if self.mfma_mode == 1 and self.check_f16_range:
+            # split-precision mode: one host sync to make the module-level call self-healing (the fused sampler loop reads
+            # the flag once per run instead); an activation beyond the f16 range -> recompute this call with fp32 MFMA
+            if self.read_flags() & _native.FLAG_F16_RANGE:
+                self.set_mfma_mode(0)
+                try:
+                    out = self.native_forward(xh, t, ctx)
+                finally:
+                    self.set_mfma_mode(1)
         return batch, out
+
+    @property
+    def mfma_mode(self) -> int:
+        return int(self._lib.gcdm_get_option(self._handle, b"mfma_mode")) if self._handle is not None else -1
+
+    def set_mfma_mode(self, mode: int) -> None:
+        """0: fp32 MFMA everywhere; 1: split-precision f16x3 edge kernel (fp32-equivalent accuracy, default)."""
+        _native.check(self._lib, self._handle, self._lib.gcdm_set_option(self._handle, b"mfma_mode", int(mode)), "gcdm_set_option")
 
     def native_forward(self, xh: torch.Tensor, t: torch.Tensor, context: Optional[torch.Tensor] = None,
                        out: Optional[torch.Tensor] = None) -> torch.Tensor:

@@ -219,7 +219,7 @@ class EquivariantVariationalDiffusion(nn.Module):
                        context: Optional[torch.Tensor] = None, fix_noise: bool = False, generate_x_only: bool = False,
                        fix_self_conditioning_noise: bool = False, norm_with_original_timesteps: bool = False,
                        noise_fn: Optional[Callable[[int], torch.Tensor]] = None, seed: int = 1234,
-                       step_callback: Optional[Callable[[int, torch.Tensor], None]] = None
+                       step_callback: Optional[Callable[[int, torch.Tensor], None]] = None, _retry_fp32: bool = False
                        ) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
         """Draw samples.  ``noise_fn(k)`` (optional) returns the k-th raw standard-normal draw [N,3+F] on ``device``
         (k = 0 for z_T, then one per step, then one for the final decode: the reference's randn call order,
@@ -237,6 +237,7 @@ class EquivariantVariationalDiffusion(nn.Module):
         dyn.plan(num_nodes.cpu())
         N, D = int(batch_index.shape[0]), self.num_x_dims + self.num_node_scalar_features
         ctx_ptr = None
+        context_in = context
         if context is not None:
             context = context.to(device, torch.float32)[batch_index].contiguous()
             ctx_ptr = C.c_void_p(context.data_ptr())
@@ -270,6 +271,17 @@ class EquivariantVariationalDiffusion(nn.Module):
         st = lib.gcdm_sample_final(h, C.c_void_p(z.data_ptr()), ctx_ptr, p, C.c_uint64(seed), C.c_void_p(out.data_ptr()), fptr, stream)
         _native.check(lib, h, st, "gcdm_sample_final")
         fl = int(flags.item())   # the one host sync of the run
+        if fl & _native.FLAG_F16_RANGE:
+            if _retry_fp32:
+                raise RuntimeError("f16 range flag raised in fp32 mode (internal error)")
+            log.warning("An activation left the f16 range of the split-precision kernels; re-running the sample with fp32 MFMA.")
+            dyn.set_mfma_mode(0)
+            try:
+                return self.mol_gen_sample(num_samples, num_nodes, device, return_frames, num_timesteps, None, context_in, fix_noise,
+                                           generate_x_only, fix_self_conditioning_noise, norm_with_original_timesteps,
+                                           noise_fn=noise_fn, seed=seed, step_callback=step_callback, _retry_fp32=True)
+            finally:
+                dyn.set_mfma_mode(1)
         if fl & _native.FLAG_NAN_VEL:
             log.warning("Detected NaN in `vel` -> GCPNet `vel` output was reset to zero for at least one time step.")
         if fl & _native.FLAG_COG_DRIFT:

@@ -34,6 +34,7 @@ extern "C" {
 #define GCDM_FLAG_NAN_VEL        0x1u  /* gcpnet.py:1213-1216: NaN seen in vel -> whole-batch vel zeroed   */
 #define GCDM_FLAG_MEAN_NOT_ZERO  0x2u  /* variational_diffusion.py:465-474 assert_mean_zero_with_mask fails  */
 #define GCDM_FLAG_COG_DRIFT      0x4u  /* variational_diffusion.py:1392-1402: CoG drift > 5e-2, re-projected  */
+#define GCDM_FLAG_F16_RANGE      0x8u  /* split-precision mode (GCDM_MFMA=f16x3): an activation exceeded 6e4 -> result invalid, re-run in fp32 mode */
 
 typedef struct GcdmConfig {
     int32_t abi_version;       /* must be GCDM_ABI_VERSION */
@@ -102,6 +103,13 @@ int gcdm_sample_init(gcdm_handle* h, float* z, const float* noise, uint64_t seed
 int64_t gcdm_debug_read(gcdm_handle* h, const char* name, float* host_out, int64_t capacity);
 /* Stops the next forward after `num_layers_to_run` interaction layers (-1 = all; test hook). */
 int gcdm_debug_set_layer_limit(gcdm_handle* h, int32_t num_layers_to_run);
+
+/* Options.  "mfma_mode": 1 (default; env GCDM_MFMA=f16x3) evaluates the per-edge contractions with three f16 MFMAs per product
+ * block on operands split as x = hi + 2^-11 lo' (fp32-equivalent accuracy; raises GCDM_FLAG_F16_RANGE if an
+ * activation exceeds 6e4, in which case the caller must re-run with mode 0); 0 (env GCDM_MFMA=f32) uses fp32 MFMA throughout.
+ * "edge_tile": 64 (default) or 32 edges per workgroup of the fp32 edge kernel. */
+int gcdm_set_option(gcdm_handle* h, const char* name, int32_t value);
+int gcdm_get_option(const gcdm_handle* h, const char* name);
 
 /* Measurement hook: when enabled, every forward brackets each launch of the dominant kernel (the fused edge-message
  * kernel, one launch per interaction layer) with HIP events on `stream`; gcdm_profile_edge_kernel_ms() synchronises on

@@ -31,7 +31,10 @@ def _ocfg(case):
                           num_layers=d["L"], norm_values=d["norm_values"])
 
 
-def _net(case, seed=17, scale=1.0):
+MODES = [pytest.param(1, id="f16x3"), pytest.param(0, id="f32")]
+
+
+def _net(case, seed=17, scale=1.0, mode=None):
     d = _dims(case)
     ds = "geom" if case == "geom" else "qm9"
     cond = ("alpha",) if d["n_ctx"] else ()
@@ -39,7 +42,11 @@ def _net(case, seed=17, scale=1.0):
     net = pkg.GCPNetDynamics(**cfgs)
     W = synth.make_weights(synth.dynamics_shapes(d["S"], d["V"], d["Se"], d["Ve"], d["L"], synth.dims_h_in(d)), seed=seed, scale_2d=scale)
     net.load_state_dict(W)
-    return net.cuda(), W, cfgs
+    net = net.cuda()
+    if mode is not None:
+        net._ensure_handle(torch.device("cuda"))
+        net.set_mfma_mode(mode)
+    return net, W, cfgs
 
 
 def _fwd(net, xh, t, bi, ctx=None):
@@ -57,11 +64,14 @@ def test_native_library_is_loaded():
     assert "libgcdm_hip.so" in maps
 
 
+@pytest.mark.parametrize("mode", MODES)
 @pytest.mark.parametrize("case", ["qm9", "qm9cond", "geom"])
-def test_forward_matches_reference_golden(case, golden_dir):
-    """Full-width production architecture vs the outputs of the REFERENCE itself (tests/golden/dyn_full_*.npz)."""
+def test_forward_matches_reference_golden(case, mode, golden_dir):
+    """Full-width production architecture vs the outputs of the REFERENCE itself (tests/golden/dyn_full_*.npz), in both
+    matrix modes (split-precision f16x3 = default, fp32 MFMA)."""
     g = np.load(os.path.join(golden_dir, f"dyn_full_{case}.npz"))
-    net, W, _ = _net(case, seed=int(g["weight_seed"]))
+    net, W, _ = _net(case, seed=int(g["weight_seed"]), mode=mode)
+    assert net.mfma_mode == mode
     nn_ = torch.tensor(g["num_nodes"])
     bi = O.num_nodes_to_batch_index(nn_)
     ctx = torch.tensor(g["ctx"]) if "ctx" in g.files else None
@@ -81,17 +91,41 @@ def test_forward_matches_reference_golden(case, golden_dir):
     ("qm9", [1]), ("qm9", [2, 1, 1, 3]), ("qm9", [29] * 7 + [3]), ("qm9", [64, 65, 63, 1, 130]),
     ("geom", [44] * 5), ("geom", [181, 3, 90]), ("qm9cond", [19] * 9),
 ])
-def test_forward_matches_oracle_ragged(case, num_nodes):
+@pytest.mark.parametrize("mode", MODES)
+def test_forward_matches_oracle_ragged(case, num_nodes, mode):
     """Edge cases of the tiling: single atoms, rows shorter / equal / longer than the 64-edge tile, rows spanning 3+ tiles
     (atomic accumulation), last tile partially filled, molecule sizes at the dataset maxima (29 / 181)."""
     d = _dims(case)
-    net, W, _ = _net(case, seed=23, scale=0.5)
+    net, W, _ = _net(case, seed=23, scale=0.5, mode=mode)
     xh, t, bi, nn_, ctx = synth.make_inputs(num_nodes, synth.dims_feat(d), seed=31, t_value=0.63, n_ctx=d["n_ctx"])
     ref = O.dynamics_forward(W, _ocfg(case), xh, t, bi, None, ctx)
     out = _fwd(net, xh, t, bi, ctx)
     scale = max(1.0, ref.abs().max().item())
     assert torch.isfinite(out).all()
     assert (out - ref).abs().max().item() <= TOL * scale
+
+
+def test_f16_range_flag_and_fp32_fallback():
+    """Activations beyond the f16 range: the split-precision kernel raises GCDM_FLAG_F16_RANGE and the module-level call
+    transparently recomputes with fp32 MFMA (bit-identical to fp32 mode)."""
+    d = _dims("qm9")
+    net, W, _ = _net("qm9", seed=29, scale=3.0)
+    xh, t, bi, nn_, _ = synth.make_inputs([70, 33, 64], synth.dims_feat(d), seed=5)
+    net._ensure_handle(torch.device("cuda"))
+    net.set_mfma_mode(0)
+    want = _fwd(net, xh, t, bi)
+    scale = want.abs().max().item()
+    net.set_mfma_mode(1)
+    net.check_f16_range = False
+    raw = _fwd(net, xh, t, bi)
+    fl = net.read_flags()
+    assert torch.isfinite(want).all() and scale > 1.0
+    assert fl & pkg._native.FLAG_F16_RANGE, "test input does not leave the f16 range"
+    net.check_f16_range = True
+    got = _fwd(net, xh, t, bi)
+    assert net.mfma_mode == 1
+    assert torch.equal(got, want) or (got - want).abs().max().item() <= 1e-6 * scale
+    del raw
 
 
 def test_forward_input_validation():
@@ -217,15 +251,16 @@ def _rot(seed=0):
     return q.float()
 
 
+@pytest.mark.parametrize("mode", MODES)
 @pytest.mark.parametrize("case,B,n", [("qm9", 1024, 19), ("geom", 256, 44)])
-def test_full_size_properties(case, B, n):
+def test_full_size_properties(case, B, n, mode):
     """At the benchmark configurations (C2 / C4): (1) run-to-run determinism, (2) per-molecule zero CoM of vel,
     (3) SE(3) equivariance (rotation + translation; reflections are not a symmetry of the frames),
     (4) batch-composition independence: a molecule's output in the 1024-batch equals its output in the 3-molecule flat
     batch of itself and its two neighbours (which fixes the flat-batch orientation context) -- exercises tile boundaries,
     and (5) agreement with the CPU oracle on a 3-molecule slice."""
     d = _dims(case)
-    net, W, _ = _net(case, seed=51, scale=0.5)
+    net, W, _ = _net(case, seed=51, scale=0.5, mode=mode)
     xh, t, bi, nn_, _ = synth.make_inputs([n] * B, synth.dims_feat(d), seed=77, t_value=0.41)
     out = _fwd(net, xh, t, bi)
     out2 = _fwd(net, xh, t, bi)

@@ -129,3 +129,37 @@ def test_dynamics_full_width(golden_dir, case):
     assert torch.allclose(inter["h_0"], g["h_l0"], atol=2e-5)
     assert (out - g["out32"]).abs().max().item() <= 2e-5
     assert (out - g["out64"]).abs().max().item() <= 1e-4
+
+
+def test_f16x3_emulation_matches_fp32_accuracy(golden_dir):
+    """Numerics of the split-precision scheme the HIP edge kernel uses by default (x = hi + 2^-11 lo', three f16 products, fp32
+    accumulation), emulated inside the oracle: against the reference's fp64 outputs it is as accurate as plain fp32."""
+    import torch.nn.functional as F
+    g = load(golden_dir, "dyn_full_qm9")
+    d = synth.DATASET_DIMS["qm9"]
+    P = synth.make_weights(synth.dynamics_shapes(d["S"], d["V"], d["Se"], d["Ve"], d["L"], synth.dims_h_in(d)), seed=int(g["weight_seed"]))
+    cfg = cfg_for("qm9", d["L"])
+    bi = O.num_nodes_to_batch_index(g["num_nodes"])
+
+    def split(x):
+        hi = x.to(torch.float16)
+        return hi.float(), ((x - hi.float()) * 2048.0).to(torch.float16).float()
+
+    orig = F.linear
+
+    def linear_x3(x, w, b=None):
+        if w.shape[0] < 32:
+            return orig(x, w, b)
+        xh, xl = split(x)
+        wh, wl = split(w)
+        y = xh @ wh.T + (xh @ wl.T + xl @ wh.T) * (1.0 / 2048.0)
+        return y if b is None else y + b
+
+    O.F.linear = linear_x3
+    try:
+        out = O.dynamics_forward(P, cfg, g["xh"], g["t"], bi)
+    finally:
+        O.F.linear = orig
+    err_x3 = (out - g["out64"]).abs().max().item()
+    err_f32 = (g["out32"] - g["out64"]).abs().max().item()
+    assert err_x3 <= 3e-6 and err_x3 <= 4 * err_f32 + 1e-6
