@@ -10,7 +10,8 @@ from typing import Optional
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libgcdm_hip.so")
 SOURCES = [os.path.join(_HERE, "csrc", "gcdm_api.hip")]
-HEADERS = [os.path.join(_HERE, "csrc", "gcdm_kernels.hip.h"), os.path.join(os.path.dirname(_HERE), "include", "gcdm_hip.h")]
+HEADERS = ([os.path.join(_HERE, "csrc", f) for f in sorted(os.listdir(os.path.join(_HERE, "csrc"))) if f.endswith(".h")]
+           + [os.path.join(os.path.dirname(_HERE), "include", "gcdm_hip.h")])
 ABI_VERSION = 1
 
 FLAG_NAN_VEL, FLAG_MEAN_NOT_ZERO, FLAG_COG_DRIFT, FLAG_F16_RANGE = 1, 2, 4, 8

@@ -28,9 +28,28 @@ __device__ __forceinline__ void split16(float x, _Float16& hi, _Float16& lo) {
 }
 
 // ---- tile GEMM on split operands: am += Whi.Xhi ; al += Whi.Xlo' + Wlo'.Xhi ------------------------------------------------
-template <int MT, int PD = 2>
-__device__ __forceinline__ void tile_gemm_x3(f32x16 (&am)[MT], f32x16 (&al)[MT], const h8* __restrict__ wH, const h8* __restrict__ wL,
-                                             int KB, const h8* xh8, const h8* xl8, int TP, int lane) {
+// A-operand ring of one GEMM (PD+1 statically indexed register sets of hi / lo' weights).  `x3_prefetch` issues the loads of the
+// first PD k-blocks; it is called one phase EARLY (right after the previous GEMM), so that the cold L2 round trip of a GEMM that
+// is only 7-18 blocks long overlaps the VALU phases instead of stalling the matrix pipe.
+template <int MT, int PD>
+struct X3Ring {
+    h8 ah[PD + 1][MT], alo[PD + 1][MT];
+};
+
+template <int MT, int PD>
+__device__ __forceinline__ void x3_prefetch(X3Ring<MT, PD>& ring, const h8* __restrict__ wH, const h8* __restrict__ wL, int KB, int lane) {
+    const int wstride = KB * 64, last = KB - 1;
+#pragma unroll
+    for (int r = 0; r < PD; ++r) {
+        const int kl = min(r, last);
+#pragma unroll
+        for (int m = 0; m < MT; ++m) { ring.ah[r][m] = wH[m * wstride + kl * 64 + lane]; ring.alo[r][m] = wL[m * wstride + kl * 64 + lane]; }
+    }
+}
+
+template <int MT, int NT, int PD>
+__device__ __forceinline__ void tile_gemm_x3(f32x16 (&am)[MT][NT], f32x16 (&al)[MT][NT], X3Ring<MT, PD>& ring, const h8* __restrict__ wH,
+                                             const h8* __restrict__ wL, int KB, const h8* xh8, const h8* xl8, int TP, int lane) {
     constexpr int R = PD + 1;
     const h8* wh = wH + lane;
     const h8* wl = wL + lane;
@@ -39,32 +58,31 @@ __device__ __forceinline__ void tile_gemm_x3(f32x16 (&am)[MT], f32x16 (&al)[MT],
     const h8* sl = xl8 + boff;
     const int wstride = KB * 64;
     const int last = KB - 1;
-    h8 ah[R][MT], alo[R][MT];
-    h8 bh[2], bl[2];
+    h8 bh[2][NT], bl[2][NT];
 #pragma unroll
-    for (int r = 0; r < PD; ++r) {
-        const int kl = min(r, last);
-#pragma unroll
-        for (int m = 0; m < MT; ++m) { ah[r][m] = wh[m * wstride + kl * 64]; alo[r][m] = wl[m * wstride + kl * 64]; }
-    }
-    bh[0] = sh[0];
-    bl[0] = sl[0];
+    for (int n = 0; n < NT; ++n) { bh[0][n] = sh[n * 32]; bl[0][n] = sl[n * 32]; }
     auto body = [&](int kb, int r, bool do_a) {
         if (do_a) {
             const int kl = min(kb + PD, last);
 #pragma unroll
-            for (int m = 0; m < MT; ++m) { ah[(r + PD) % R][m] = wh[m * wstride + kl * 64]; alo[(r + PD) % R][m] = wl[m * wstride + kl * 64]; }
+            for (int m = 0; m < MT; ++m) { ring.ah[(r + PD) % R][m] = wh[m * wstride + kl * 64]; ring.alo[(r + PD) % R][m] = wl[m * wstride + kl * 64]; }
         }
         const int kn = min(kb + 1, last);
-        bh[(r + 1) & 1] = sh[(2 * kn) * TP];
-        bl[(r + 1) & 1] = sl[(2 * kn) * TP];
+#pragma unroll
+        for (int n = 0; n < NT; ++n) { bh[(r + 1) & 1][n] = sh[(2 * kn) * TP + n * 32]; bl[(r + 1) & 1][n] = sl[(2 * kn) * TP + n * 32]; }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int m = 0; m < MT; ++m) am[m] = MFMA16(ah[r % R][m], bh[r & 1], am[m]);
+        for (int m = 0; m < MT; ++m)
 #pragma unroll
-        for (int m = 0; m < MT; ++m) al[m] = MFMA16(ah[r % R][m], bl[r & 1], al[m]);
+            for (int n = 0; n < NT; ++n) am[m][n] = MFMA16(ring.ah[r % R][m], bh[r & 1][n], am[m][n]);
 #pragma unroll
-        for (int m = 0; m < MT; ++m) al[m] = MFMA16(alo[r % R][m], bh[r & 1], al[m]);
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int n = 0; n < NT; ++n) al[m][n] = MFMA16(ring.ah[r % R][m], bl[r & 1][n], al[m][n]);
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int n = 0; n < NT; ++n) al[m][n] = MFMA16(ring.alo[r % R][m], bh[r & 1][n], al[m][n]);
         __builtin_amdgcn_sched_barrier(0);
     };
     int k0 = 0;
@@ -77,53 +95,76 @@ __device__ __forceinline__ void tile_gemm_x3(f32x16 (&am)[MT], f32x16 (&al)[MT],
         if (k0 + r < KB) body(k0 + r, r, r + PD < 2 * R - 1);
 }
 
-// gate partial from registers: contraction over the 64 channels this wave holds (two 16-deep blocks per M-tile)
-template <int MT>
-__device__ __forceinline__ void gate_partial_x3(f32x16& gm, f32x16& gl, const f32x16 (&act)[MT], const h8* __restrict__ wgH,
+// gate partial from registers: contraction over the channels this wave holds (two 16-deep blocks per M-tile)
+template <int MT, int NT>
+__device__ __forceinline__ void gate_partial_x3(f32x16 (&gm)[NT], f32x16 (&gl)[NT], const f32x16 (&act)[MT][NT], const h8* __restrict__ wgH,
                                                 const h8* __restrict__ wgL, int mt0, int lane) {
 #pragma unroll
     for (int m = 0; m < MT; ++m)
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-            h8 bh, bl;
-#pragma unroll
-            for (int s = 0; s < 8; ++s) {
-                _Float16 hi, lo;
-                split16(act[m][8 * j + s], hi, lo);
-                bh[s] = hi;
-                bl[s] = lo;
-            }
             const h8 aH = wgH[((mt0 + m) * 2 + j) * 64 + lane];
             const h8 aL = wgL[((mt0 + m) * 2 + j) * 64 + lane];
-            gm = MFMA16(aH, bh, gm);
-            gl = MFMA16(aH, bl, gl);
-            gl = MFMA16(aL, bh, gl);
+            h8 bh[NT], bl[NT];
+#pragma unroll
+            for (int n = 0; n < NT; ++n)
+#pragma unroll
+                for (int s = 0; s < 8; ++s) {
+                    _Float16 hi, lo;
+                    split16(act[m][n][8 * j + s], hi, lo);
+                    bh[n][s] = hi;
+                    bl[n][s] = lo;
+                }
+#pragma unroll
+            for (int n = 0; n < NT; ++n) gm[n] = MFMA16(aH, bh[n], gm[n]);
+#pragma unroll
+            for (int n = 0; n < NT; ++n) gl[n] = MFMA16(aH, bl[n], gl[n]);
+#pragma unroll
+            for (int n = 0; n < NT; ++n) gl[n] = MFMA16(aL, bh[n], gl[n]);
+        }
+}
+
+// Gate partials of the 8 channel blocks are folded pairwise in two stages (LDS float atomics run at ~1 lane/clk on gfx950):
+// waves 0-3 store their partial into slot w, (barrier), waves 4-7 add theirs onto slot w-4.  Fixed order -> deterministic.
+template <int NT>
+__device__ __forceinline__ void put_gate_partial(float* PG, const f32x16 (&gm)[NT], const f32x16 (&gl)[NT], int TP, int slot, int lane, bool add) {
+    const int half = lane >> 5, l31 = lane & 31;
+#pragma unroll
+    for (int n = 0; n < NT; ++n)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int c = (r & 3) + 8 * (r >> 2) + 4 * half;
+            float* p = &PG[(slot * 32 + c) * TP + 32 * n + l31];
+            const float v = gm[n][r] + gl[n][r] * X3_INV_SCALE;
+            *p = add ? *p + v : v;
         }
 }
 
 // hi / lo' images of the wave's fp32 state -> XH8 / XL8 (8 bytes per lane and group: channels 8q+4*half+{0..3})
-template <int MT>
-__device__ __forceinline__ bool store_state_x3(char* XH, char* XL, int gbase8, const f32x16 (&st)[MT], int TP, int mt0, int lane, int col0) {
+template <int MT, int NT>
+__device__ __forceinline__ bool store_state_x3(char* XH, char* XL, int gbase8, const f32x16 (&st)[MT][NT], int TP, int mt0, int lane) {
     const int half = lane >> 5, l31 = lane & 31;
     bool over = false;
 #pragma unroll
     for (int m = 0; m < MT; ++m)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            h4 vh, vl;
+        for (int n = 0; n < NT; ++n)
 #pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                const float x = st[m][4 * q + t];
-                over |= fabsf(x) > X3_RANGE;
-                _Float16 hi, lo;
-                split16(x, hi, lo);
-                vh[t] = hi;
-                vl[t] = lo;
+            for (int q = 0; q < 4; ++q) {
+                h4 vh, vl;
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const float x = st[m][n][4 * q + t];
+                    over |= fabsf(x) > X3_RANGE;
+                    _Float16 hi, lo;
+                    split16(x, hi, lo);
+                    vh[t] = hi;
+                    vl[t] = lo;
+                }
+                const int off = ((gbase8 + 4 * (mt0 + m) + q) * TP + 32 * n + l31) * 16 + 8 * half;
+                *(h4*)(XH + off) = vh;
+                *(h4*)(XL + off) = vl;
             }
-            const int off = ((gbase8 + 4 * (mt0 + m) + q) * TP + col0 + l31) * 16 + 8 * half;
-            *(h4*)(XH + off) = vh;
-            *(h4*)(XL + off) = vl;
-        }
     return over;
 }
 
@@ -240,6 +281,9 @@ __global__ __launch_bounds__(512) void k_edge_msg_x3(EdgeMsgX3Args ax) {
     const int ni = a.EROW[eid], nj = a.ECOL[eid];
     const uint64_t t_start = a.prof ? __builtin_amdgcn_s_memtime() : 0;
     bool over = false;
+    constexpr int PD = 2;
+    X3Ring<1, PD> ring;
+    x3_prefetch<1, PD>(ring, ax.w0H + (size_t)wave * ax.KB0 * 64, ax.w0L + (size_t)wave * ax.KB0 * 64, ax.KB0, lane);   // flies during P1
 
     if (wave == 0) {
         m_row[e] = ni;
@@ -333,48 +377,50 @@ __global__ __launch_bounds__(512) void k_edge_msg_x3(EdgeMsgX3Args ax) {
     STAMP(2);
 
     const int half = lane >> 5, l31 = lane & 31;
-    const int mt0 = 2 * (wave & 3);
-    const int col0 = 32 * (wave >> 2);
-    f32x16 st[2];        // fp32 message scalars of this wave's 64 channels x 32 edges (lives in registers for the whole tile)
-    f32x16 am[2], al2[2];
-    f32x16 gm, gl;
-    const h8* xh8 = (const h8*)XH + col0;
-    const h8* xl8 = (const h8*)XL + col0;
+    const int mt0 = wave;   // wave w owns M-tile w (32 output channels) for all 64 edges: every weight byte is loaded once per CU
+    f32x16 st[1][2];     // fp32 message scalars of this wave's 32 channels x 64 edges (live in registers for the whole tile)
+    f32x16 am[1][2], al2[1][2];
+    f32x16 gm[2], gl[2];
+    const h8* xh8 = (const h8*)XH;
+    const h8* xl8 = (const h8*)XL;
 
     // ---- P2: msg0 GEMM ----------------------------------------------------------------------------------------------------
     {
-        const int ri = m_row[col0 + l31], cj = m_col[col0 + l31];
 #pragma unroll
-        for (int m = 0; m < 2; ++m)
+        for (int n = 0; n < 2; ++n) {
+            const int ri = m_row[32 * n + l31], cj = m_col[32 * n + l31];
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const int g = 8 * (mt0 + m) + 2 * q + half;
+                const int g = 8 * mt0 + 2 * q + half;
                 const v4f p = a.PQ4[(size_t)g * N + ri];
                 const v4f qq = a.PQ4[(size_t)(64 + g) * N + cj];
 #pragma unroll
-                for (int t = 0; t < 4; ++t) { am[m][4 * q + t] = p[t] + qq[t]; al2[m][4 * q + t] = 0.f; }
+                for (int t = 0; t < 4; ++t) { am[0][n][4 * q + t] = p[t] + qq[t]; al2[0][n][4 * q + t] = 0.f; }
             }
+        }
         STAMP(3);
-        tile_gemm_x3<2>(am, al2, ax.w0H + (size_t)mt0 * ax.KB0 * 64, ax.w0L + (size_t)mt0 * ax.KB0 * 64, ax.KB0, xh8, xl8, ETP, lane);
+        tile_gemm_x3<1, 2, PD>(am, al2, ring, ax.w0H + (size_t)mt0 * ax.KB0 * 64, ax.w0L + (size_t)mt0 * ax.KB0 * 64, ax.KB0, xh8, xl8, ETP, lane);
+        x3_prefetch<1, PD>(ring, ax.wH[0] + (size_t)mt0 * ax.KB * 64, ax.wL[0] + (size_t)mt0 * ax.KB * 64, ax.KB, lane);
         STAMP(4);
 #pragma unroll
-        for (int m = 0; m < 2; ++m)
+        for (int n = 0; n < 2; ++n)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) st[m][r] = fast_silu(am[m][r] + al2[m][r] * X3_INV_SCALE);
+            for (int r = 0; r < 16; ++r) st[0][n][r] = fast_silu(am[0][n][r] + al2[0][n][r] * X3_INV_SCALE);
         STAMP(5);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { gm[r] = 0.f; gl[r] = 0.f; }
-        gate_partial_x3<2>(gm, gl, st, ax.wg0H, ax.wg0L, mt0, lane);
+        for (int n = 0; n < 2; ++n)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) gm[r] += gl[r] * X3_INV_SCALE;
-        f32x16 gtmp[1] = {gm};
-        store_gate_partial<1>(PG, gtmp, ETP, wave & 3, lane, col0);
+            for (int r = 0; r < 16; ++r) { gm[n][r] = 0.f; gl[n][r] = 0.f; }
+        gate_partial_x3<1, 2>(gm, gl, st, ax.wg0H, ax.wg0L, mt0, lane);
+        if (wave < 4) put_gate_partial<2>(PG, gm, gl, ETP, wave, lane, false);
+        __syncthreads();
+        if (wave >= 4) put_gate_partial<2>(PG, gm, gl, ETP, wave - 4, lane, true);
         STAMP(6);
     }
     __syncthreads();
     STAMP(7);
     // ---- P3: state images + vector part of msg0 ---------------------------------------------------------------------------
-    over |= store_state_x3<2>(XH, XL, 0, st, ETP, mt0, lane, col0);
+    over |= store_state_x3<1, 2>(XH, XL, 0, st, ETP, mt0, lane);
     vec_finish<ET, H0, EK_THREADS>(PG, a.bg0, a.wup0, GCDM_V, VH, e, part, [&](int c, float ox, float oy, float oz) {
         VV[(c * 3 + 0) * ETP + e] = ox;
         VV[(c * 3 + 1) * ETP + e] = oy;
@@ -391,42 +437,40 @@ __global__ __launch_bounds__(512) void k_edge_msg_x3(EdgeMsgX3Args ax) {
         if (k == 0) STAMP(10);
         __syncthreads();
         if (k == 0) STAMP(11);
-        {
-            f32x16 bias[2][1];
-            acc_init_bias<2, 1>(bias, w.b, mt0, lane);
+        acc_init_bias<1, 2>(am, w.b, mt0, lane);
 #pragma unroll
-            for (int m = 0; m < 2; ++m)
+        for (int n = 0; n < 2; ++n)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) { am[m][r] = bias[m][0][r]; al2[m][r] = 0.f; }
-        }
-        tile_gemm_x3<2>(am, al2, ax.wH[k] + (size_t)mt0 * ax.KB * 64, ax.wL[k] + (size_t)mt0 * ax.KB * 64, ax.KB, xh8, xl8, ETP, lane);
+            for (int r = 0; r < 16; ++r) al2[0][n][r] = 0.f;
+        if (k == 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); STAMP(21); }
+        tile_gemm_x3<1, 2, PD>(am, al2, ring, ax.wH[k] + (size_t)mt0 * ax.KB * 64, ax.wL[k] + (size_t)mt0 * ax.KB * 64, ax.KB, xh8, xl8, ETP, lane);
+        if (k == 0) STAMP(22);
+        if (k < 2) x3_prefetch<1, PD>(ring, ax.wH[k + 1] + (size_t)mt0 * ax.KB * 64, ax.wL[k + 1] + (size_t)mt0 * ax.KB * 64, ax.KB, lane);
         if (k == 0) STAMP(12);
 #pragma unroll
-        for (int m = 0; m < 2; ++m)
+        for (int n = 0; n < 2; ++n)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) am[m][r] = fast_silu(am[m][r] + al2[m][r] * X3_INV_SCALE);
+            for (int r = 0; r < 16; ++r) am[0][n][r] = fast_silu(am[0][n][r] + al2[0][n][r] * X3_INV_SCALE);
         if (k == 0) STAMP(13);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { gm[r] = 0.f; gl[r] = 0.f; }
-        gate_partial_x3<2>(gm, gl, am, ax.wgH[k], ax.wgL[k], mt0, lane);
+        for (int n = 0; n < 2; ++n)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) gm[r] += gl[r] * X3_INV_SCALE;
-        f32x16 gtmp[1] = {gm};
-        store_gate_partial<1>(PG, gtmp, ETP, wave & 3, lane, col0);
+            for (int r = 0; r < 16; ++r) { gm[n][r] = 0.f; gl[n][r] = 0.f; }
+        gate_partial_x3<1, 2>(gm, gl, am, ax.wgH[k], ax.wgL[k], mt0, lane);
+        if (wave < 4) put_gate_partial<2>(PG, gm, gl, ETP, wave, lane, false);
+        __syncthreads();
+        if (wave >= 4) put_gate_partial<2>(PG, gm, gl, ETP, wave - 4, lane, true);
         if (k == 0) STAMP(14);
         __syncthreads();                 // every wave is done reading the old XH8 / XL8 images
         if (k == 0) STAMP(15);
 #pragma unroll
-        for (int m = 0; m < 2; ++m)
+        for (int n = 0; n < 2; ++n)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) st[m][r] += am[m][r];       // residual add in fp32 (gcpnet.py:701)
+            for (int r = 0; r < 16; ++r) st[0][n][r] += am[0][n][r];       // residual add in fp32 (gcpnet.py:701)
         if (k < 2) {
-            over |= store_state_x3<2>(XH, XL, 0, st, ETP, mt0, lane, col0);
+            over |= store_state_x3<1, 2>(XH, XL, 0, st, ETP, mt0, lane);
         } else {                          // last GCP2: fp32 image for attention + segment sums (aliases XH8 / XL8)
-            f32x16 s2[2][1];
-            s2[0][0] = st[0];
-            s2[1][0] = st[1];
-            store_state<2, 1, false>(XS4, 0, s2, ETP, mt0, lane, col0);
+            store_state<1, 2, false>(XS4, 0, st, ETP, mt0, lane, 0);
         }
         vec_finish<ET, 8, EK_THREADS>(PG, w.bg, w.wup, GCDM_V, VH, e, part, [&](int c, float ox, float oy, float oz) {
             VV[(c * 3 + 0) * ETP + e] += ox;

@@ -49,3 +49,4 @@ prev = 0.0
 for i in range(1, 21):
     print(f"  {i:2d} {names[i]:<18s} delta={mean[i]-prev:10.0f}  cum={mean[i]:10.0f}")
     prev = mean[i]
+print("  extra stamps: 21 (acc init done) = %.0f, 22 (gemm done) = %.0f  -> pure gemm %.0f" % (mean[21], mean[22], mean[22] - mean[21]))
