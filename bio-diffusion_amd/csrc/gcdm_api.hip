@@ -2,6 +2,7 @@
 // fragment layout, batch plan, kernel launches.  gfx950 only; no torch types, no exceptions across the ABI.
 #include "gcdm_kernels.hip.h"
 #include "gcdm_edge_x3.hip.h"
+#include "gcdm_node_x3.hip.h"
 #include "../../include/gcdm_hip.h"
 
 #include <cmath>
@@ -30,6 +31,8 @@ struct LayerDev {
     // split-precision (f16 x3) images of the edge-kernel GEMM weights
     const h8 *w0H, *w0L, *wg0H, *wg0L, *wH[3], *wL[3], *wgH[3], *wgL[3];
     int KB0, KB;
+    GcpX3 ffx, posx;
+    const h8 *wpqH, *wpqL;
 };
 
 }  // namespace
@@ -45,6 +48,7 @@ struct gcdm_handle {
     float* wpool = nullptr;
     std::vector<LayerDev> layers;
     GcpW emb{}, proj{};
+    GcpX3 embx{}, projx{};
     const float *ee_ws = nullptr, *ee_bs = nullptr, *ee_wd = nullptr, *ee_wdf = nullptr, *ee_kappa = nullptr, *ee_wg = nullptr, *ee_bg = nullptr;
     std::vector<float> gamma;
     // plan
@@ -184,6 +188,8 @@ struct GcpOff {
     size_t w = 0, b = 0, w2 = 0, b2 = 0, wdd = 0, wg = 0, bg = 0, wup = 0;
     bool has_w2 = false, has_gate = false;
     int G = 0, H = 0, V_in = 0, V_out = 0;
+    size_t xwH = 0, xwL = 0, xw2H = 0, xw2L = 0, xwgH = 0, xwgL = 0;   // split-precision images
+    int KB = 0;
 };
 
 // generic GCP2 (scalar input = s_in channels laid out in 4-groups starting at K' = 0)
@@ -206,6 +212,19 @@ bool build_gcp(gcdm_handle* h, Pool& pool, const std::string& pre, int s_in, int
     o.w = pool.add(pack_mfma(W));
     o.b = pool.add(padded(bs, Mp));
     o.G = Kp / 8; o.H = H; o.V_in = v_in; o.V_out = v_out;
+    {   // split-precision image: K' = [s_in -> 8-groups | n (H -> 8-groups) | q (9 -> 16)] padded to a multiple of 16
+        const int S8 = (s_in + 7) / 8, H8 = (H + 7) / 8;
+        const int Kx = round_up(8 * (S8 + H8 + 2), 16);
+        Dense Wx(Mp, Kx);
+        for (int m = 0; m < s_out; ++m) {
+            for (int k = 0; k < s_in; ++k) Wx.at(m, k) = ws.at(m, k);
+            for (int k = 0; k < H; ++k) Wx.at(m, 8 * S8 + k) = ws.at(m, s_in + k);
+            for (int k = 0; k < 9; ++k) Wx.at(m, 8 * (S8 + H8) + k) = ws.at(m, s_in + H + k);
+        }
+        std::vector<float> xh, xl;
+        pack_x3(Wx, xh, xl);
+        o.xwH = pool.add(xh); o.xwL = pool.add(xl); o.KB = Kx / 16;
+    }
     std::vector<float> dd((size_t)(H + 3) * v_in);
     for (int r = 0; r < H; ++r) for (int c = 0; c < v_in; ++c) dd[(size_t)r * v_in + c] = wd.at(r, c);
     for (int r = 0; r < 3; ++r) for (int c = 0; c < v_in; ++c) dd[(size_t)(H + r) * v_in + c] = wdf.at(r, c);
@@ -218,6 +237,9 @@ bool build_gcp(gcdm_handle* h, Pool& pool, const std::string& pre, int s_in, int
         o.w2 = pool.add(pack_mfma(W2));
         o.b2 = pool.add(padded(b2, s_out));
         o.has_w2 = true;
+        std::vector<float> xh, xl;
+        pack_x3(W2, xh, xl);
+        o.xw2H = pool.add(xh); o.xw2L = pool.add(xl);
     }
     if (v_out) {
         WView wg, bg, wu;
@@ -230,6 +252,11 @@ bool build_gcp(gcdm_handle* h, Pool& pool, const std::string& pre, int s_in, int
         o.bg = pool.add(padded(bg, 32));
         o.wup = pool.add(padded(wu, v_out * H));
         o.has_gate = true;
+        if (s_out == 256) {
+            std::vector<float> xh, xl;
+            pack_gate_x3(Wg, xh, xl);
+            o.xwgH = pool.add(xh); o.xwgL = pool.add(xl);
+        }
     }
     return true;
 }
@@ -248,12 +275,21 @@ GcpW resolve(const GcpOff& o, const float* base) {
     return g;
 }
 
+GcpX3 resolve_x3(const GcpOff& o, const float* base) {
+    GcpX3 g{};
+    g.wH = (const h8*)(base + o.xwH); g.wL = (const h8*)(base + o.xwL); g.KB = o.KB;
+    g.w2H = o.has_w2 ? (const h8*)(base + o.xw2H) : nullptr; g.w2L = o.has_w2 ? (const h8*)(base + o.xw2L) : nullptr;
+    g.wgH = o.has_gate ? (const h8*)(base + o.xwgH) : nullptr; g.wgL = o.has_gate ? (const h8*)(base + o.xwgL) : nullptr;
+    return g;
+}
+
 struct LayerOff {
     size_t w0, wddE, wg0, bg0, wup0, wa, wpq, bpq, wddI, wddJ;
     int G0;
     float ba;
     GcpOff mk[3], ff, pos;
     size_t w0H, w0L, wg0H, wg0L, wH[3], wL[3], wgH[3], wgL[3];
+    size_t wpqH, wpqL;
     int KB0, KB;
 };
 
@@ -396,6 +432,11 @@ int gcdm_finalize_weights(gcdm_handle* h) {
                 }
             o.wpq = pool.add(pack_mfma(PQ));
             o.bpq = pool.add(padded(bs, 2 * S));
+            {
+                std::vector<float> xh, xl;
+                pack_x3(PQ, xh, xl);
+                o.wpqH = pool.add(xh); o.wpqL = pool.add(xl);
+            }
             std::vector<float> dI((size_t)(H0 + 3) * V), dJ((size_t)(H0 + 3) * V), dE((size_t)(H0 + 3) * Ve);
             for (int r = 0; r < H0 + 3; ++r) {
                 const WView& src = r < H0 ? wd : wdf;
@@ -464,6 +505,8 @@ int gcdm_finalize_weights(gcdm_handle* h) {
     h->ee_kappa = base + o_kap; h->ee_wg = base + o_wg; h->ee_bg = base + o_bg;
     h->emb = resolve(emb, base);
     h->proj = resolve(proj, base);
+    h->embx = resolve_x3(emb, base);
+    h->projx = resolve_x3(proj, base);
     h->layers.resize(L);
     for (int l = 0; l < L; ++l) {
         const LayerOff& o = lo[l];
@@ -475,6 +518,8 @@ int gcdm_finalize_weights(gcdm_handle* h) {
         d.ff = resolve(o.ff, base); d.pos = resolve(o.pos, base);
         d.wpq = (const v4f*)(base + o.wpq); d.bpq = base + o.bpq; d.wddI = base + o.wddI; d.wddJ = base + o.wddJ;
         d.w0H = (const h8*)(base + o.w0H); d.w0L = (const h8*)(base + o.w0L); d.KB0 = o.KB0; d.KB = o.KB;
+        d.ffx = resolve_x3(o.ff, base); d.posx = resolve_x3(o.pos, base);
+        d.wpqH = (const h8*)(base + o.wpqH); d.wpqL = (const h8*)(base + o.wpqL);
         d.wg0H = (const h8*)(base + o.wg0H); d.wg0L = (const h8*)(base + o.wg0L);
         for (int k = 0; k < 3; ++k) {
             d.wH[k] = (const h8*)(base + o.wH[k]); d.wL[k] = (const h8*)(base + o.wL[k]);
@@ -485,6 +530,7 @@ int gcdm_finalize_weights(gcdm_handle* h) {
         if (set_lds_attr(h, k_edge_msg<64, 16, 64>, EdgeGeo<64>::LDS_BYTES) || set_lds_attr(h, k_edge_msg<16, 8, 64>, EdgeGeo<64>::LDS_BYTES) ||
             set_lds_attr(h, k_edge_msg<64, 16, 32>, EdgeGeo<32>::LDS_BYTES) || set_lds_attr(h, k_edge_msg<16, 8, 32>, EdgeGeo<32>::LDS_BYTES) ||
             set_lds_attr(h, k_edge_msg_x3<64, 16>, EdgeGeo<64>::LDS_BYTES) || set_lds_attr(h, k_edge_msg_x3<16, 8>, EdgeGeo<64>::LDS_BYTES) ||
+            set_lds_attr(h, k_node_x3<true>, NK_LDS_BYTES) || set_lds_attr(h, k_node_x3<false>, NK_LDS_BYTES) ||
             set_lds_attr(h, k_node<true>, NK_LDS_BYTES) || set_lds_attr(h, k_node<false>, NK_LDS_BYTES))
             return -1;
         h->attr_set = true;
@@ -590,8 +636,22 @@ int gcdm_forward(gcdm_handle* h, const float* xh, const float* t, const float* c
         }
     };
     const int ngrid = (N + NT_ - 1) / NT_;
+    NodeX3Args nx{};
+    auto launch_node = [&](bool embed, int next_layer, const LayerDev* cur) {
+        if (h->mfma_x3) {
+            nx.base = na;
+            nx.emb = h->embx; nx.proj = h->projx;
+            if (cur) { nx.ff = cur->ffx; nx.pos = cur->posx; }
+            if (next_layer < h->L) { nx.wpqH = h->layers[next_layer].wpqH; nx.wpqL = h->layers[next_layer].wpqL; }
+            if (embed) hipLaunchKernelGGL(k_node_x3<true>, dim3(ngrid), dim3(NX_THREADS), NK_LDS_BYTES, st, nx);
+            else hipLaunchKernelGGL(k_node_x3<false>, dim3(ngrid), dim3(NX_THREADS), NK_LDS_BYTES, st, nx);
+        } else {
+            if (embed) hipLaunchKernelGGL(k_node<true>, dim3(ngrid), dim3(256), NK_LDS_BYTES, st, na);
+            else hipLaunchKernelGGL(k_node<false>, dim3(ngrid), dim3(256), NK_LDS_BYTES, st, na);
+        }
+    };
     set_next(0);
-    hipLaunchKernelGGL(k_node<true>, dim3(ngrid), dim3(256), NK_LDS_BYTES, st, na);
+    launch_node(true, 0, nullptr);
     const int ET = h->edge_tile;
     const int tiles = (E + ET - 1) / ET;
     for (int l = 0; l < L; ++l) {
@@ -624,7 +684,7 @@ int gcdm_forward(gcdm_handle* h, const float* xh, const float* t, const float* c
         if (h->profile) { HIP_OK(h, hipEventRecord(h->ev[2 * l + 1], st)); h->ev_used = l + 1; }
         na.ff = d.ff; na.pos = d.pos;
         set_next(l + 1);   // next layer's msg0 halves, or the output projection after the last layer
-        hipLaunchKernelGGL(k_node<false>, dim3(ngrid), dim3(256), NK_LDS_BYTES, st, na);
+        launch_node(false, l + 1, &d);
     }
     if (!truncated) {
         FinishArgs fa{h->VEL, h->d_noff, N, h->D, out, h->d_flags, flags};

@@ -1,0 +1,334 @@
+// gcdm_node_x3.hip.h -- split-precision (f16 x3) variant of the node kernels (gfx950).
+//
+// Same work as k_node (gcdm_kernels.hip.h): node embedding, or feed-forward GCP2 + residual + position update, followed by the
+// node-level halves of the next layer's msg0 or the output projection -- with the dense contractions on v_mfma_f32_32x32x16_f16 and
+// operands split as x = hi + 2^-11 lo' (see gcdm_edge_x3.hip.h).  One workgroup = 32 nodes, 512 threads: wave w owns M-tile w
+// (32 output channels); the fp32 node scalars h of those channels stay in its registers, LDS holds the hi / lo' images.
+#pragma once
+#include "gcdm_edge_x3.hip.h"
+
+struct GcpX3 {
+    const h8 *wH, *wL; int KB;     // scalar_out (first Linear) packed [M'/32][KB][64]
+    const h8 *w2H, *w2L;           // feed-forward second Linear packed [8][16][64] (or null)
+    const h8 *wgH, *wgL;           // vector gate packed [8][2][64] (or null)
+};
+
+struct NodeX3Args {
+    NodeArgs base;
+    GcpX3 emb, ff, pos, proj;
+    const h8 *wpqH, *wpqL;         // next layer's msg0 node halves, packed [16][16][64]
+};
+
+// generic GCP2 pre-phase writing the extended-K rows as hi / lo' images (rows of [W_down; W_frames] split over the PARTS threads of an entity)
+template <int T, int H, int V_IN, int NTHR>
+__device__ __forceinline__ bool gcp2_pre_x3g(const float* __restrict__ wdd, const float* VV, int vch0, const float* FR, char* XH, char* XL,
+                                             int gN8, int gQ8, int gEnd8, float* VH, int e, int part) {
+    constexpr int TP = T + 1, PARTS = NTHR / T, ROWS = H + 3, NH = (ROWS + PARTS - 1) / PARTS;
+    float ax[NH], ay[NH], az[NH];
+    const float* wrow[NH];
+#pragma unroll
+    for (int i = 0; i < NH; ++i) {
+        ax[i] = ay[i] = az[i] = 0.f;
+        const int hh = part + PARTS * i;
+        wrow[i] = wdd + (hh < ROWS ? hh : ROWS - 1) * V_IN;
+    }
+    const float* vp = VV + (vch0 * 3) * TP + e;
+#pragma unroll 8
+    for (int c = 0; c < V_IN; ++c) {
+        const float vx = vp[0], vy = vp[TP], vz = vp[2 * TP];
+        vp += 3 * TP;
+#pragma unroll
+        for (int i = 0; i < NH; ++i) {
+            const float wc = wrow[i][c];
+            ax[i] += wc * vx; ay[i] += wc * vy; az[i] += wc * vz;
+        }
+    }
+    float f[9];
+#pragma unroll
+    for (int r = 0; r < 9; ++r) f[r] = FR[r * TP + e];
+    bool over = false;
+#pragma unroll
+    for (int i = 0; i < NH; ++i) {
+        const int hh = part + PARTS * i;
+        const float vx = ax[i], vy = ay[i], vz = az[i];
+        if (hh < H) {
+            over |= put16(XH, XL, TP, gN8 + (hh >> 3), hh & 7, e, sqrtf(vx * vx + vy * vy + vz * vz + 1e-8f) + 1e-8f);
+            VH[(hh * 3 + 0) * TP + e] = vx;
+            VH[(hh * 3 + 1) * TP + e] = vy;
+            VH[(hh * 3 + 2) * TP + e] = vz;
+        } else if (hh < ROWS) {
+            const int k = hh - H;
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+                const int idx = 3 * k + r;
+                over |= put16(XH, XL, TP, gQ8 + (idx >> 3), idx & 7, e, f[3 * r] * vx + f[3 * r + 1] * vy + f[3 * r + 2] * vz);
+            }
+        }
+    }
+    if (part == PARTS - 1) {
+        for (int hh = H; hh < 8 * (gQ8 - gN8); ++hh) put16(XH, XL, TP, gN8 + (hh >> 3), hh & 7, e, 0.f);
+        for (int idx = 9; idx < 16; ++idx) put16(XH, XL, TP, gQ8 + (idx >> 3), idx & 7, e, 0.f);
+        for (int g = gQ8 + 2; g < gEnd8; ++g) {
+            *(v4f*)(XH + (g * TP + e) * 16) = (v4f){0.f, 0.f, 0.f, 0.f};
+            *(v4f*)(XL + (g * TP + e) * 16) = (v4f){0.f, 0.f, 0.f, 0.f};
+        }
+    }
+    return over;
+}
+
+// hi / lo' images of a C-layout register block (one M-tile, one N-tile) -> 8-groups gbase8 .. gbase8+3
+__device__ __forceinline__ bool store_block_x3(char* XH, char* XL, int gbase8, const f32x16& v, int TP, int lane) {
+    f32x16 t[1][1] = {{v}};
+    return store_state_x3<1, 1>(XH, XL, gbase8, t, TP, 0, lane);
+}
+
+constexpr int NX_GROUPS8 = 70;
+constexpr int NX_THREADS = 512;
+static_assert(2 * NX_GROUPS8 * NTP * 16 == NK_XS_GROUPS * NTP * 16, "XH8/XL8 must exactly fill the fp32 XS4 region of k_node");
+
+template <bool EMBED>
+__global__ __launch_bounds__(NX_THREADS) void k_node_x3(NodeX3Args ax) {
+    const NodeArgs& a = ax.base;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* XH = smem + NK_OFF_XS;
+    char* XL = XH + NX_GROUPS8 * NTP * 16;
+    float* VV = (float*)(smem + NK_OFF_VV);
+    float* VH = (float*)(smem + NK_OFF_VH);
+    float* PG = (float*)(smem + NK_OFF_PG);
+    float* FR = (float*)(smem + NK_OFF_FR);
+    float* XP = (float*)(smem + NK_OFF_XP);
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int e = tid & 31, part = tid >> 5;       // 16 threads share an entity in the VALU phases
+    constexpr int PARTS = NX_THREADS / NT_;
+    const int half = lane >> 5, l31 = lane & 31;
+    const int N = a.N;
+    const int n0 = blockIdx.x * NT_;
+    const int nid = min(n0 + e, N - 1);
+    const bool valid = (n0 + e) < N;
+    const int nidl = min(n0 + l31, N - 1);           // node of this lane in the MFMA (C-layout) phases
+    const bool validl = (n0 + l31) < N;
+    constexpr int HB8 = 32;   // 8-group base of h inside XH8/XL8 (LAYER: groups 0..31 hold agg.s, then the ff hidden activations)
+    constexpr int CB = 32;    // channel base of chi inside VV
+    constexpr int PD = 2;
+    bool over = false;
+
+    for (int r = part; r < 9; r += PARTS) FR[r * NTP + e] = a.FBAR[(size_t)r * N + nid];
+    if (part < 3) XP[part * NTP + e] = a.XC[(size_t)part * N + nid];
+
+    f32x16 hst;                  // fp32 master of h: channels 32*wave .. +31 of the 32 nodes (C layout)
+    f32x16 am[1][1], al[1][1];
+    f32x16 gm[1], gl[1];
+    X3Ring<1, PD> ring;
+    const h8* xh8 = (const h8*)XH;
+    const h8* xl8 = (const h8*)XL;
+
+    auto gemm = [&](const h8* wH, const h8* wL, int KB, int g8base) {
+        const h8* wh = wH + (size_t)wave * KB * 64;
+        const h8* wl = wL + (size_t)wave * KB * 64;
+        x3_prefetch<1, PD>(ring, wh, wl, KB, lane);
+        tile_gemm_x3<1, 1, PD>(am, al, ring, wh, wl, KB, xh8 + g8base * NTP, xl8 + g8base * NTP, NTP, lane);
+    };
+    auto acc_bias = [&](const float* b) {
+        acc_init_bias<1, 1>(am, b, wave, lane);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) al[0][0][r] = 0.f;
+    };
+    auto fold_gate = [&](const h8* wgH, const h8* wgL, const f32x16 (&act)[1][1]) {   // two-stage fold of the 8 gate partials
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { gm[0][r] = 0.f; gl[0][r] = 0.f; }
+        gate_partial_x3<1, 1>(gm, gl, act, wgH, wgL, wave, lane);
+        if (wave < 4) put_gate_partial<1>(PG, gm, gl, NTP, wave, lane, false);
+        __syncthreads();
+        if (wave >= 4) put_gate_partial<1>(PG, gm, gl, NTP, wave - 4, lane, true);
+    };
+
+    if (EMBED) {
+        // h_in (fp32 float4 groups in HBM) -> images; zero the unused half of the last 8-group
+        const int G8in = (a.FinG + 1) >> 1;
+        for (int g = part; g < 2 * G8in; g += PARTS) {
+            const v4f v = g < a.FinG ? a.HIN4[(size_t)g * N + nid] : (v4f){0.f, 0.f, 0.f, 0.f};
+            h4 vh, vl;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                _Float16 hi, lo;
+                split16(v[t], hi, lo);
+                vh[t] = hi; vl[t] = lo;
+                over |= fabsf(v[t]) > X3_RANGE;
+            }
+            const int off = ((g >> 1) * NTP + e) * 16 + 8 * (g & 1);
+            *(h4*)(XH + off) = vh;
+            *(h4*)(XL + off) = vl;
+        }
+        if (part < 6) VV[part * NTP + e] = a.CHI0[(size_t)part * N + nid];
+        __syncthreads();
+        const GcpW& w = a.emb;
+        over |= gcp2_pre_x3g<NT_, 32, 2, NX_THREADS>(w.wdd, VV, 0, FR, XH, XL, G8in, G8in + 4, 2 * ax.emb.KB, VH, e, part);
+        __syncthreads();
+        acc_bias(w.b);
+        gemm(ax.emb.wH, ax.emb.wL, ax.emb.KB, 0);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) am[0][0][r] += al[0][0][r] * X3_INV_SCALE;     // nonlinearities (None, None): h = p
+        hst = am[0][0];
+        fold_gate(ax.emb.wgH, ax.emb.wgL, am);
+        __syncthreads();
+        over |= store_block_x3(XH, XL, HB8 + 4 * wave, hst, NTP, lane);
+        vec_finish<NT_, 32, NX_THREADS>(PG, w.bg, w.wup, GCDM_V, VH, e, part, [&](int c, float ox, float oy, float oz) {
+            VV[((CB + c) * 3 + 0) * NTP + e] = ox;
+            VV[((CB + c) * 3 + 1) * NTP + e] = oy;
+            VV[((CB + c) * 3 + 2) * NTP + e] = oz;
+        });
+        __syncthreads();
+    } else {
+        // agg.s -> images (8-groups 0..31), agg.v -> VV channels 0..31, h -> registers + images (8-groups 32..63), chi -> VV channels 32..63
+        {
+            const float* src = a.AGG + (size_t)nidl * GCDM_AGGW + 32 * wave + 4 * half;
+            f32x16 t;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const v4f v = *(const v4f*)(src + 8 * q);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) t[4 * q + k] = v[k];
+            }
+            over |= store_block_x3(XH, XL, 4 * wave, t, NTP, lane);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const v4f v = a.H4[(size_t)(8 * wave + 2 * q + half) * N + nidl];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) hst[4 * q + k] = v[k];
+            }
+            over |= store_block_x3(XH, XL, HB8 + 4 * wave, hst, NTP, lane);
+        }
+        for (int x = wave; x < NT_; x += 8) {
+            const int nd = min(n0 + x, N - 1);
+            const float* src = a.AGG + (size_t)nd * GCDM_AGGW + GCDM_S;
+            VV[lane * NTP + x] = src[lane];
+            if (lane < 32) VV[(64 + lane) * NTP + x] = src[64 + lane];
+        }
+        for (int r = part; r < 96; r += PARTS) VV[(CB * 3 + r) * NTP + e] = a.CHI[(size_t)r * N + nid];
+        __syncthreads();
+        // ---- feed-forward GCP2 ------------------------------------------------------------------------------------------------
+        {
+            const GcpW& w = a.ff;
+            over |= gcp2_pre_x3g<NT_, 16, 2 * GCDM_V, NX_THREADS>(w.wdd, VV, 0, FR, XH, XL, 64, 66, 2 * ax.ff.KB, VH, e, part);
+            __syncthreads();
+            acc_bias(w.b);
+            gemm(ax.ff.wH, ax.ff.wL, ax.ff.KB, 0);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) am[0][0][r] = fast_silu(am[0][0][r] + al[0][0][r] * X3_INV_SCALE);
+            __syncthreads();                                      // every wave is done reading agg.s (8-groups 0..31)
+            over |= store_block_x3(XH, XL, 4 * wave, am[0][0], NTP, lane);   // hidden activations of Linear-SiLU-Linear
+            __syncthreads();
+            acc_bias(w.b2);
+            gemm(ax.ff.w2H, ax.ff.w2L, 16, 0);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) am[0][0][r] += al[0][0][r] * X3_INV_SCALE;   // nonlinearities (None, None)
+            fold_gate(ax.ff.wgH, ax.ff.wgL, am);
+            __syncthreads();
+#pragma unroll
+            for (int r = 0; r < 16; ++r) hst[r] += am[0][0][r];     // h <- h + ff.s (gcpnet.py:907), fp32
+            over |= store_block_x3(XH, XL, HB8 + 4 * wave, hst, NTP, lane);
+            vec_finish<NT_, 16, NX_THREADS>(PG, w.bg, w.wup, GCDM_V, VH, e, part, [&](int c, float ox, float oy, float oz) {
+                VV[((CB + c) * 3 + 0) * NTP + e] += ox;
+                VV[((CB + c) * 3 + 1) * NTP + e] += oy;
+                VV[((CB + c) * 3 + 2) * NTP + e] += oz;
+            });
+            __syncthreads();
+        }
+        // ---- position update GCP2 -------------------------------------------------------------------------------------------------
+        {
+            const GcpW& w = a.pos;
+            over |= gcp2_pre_x3g<NT_, 8, GCDM_V, NX_THREADS>(w.wdd, VV, CB, FR, XH, XL, 64, 65, HB8 + 2 * ax.pos.KB, VH, e, part);
+            __syncthreads();
+            acc_bias(w.b);
+            gemm(ax.pos.wH, ax.pos.wL, ax.pos.KB, HB8);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) am[0][0][r] = fast_silu(am[0][0][r] + al[0][0][r] * X3_INV_SCALE);
+            fold_gate(ax.pos.wgH, ax.pos.wgL, am);
+            __syncthreads();
+            vec_finish<NT_, 8, NX_THREADS>(PG, w.bg, w.wup, 1, VH, e, part, [&](int c, float ox, float oy, float oz) {
+                XP[0 * NTP + e] += ox * a.pos_weight;
+                XP[1 * NTP + e] += oy * a.pos_weight;
+                XP[2 * NTP + e] += oz * a.pos_weight;
+            });
+            __syncthreads();
+            if (part < 3 && valid) a.XC[(size_t)part * N + nid] = XP[part * NTP + e];
+        }
+    }
+    // ---- write the node state back (h from the register master, chi from LDS) ----------------------------------------------------
+    if (validl) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            a.H4[(size_t)(8 * wave + 2 * q + half) * N + n0 + l31] = (v4f){hst[4 * q], hst[4 * q + 1], hst[4 * q + 2], hst[4 * q + 3]};
+    }
+    if (valid) {
+        for (int r = part; r < 96; r += PARTS) a.CHI[(size_t)r * N + nid] = VV[(CB * 3 + r) * NTP + e];
+    }
+
+    if (a.has_next) {
+        // ---- node-level halves of the next layer's msg0: wave w computes M-tiles w (P half) and w + 8 (Q half) --------------------
+        X3Ring<1, PD> r2;
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            const int mt = wave + 8 * m;
+            acc_init_bias<1, 1>(am, a.bpq, mt, lane);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) al[0][0][r] = 0.f;
+            const h8* wh = ax.wpqH + (size_t)mt * 16 * 64;
+            const h8* wl = ax.wpqL + (size_t)mt * 16 * 64;
+            x3_prefetch<1, PD>(r2, wh, wl, 16, lane);
+            tile_gemm_x3<1, 1, PD>(am, al, r2, wh, wl, 16, xh8 + HB8 * NTP, xl8 + HB8 * NTP, NTP, lane);
+            if (validl) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int g = 8 * mt + 2 * q + half;
+                    v4f o;
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) o[t] = am[0][0][4 * q + t] + al[0][0][4 * q + t] * X3_INV_SCALE;
+                    a.PQ4[(size_t)g * N + n0 + l31] = o;
+                }
+            }
+        }
+        if (valid) {
+            const int rows = a.H0 + 3;
+            for (int it = part; it < 2 * rows; it += PARTS) {
+                const int side = it >= rows, hh = side ? it - rows : it;
+                const float* w = (side ? a.wddJ : a.wddI) + hh * GCDM_V;
+                const float* vp = VV + (CB * 3) * NTP + e;
+                float vx = 0.f, vy = 0.f, vz = 0.f;
+#pragma unroll 8
+                for (int c = 0; c < GCDM_V; ++c) {
+                    const float wc = w[c];
+                    vx += wc * vp[0]; vy += wc * vp[NTP]; vz += wc * vp[2 * NTP];
+                    vp += 3 * NTP;
+                }
+                float* dst = (side ? a.VDJ : a.VDI) + (size_t)(hh * 3) * N + nid;
+                dst[0] = vx; dst[N] = vy; dst[2 * (size_t)N] = vz;
+            }
+        }
+    } else {
+        // ---- scalar projection GCP2 (S, V) -> (F+1+C, 0), bottleneck 1, no activation (gcpnet.py:1191-1197) -----------------------
+        const GcpW& w = a.proj;
+        over |= gcp2_pre_x3g<NT_, 32, GCDM_V, NX_THREADS>(w.wdd, VV, CB, FR, XH, XL, 64, 68, HB8 + 2 * ax.proj.KB, VH, e, part);
+        __syncthreads();
+        if (wave == 0) {
+            acc_bias(w.b);
+            gemm(ax.proj.wH, ax.proj.wL, ax.proj.KB, HB8);
+            if (validl) {
+                float* dst = a.OUT + (size_t)(n0 + l31) * a.Dout + 3;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int c = (r & 3) + 8 * (r >> 2) + 4 * half;
+                    if (c < a.F) dst[c] = am[0][0][r] + al[0][0][r] * X3_INV_SCALE;
+                }
+            }
+        }
+        if (part < 3 && valid) {
+            const float v = XP[part * NTP + e] - a.X0[(size_t)part * N + nid];
+            a.VEL[(size_t)part * N + nid] = v;
+            if (v != v) atomicOr(a.flags_dev, 1u);
+        }
+    }
+    if (__any(over) && lane == 0) atomicOr(a.flags_dev, GCDM_FLAG_F16_RANGE_BIT);
+}
