@@ -36,14 +36,17 @@ struct X3Ring {
     h8 ah[PD + 1][MT], alo[PD + 1][MT];
 };
 
+// NOTE: the prefetches run PD k-blocks (A) / one k-block (B) past the end of the contraction without clamping: the packed weight
+// arrays carry X3_TAIL_BLOCKS zero blocks of padding behind the last M-tile, and the LDS reads stay inside the XH8|XL8|VV allocation.
+#define X3_TAIL_BLOCKS 4
+
 template <int MT, int PD>
 __device__ __forceinline__ void x3_prefetch(X3Ring<MT, PD>& ring, const h8* __restrict__ wH, const h8* __restrict__ wL, int KB, int lane) {
-    const int wstride = KB * 64, last = KB - 1;
+    const int wstride = KB * 64;
 #pragma unroll
     for (int r = 0; r < PD; ++r) {
-        const int kl = min(r, last);
 #pragma unroll
-        for (int m = 0; m < MT; ++m) { ring.ah[r][m] = wH[m * wstride + kl * 64 + lane]; ring.alo[r][m] = wL[m * wstride + kl * 64 + lane]; }
+        for (int m = 0; m < MT; ++m) { ring.ah[r][m] = wH[m * wstride + r * 64 + lane]; ring.alo[r][m] = wL[m * wstride + r * 64 + lane]; }
     }
 }
 
@@ -51,25 +54,24 @@ template <int MT, int NT, int PD>
 __device__ __forceinline__ void tile_gemm_x3(f32x16 (&am)[MT][NT], f32x16 (&al)[MT][NT], X3Ring<MT, PD>& ring, const h8* __restrict__ wH,
                                              const h8* __restrict__ wL, int KB, const h8* xh8, const h8* xl8, int TP, int lane) {
     constexpr int R = PD + 1;
-    const h8* wh = wH + lane;
-    const h8* wl = wL + lane;
+    const int wstride = KB * 64;
+    const h8* wh = wH + lane + PD * 64;          // running pointers: one add per k-block, no clamping
+    const h8* wl = wL + lane + PD * 64;
     const int boff = (lane >> 5) * TP + (lane & 31);
     const h8* sh = xh8 + boff;
     const h8* sl = xl8 + boff;
-    const int wstride = KB * 64;
-    const int last = KB - 1;
     h8 bh[2][NT], bl[2][NT];
 #pragma unroll
     for (int n = 0; n < NT; ++n) { bh[0][n] = sh[n * 32]; bl[0][n] = sl[n * 32]; }
-    auto body = [&](int kb, int r, bool do_a) {
-        if (do_a) {
-            const int kl = min(kb + PD, last);
+    auto body = [&](int r) {
 #pragma unroll
-            for (int m = 0; m < MT; ++m) { ring.ah[(r + PD) % R][m] = wh[m * wstride + kl * 64]; ring.alo[(r + PD) % R][m] = wl[m * wstride + kl * 64]; }
-        }
-        const int kn = min(kb + 1, last);
+        for (int m = 0; m < MT; ++m) { ring.ah[(r + PD) % R][m] = wh[m * wstride]; ring.alo[(r + PD) % R][m] = wl[m * wstride]; }
+        wh += 64;
+        wl += 64;
+        sh += 2 * TP;
+        sl += 2 * TP;
 #pragma unroll
-        for (int n = 0; n < NT; ++n) { bh[(r + 1) & 1][n] = sh[(2 * kn) * TP + n * 32]; bl[(r + 1) & 1][n] = sl[(2 * kn) * TP + n * 32]; }
+        for (int n = 0; n < NT; ++n) { bh[(r + 1) & 1][n] = sh[n * 32]; bl[(r + 1) & 1][n] = sl[n * 32]; }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int m = 0; m < MT; ++m)
@@ -88,11 +90,11 @@ __device__ __forceinline__ void tile_gemm_x3(f32x16 (&am)[MT][NT], f32x16 (&al)[
     int k0 = 0;
     for (; k0 + 2 * R <= KB; k0 += 2 * R) {
 #pragma unroll
-        for (int r = 0; r < 2 * R; ++r) body(k0 + r, r, true);
+        for (int r = 0; r < 2 * R; ++r) body(r);
     }
 #pragma unroll
     for (int r = 0; r < 2 * R - 1; ++r)
-        if (k0 + r < KB) body(k0 + r, r, r + PD < 2 * R - 1);
+        if (k0 + r < KB) body(r);
 }
 
 // gate partial from registers: contraction over the channels this wave holds (two 16-deep blocks per M-tile)
