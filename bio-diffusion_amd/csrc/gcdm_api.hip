@@ -3,7 +3,6 @@
 #include "gcdm_kernels.hip.h"
 #include "gcdm_edge_x3.hip.h"
 #include "gcdm_node_x3.hip.h"
-#include "gcdm_edge_x3v.hip.h"
 #include "../../include/gcdm_hip.h"
 
 #include <cmath>
@@ -34,7 +33,6 @@ struct LayerDev {
     int KB0, KB;
     GcpX3 ffx, posx;
     const h8 *wpqH, *wpqL;
-    const h8 *wup0H, *wup0L, *wddH[3], *wddL[3], *wupH[3], *wupL[3];
 };
 
 }  // namespace
@@ -64,7 +62,6 @@ struct gcdm_handle {
     uint32_t* d_flags = nullptr;
     int layer_limit = -1;
     int edge_tile = 64;              // 64: one 8-wave workgroup per CU; 32: two 4-wave workgroups per CU (env GCDM_EDGE_TILE)
-    int vec_mfma = 0;                // 1: vector pre/finish contractions on the matrix pipe too (k_edge_msg_x3v; measured 36% SLOWER, experiment only; env GCDM_VEC=mfma enables)
     int mfma_x3 = 1;                 // 1: split-precision f16 x3 edge kernel (default; env GCDM_MFMA=f16x3|f32), 0: fp32 MFMA
     bool attr_set = false;
     // profiling (HIP events around the k_edge_msg launches of one forward)
@@ -293,7 +290,6 @@ struct LayerOff {
     GcpOff mk[3], ff, pos;
     size_t w0H, w0L, wg0H, wg0L, wH[3], wL[3], wgH[3], wgL[3];
     size_t wpqH, wpqL;
-    size_t wup0H, wup0L, wddH[3], wddL[3], wupH[3], wupL[3];
     int KB0, KB;
 };
 
@@ -344,7 +340,6 @@ int gcdm_create(const GcdmConfig* cfg, gcdm_handle** out) {
     if (const char* et = getenv("GCDM_EDGE_TILE")) h->edge_tile = (atoi(et) == 32) ? 32 : 64;
     if (const char* mm = getenv("GCDM_MFMA")) h->mfma_x3 = (std::strcmp(mm, "f16x3") == 0) ? 1 : 0;
     if (h->mfma_x3) h->edge_tile = 64;
-    if (const char* vm = getenv("GCDM_VEC")) h->vec_mfma = (std::strcmp(vm, "mfma") == 0) ? 1 : 0;
     HIP_OK(h, hipSetDevice(cfg->device));
     HIP_OK(h, hipMalloc(&h->d_flags, sizeof(uint32_t)));
     HIP_OK(h, hipMemset(h->d_flags, 0, sizeof(uint32_t)));
@@ -470,10 +465,6 @@ int gcdm_finalize_weights(gcdm_handle* h) {
             o.w0H = pool.add(xh); o.w0L = pool.add(xl); o.KB0 = Kx / 16;
             pack_gate_x3(Wg, xh, xl);
             o.wg0H = pool.add(xh); o.wg0L = pool.add(xl);
-            Dense Wu0(32, 32);                                   // vector_up of msg0: k-slots = hidden channels (H0 -> 32)
-            for (int c = 0; c < V; ++c) for (int hh = 0; hh < H0; ++hh) Wu0.at(c, hh) = wu.at(c, hh);
-            pack_x3(Wu0, xh, xl);
-            o.wup0H = pool.add(xh); o.wup0L = pool.add(xl);
         }
         for (int k = 1; k <= 3; ++k) {
             const std::string p = lp + "interaction.message_fusion." + std::to_string(k) + ".";
@@ -493,18 +484,6 @@ int gcdm_finalize_weights(gcdm_handle* h) {
             for (int m = 0; m < V; ++m) for (int kk = 0; kk < S; ++kk) Wgd.at(m, kk) = wg.at(m, kk);
             pack_gate_x3(Wgd, xh, xl);
             o.wgH[k - 1] = pool.add(xh); o.wgL[k - 1] = pool.add(xl);
-            WView wd, wdf, wu;
-            if (!get_w(h, p + "vector_down.weight", 8, V, wd) || !get_w(h, p + "vector_down_frames.weight", 3, V, wdf) ||
-                !get_w(h, p + "vector_up.weight", V, 8, wu))
-                return -1;
-            Dense Wdd(32, 32), Wu(32, 16);                       // rows: 8 W_down, 3 W_frames (rest 0) ; vector_up with k-slots 8..15 zero
-            for (int r = 0; r < 8; ++r) for (int c = 0; c < V; ++c) Wdd.at(r, c) = wd.at(r, c);
-            for (int r = 0; r < 3; ++r) for (int c = 0; c < V; ++c) Wdd.at(8 + r, c) = wdf.at(r, c);
-            for (int c = 0; c < V; ++c) for (int hh = 0; hh < 8; ++hh) Wu.at(c, hh) = wu.at(c, hh);
-            pack_x3(Wdd, xh, xl);
-            o.wddH[k - 1] = pool.add(xh); o.wddL[k - 1] = pool.add(xl);
-            pack_x3(Wu, xh, xl);
-            o.wupH[k - 1] = pool.add(xh); o.wupL[k - 1] = pool.add(xl);
         }
         {
             WView wa, ba;
@@ -542,11 +521,6 @@ int gcdm_finalize_weights(gcdm_handle* h) {
         d.w0H = (const h8*)(base + o.w0H); d.w0L = (const h8*)(base + o.w0L); d.KB0 = o.KB0; d.KB = o.KB;
         d.ffx = resolve_x3(o.ff, base); d.posx = resolve_x3(o.pos, base);
         d.wpqH = (const h8*)(base + o.wpqH); d.wpqL = (const h8*)(base + o.wpqL);
-        d.wup0H = (const h8*)(base + o.wup0H); d.wup0L = (const h8*)(base + o.wup0L);
-        for (int k = 0; k < 3; ++k) {
-            d.wddH[k] = (const h8*)(base + o.wddH[k]); d.wddL[k] = (const h8*)(base + o.wddL[k]);
-            d.wupH[k] = (const h8*)(base + o.wupH[k]); d.wupL[k] = (const h8*)(base + o.wupL[k]);
-        }
         d.wg0H = (const h8*)(base + o.wg0H); d.wg0L = (const h8*)(base + o.wg0L);
         for (int k = 0; k < 3; ++k) {
             d.wH[k] = (const h8*)(base + o.wH[k]); d.wL[k] = (const h8*)(base + o.wL[k]);
@@ -557,7 +531,6 @@ int gcdm_finalize_weights(gcdm_handle* h) {
         if (set_lds_attr(h, k_edge_msg<64, 16, 64>, EdgeGeo<64>::LDS_BYTES) || set_lds_attr(h, k_edge_msg<16, 8, 64>, EdgeGeo<64>::LDS_BYTES) ||
             set_lds_attr(h, k_edge_msg<64, 16, 32>, EdgeGeo<32>::LDS_BYTES) || set_lds_attr(h, k_edge_msg<16, 8, 32>, EdgeGeo<32>::LDS_BYTES) ||
             set_lds_attr(h, k_edge_msg_x3<64, 16>, EdgeGeo<64>::LDS_BYTES) || set_lds_attr(h, k_edge_msg_x3<16, 8>, EdgeGeo<64>::LDS_BYTES) ||
-            set_lds_attr(h, k_edge_msg_x3v<64, 16>, EdgeGeoV<64>::LDS_BYTES) || set_lds_attr(h, k_edge_msg_x3v<16, 8>, EdgeGeoV<64>::LDS_BYTES) ||
             set_lds_attr(h, k_node_x3<true>, NK_LDS_BYTES) || set_lds_attr(h, k_node_x3<false>, NK_LDS_BYTES) ||
             set_lds_attr(h, k_node<true>, NK_LDS_BYTES) || set_lds_attr(h, k_node<false>, NK_LDS_BYTES))
             return -1;
@@ -700,14 +673,7 @@ int gcdm_forward(gcdm_handle* h, const float* xh, const float* t, const float* c
             for (int k = 0; k < 3; ++k) { xa.wH[k] = d.wH[k]; xa.wL[k] = d.wL[k]; xa.wgH[k] = d.wgH[k]; xa.wgL[k] = d.wgL[k]; }
             xa.flags_dev = h->d_flags;
             const int xtiles = (E + 63) / 64;
-            if (h->vec_mfma) {
-                EdgeMsgX3VArgs va{};
-                va.x3 = xa;
-                va.wup0H = d.wup0H; va.wup0L = d.wup0L;
-                for (int k = 0; k < 3; ++k) { va.wddH[k] = d.wddH[k]; va.wddL[k] = d.wddL[k]; va.wupH[k] = d.wupH[k]; va.wupL[k] = d.wupL[k]; }
-                if (h->Se == 64) hipLaunchKernelGGL((k_edge_msg_x3v<64, 16>), dim3(xtiles), dim3(512), EdgeGeoV<64>::LDS_BYTES, st, va);
-                else hipLaunchKernelGGL((k_edge_msg_x3v<16, 8>), dim3(xtiles), dim3(512), EdgeGeoV<64>::LDS_BYTES, st, va);
-            } else if (h->Se == 64) hipLaunchKernelGGL((k_edge_msg_x3<64, 16>), dim3(xtiles), dim3(512), EdgeGeo<64>::LDS_BYTES, st, xa);
+            if (h->Se == 64) hipLaunchKernelGGL((k_edge_msg_x3<64, 16>), dim3(xtiles), dim3(512), EdgeGeo<64>::LDS_BYTES, st, xa);
             else hipLaunchKernelGGL((k_edge_msg_x3<16, 8>), dim3(xtiles), dim3(512), EdgeGeo<64>::LDS_BYTES, st, xa);
         } else if (ET == 64) {
             if (h->Se == 64) hipLaunchKernelGGL((k_edge_msg<64, 16, 64>), dim3(tiles), dim3(EdgeGeo<64>::THREADS), EdgeGeo<64>::LDS_BYTES, st, ma);
@@ -817,7 +783,6 @@ int gcdm_set_option(gcdm_handle* h, const char* name, int32_t value) {
         if (value) h->edge_tile = 64;
         return 0;
     }
-    if (k == "vec_mfma") { h->vec_mfma = value ? 1 : 0; return 0; }
     if (k == "edge_tile") {
         if (value != 32 && value != 64) return fail(h, "gcdm_set_option(edge_tile): 32 or 64");
         if (h->mfma_x3 && value != 64) return fail(h, "gcdm_set_option(edge_tile): the split-precision kernel uses 64-edge tiles");
@@ -831,7 +796,6 @@ int gcdm_get_option(const gcdm_handle* h, const char* name) {
     if (!h || !name) return -1;
     const std::string k(name);
     if (k == "mfma_mode") return h->mfma_x3;
-    if (k == "vec_mfma") return h->vec_mfma;
     if (k == "edge_tile") return h->edge_tile;
     return -1;
 }

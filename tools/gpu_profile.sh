@@ -1,0 +1,17 @@
+#!/bin/bash
+# Round profile of bench.py on the GPU box (run through gpurun): kernel-trace stats + separate PMC passes.
+#   tools/gpu_profile.sh <tag> [workload]      -> gpurun_out/<tag>_{stats,pmc1..4}
+set -u
+TAG=${1:-prof}; WL=${2:-qm9}
+ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$ROOT/gpurun_out
+export TMPDIR=/tmp
+cd /tmp
+B="python $ROOT/bench.py --workload $WL --steps 6 --warmup 2 --no-cpu-baseline"
+run() { local name=$1; shift; (timeout 280 rocprofv3 --kernel-trace "$@" --output-format csv -d $OUT/${TAG}_$name -- $B > $OUT/${TAG}_$name.log 2>&1; echo "$name exit=$?"); }
+run stats --stats
+run pmc1 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F16 SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS SQ_INSTS_VALU
+run pmc2 --pmc FETCH_SIZE
+run pmc3 --pmc WRITE_SIZE
+run pmc4 --pmc TCC_HIT_sum TCC_MISS_sum TCP_TCC_READ_REQ_sum
+du -sh $OUT/${TAG}_*
