@@ -41,6 +41,11 @@ WORKLOADS = {
     "qm9": dict(dataset="qm9", cond=(), B=1024, n=19, name="QM9 unconditional, 1024 molecules x 19 atoms / GPU, 1000-step DDPM"),
     "qm9cond": dict(dataset="qm9", cond=("alpha",), B=1024, n=19, name="QM9 alpha-conditional, 1024 x 19 / GPU, 1000-step DDPM"),
     "geom": dict(dataset="geom", cond=(), B=256, n=44, name="GEOM-Drugs unconditional, 256 molecules x 44 atoms / GPU, 1000-step DDPM"),
+    # ragged variants, molecule sizes drawn from the dataset histogram under torch.manual_seed(1); "eval" is the
+    # batch shape of the reference's 10 000-sample evaluation driver (mol_gen_eval.py:131-137, batch 100).  Not the headline.
+    "qm9_ragged": dict(dataset="qm9", cond=(), B=1024, n=None, name="QM9 unconditional, 1024 molecules with sizes from the dataset histogram / GPU"),
+    "geom_ragged": dict(dataset="geom", cond=(), B=256, n=None, name="GEOM-Drugs unconditional, 256 molecules with sizes from the dataset histogram / GPU"),
+    "qm9_eval": dict(dataset="qm9", cond=(), B=100, n=None, name="QM9 evaluation-driver batch: 100 molecules with sizes from the dataset histogram / GPU"),
 }
 
 
@@ -59,7 +64,7 @@ def cpu_baseline(dataset, cond, dims, seconds_budget=20.0):
     from oracle import gcdm_oracle as O
     case = "geom" if dataset == "geom" else ("qm9cond" if cond else "qm9")
     d = synth.DATASET_DIMS[case]
-    n = 44 if dataset == "geom" else 19
+    n = 44 if dataset == "geom" else 19       # ragged workloads: the CPU sample uses the fixed README sizes (same per-edge cost)
     Bc = 8 if dataset == "geom" else 16
     threads = min(os.cpu_count() or 1, int(os.environ.get("GCDM_CPU_THREADS", "32")))
     torch.set_num_threads(threads)     # very wide hosts: torch CPU ops on these sizes stop scaling (and thrash) past ~32 threads
@@ -148,10 +153,14 @@ def main():
             if p.dim() == 2:
                 p.mul_(0.25)
     net = net.to(dev)
-    ddpm = pkg.EquivariantVariationalDiffusion(net, cfgs["diffusion_cfg"], cfgs["dataloader_cfg"],
-                                               pkg.dataset_info("geom" if wl["dataset"] == "geom" else "qm9"))
+    info = pkg.dataset_info("geom" if wl["dataset"] == "geom" else "qm9")
+    ddpm = pkg.EquivariantVariationalDiffusion(net, cfgs["diffusion_cfg"], cfgs["dataloader_cfg"], info)
     dyn, lib, h = ddpm._native(dev)
-    num_nodes = torch.full((B,), wl["n"], dtype=torch.int32)
+    if wl["n"] is not None:
+        num_nodes = torch.full((B,), wl["n"], dtype=torch.int32)
+    else:
+        torch.manual_seed(1 + rank)
+        num_nodes = ddpm.num_nodes_distribution.sample(B).to(torch.int32)
     dyn.plan(num_nodes)
     N, E = int(lib.gcdm_num_nodes(h)), int(lib.gcdm_num_edges(h))
     D = 3 + d["num_atom_types"] + int(d["include_charges"])
@@ -225,6 +234,16 @@ def main():
         torch.cuda.synchronize(dev)
         gather_ms = (time.perf_counter() - tg) * 1e3
     finite = bool(torch.isfinite(out).all().item())
+    # post-sampling stability statistics on the device, timed for information; not part of `value`
+    types = out[:, 3:3 + d["num_atom_types"]].argmax(-1)
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+    pkg.check_molecular_stability_batch(out, types, num_nodes, info)
+    ev[0].record()
+    stab = pkg.check_molecular_stability_batch(out, types, num_nodes, info)
+    ev[1].record()
+    torch.cuda.synchronize(dev)
+    stability_ms = ev[0].elapsed_time(ev[1])
+    assert int(stab[:, 2].sum().item()) == N
     fl = int(flags.item())
 
     if rank == 0:
@@ -240,10 +259,10 @@ def main():
             "metric": "molecules/sec (1000-step DDPM sample)", "value": world * B / (ms_per_step * 1e-3 * NET_EVALS_PER_SAMPLE),
             "unit": "molecules/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": wl["name"], "molecules_per_gpu": B, "atoms_per_molecule": wl["n"], "nodes_per_gpu": N,
+            "config": {"workload": wl["name"], "molecules_per_gpu": B, "atoms_per_molecule": wl["n"] if wl["n"] is not None else round(N / B, 2), "nodes_per_gpu": N,
                        "edges_per_gpu": E, "noise": "on-device Philox", "weights": "default init, 2-D x0.25 (SURVEY 8d)",
                        "value_definition": f"molecules / ({NET_EVALS_PER_SAMPLE} x measured s/step)", "parallelism": f"shard{world}",
-                       "final_gather_ms": gather_ms, "outputs_finite": finite, "flags": fl,
+                       "final_gather_ms": gather_ms, "stability_check_ms": stability_ms, "outputs_finite": finite, "flags": fl,
                        "step_tflops_algorithmic": alg_total / (ms_per_step * 1e-3) / 1e12,
                        "step_tflops_executed": exe_total / (ms_per_step * 1e-3) / 1e12},
             "roofline": {"bound": "mfma", "kernel": "k_edge_msg_x3" if x3 else "k_edge_msg", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",

@@ -14,10 +14,12 @@ from .config import AttrDict, default_cfgs, load_cfg_tree, dataset_info         
 from .gcpnet import GCP2, GCPNetDynamics                                        # noqa: F401
 from .variational_diffusion import EquivariantVariationalDiffusion, PredefinedNoiseSchedule, NumNodesDistribution  # noqa: F401
 from .mol_gen_ddpm import QM9MoleculeGenerationDDPM, GEOMMoleculeGenerationDDPM  # noqa: F401
-from . import _native                                                           # noqa: F401
+from . import _native, stability                                                # noqa: F401
+from .stability import check_molecular_stability, check_molecular_stability_batch, get_bond_length_arrays, CategoricalDistribution  # noqa: F401
 
 __all__ = [
     "AttrDict", "default_cfgs", "load_cfg_tree", "dataset_info", "GCP2", "GCPNetDynamics",
     "EquivariantVariationalDiffusion", "PredefinedNoiseSchedule", "NumNodesDistribution",
     "QM9MoleculeGenerationDDPM", "GEOMMoleculeGenerationDDPM",
+    "check_molecular_stability", "check_molecular_stability_batch", "get_bond_length_arrays", "CategoricalDistribution",
 ]

@@ -28,11 +28,24 @@ class GcdmConfig(C.Structure):
     ]
 
 
+STABILITY_MAX_TYPES = 16
+
+
+class GcdmBondTables(C.Structure):
+    _fields_ = [
+        ("num_types", C.c_int32), ("limit_bonds_to_one", C.c_int32),
+        ("thr1", C.c_float * (STABILITY_MAX_TYPES * STABILITY_MAX_TYPES)),
+        ("thr2", C.c_float * (STABILITY_MAX_TYPES * STABILITY_MAX_TYPES)),
+        ("thr3", C.c_float * (STABILITY_MAX_TYPES * STABILITY_MAX_TYPES)),
+        ("allowed_mask", C.c_uint32 * STABILITY_MAX_TYPES),
+    ]
+
+
 EXPORTS = [
     "gcdm_create", "gcdm_destroy", "gcdm_last_error", "gcdm_set_weight", "gcdm_finalize_weights", "gcdm_set_gamma",
     "gcdm_plan_batch", "gcdm_forward", "gcdm_sample_step", "gcdm_sample_final", "gcdm_sample_init", "gcdm_debug_read",
     "gcdm_debug_set_layer_limit", "gcdm_num_nodes", "gcdm_num_edges", "gcdm_forward_flops_executed",
-    "gcdm_profile_enable", "gcdm_profile_edge_kernel_ms", "gcdm_set_option", "gcdm_get_option",
+    "gcdm_profile_enable", "gcdm_profile_edge_kernel_ms", "gcdm_set_option", "gcdm_get_option", "gcdm_check_stability",
 ]
 
 _lib: Optional[C.CDLL] = None
@@ -84,6 +97,8 @@ def load() -> C.CDLL:
     lib.gcdm_profile_edge_kernel_ms.argtypes = [H, C.POINTER(C.c_double), C.POINTER(C.c_int32)]
     lib.gcdm_forward_flops_executed.argtypes = [H]
     lib.gcdm_forward_flops_executed.restype = C.c_double
+    lib.gcdm_check_stability.argtypes = [C.POINTER(GcdmBondTables), C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p,
+                                         C.c_void_p]
     for name in EXPORTS:
         if getattr(lib, name).restype is C.c_int:
             getattr(lib, name).restype = C.c_int

@@ -3,6 +3,7 @@
 #include "gcdm_kernels.hip.h"
 #include "gcdm_edge_x3.hip.h"
 #include "gcdm_node_x3.hip.h"
+#include "gcdm_stability.hip.h"
 #include "../../include/gcdm_hip.h"
 
 #include <cmath>
@@ -591,6 +592,16 @@ int gcdm_plan_batch(gcdm_handle* h, int32_t B, const int32_t* nn) {
     h->AL = w + oAL; h->U = w + oU; h->FR = w + oFR; h->PROF = w + oPROF;
     h->B = B; h->N = N; h->E = E; h->max_n = max_n;
     return 0;
+}
+
+int gcdm_check_stability(const GcdmBondTables* tables, const float* x, int64_t x_row_stride, const int32_t* atom_types,
+                         const int32_t* mol_offsets, int32_t num_molecules, int32_t* out, void* stream) {
+    if (!tables || tables->num_types < 1 || tables->num_types > GCDM_STABILITY_MAX_TYPES || num_molecules < 0 || x_row_stride < 3) return -1;
+    if (num_molecules == 0) return 0;
+    if (!x || !atom_types || !mol_offsets || !out) return -1;
+    hipLaunchKernelGGL(k_stability, dim3(num_molecules), dim3(64), 0, (hipStream_t)stream, *tables, x, (long)x_row_stride, atom_types,
+                       mol_offsets, out);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
 int64_t gcdm_num_nodes(const gcdm_handle* h) { return h ? h->N : -1; }

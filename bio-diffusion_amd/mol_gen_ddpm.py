@@ -3,7 +3,8 @@
 Boundary only (plug point 2): the constructor keywords, ``load_from_checkpoint``, ``.to(device)``,
 ``.dataset_info``, ``.ddpm.num_nodes_distribution.sample(n)``, ``.sample(...)`` and ``.generate_molecules(...)`` that
 ``src/mol_gen_sample.py:81-182`` and ``src/mol_gen_eval_conditional_qm9.py:101-109`` use of
-``src/models/qm9_mol_gen_ddpm.py`` / ``geom_mol_gen_ddpm.py``.  Training / validation hooks, metrics and RDKit
+``src/models/qm9_mol_gen_ddpm.py`` / ``geom_mol_gen_ddpm.py``, plus the evaluation driver ``sample_and_analyze`` (``:747-885``)
+with the stability statistics computed on the device.  Training / validation hooks, RDKit metrics and RDKit
 post-processing are out of scope; ``generate_molecules`` returns raw (positions, atom-type indices, charges) per
 molecule and hands them to an optional ``molecule_builder`` (the reference's ``build_molecule``) when given.
 """
@@ -13,11 +14,13 @@ import io
 import pickle
 from typing import Any, Callable, Dict, List, Optional, Tuple
 
+import numpy as np
 import torch
 from torch import nn
 
 from .config import cfg_get, dataset_info as _dataset_info
 from .gcpnet import GCPNetDynamics
+from .stability import CategoricalDistribution, check_molecular_stability_batch
 from .variational_diffusion import EquivariantVariationalDiffusion
 
 
@@ -90,6 +93,9 @@ class _MoleculeGenerationDDPM(nn.Module):
         self.ddpm = EquivariantVariationalDiffusion(dynamics_network=dynamics_network, diffusion_cfg=diffusion_cfg,
                                                     dataloader_cfg=dataloader_cfg, dataset_info=self.dataset_info)
         self.props_distr = None   # set by the conditional-evaluation driver (PropertiesDistribution needs training data)
+        # qm9_mol_gen_ddpm.py:196-199: node-type statistics of the training set, for the KL reported by analyze_samples
+        self.node_type_distribution = CategoricalDistribution(self.dataset_info["atom_types"], self.dataset_info["atom_encoder"])
+        self.molecular_metrics = None   # BasicMolecularMetrics needs RDKit + the training SMILES (out of scope); attach one to get validity etc.
         self._init_kwargs = dict(model_cfg=model_cfg, module_cfg=module_cfg, layer_cfg=layer_cfg, diffusion_cfg=diffusion_cfg,
                                  dataloader_cfg=dataloader_cfg, path_cfg=path_cfg)
 
@@ -157,6 +163,54 @@ class _MoleculeGenerationDDPM(nn.Module):
             mols.append(molecule_builder(pos, at, self.dataset_info) if molecule_builder is not None else (pos, at, ch))
             o += n
         return mols
+
+
+    @torch.inference_mode()
+    def sample_and_analyze(self, num_samples: int, node_mask: Optional[torch.Tensor] = None, context: Optional[torch.Tensor] = None,
+                           batch_size: Optional[int] = None, max_num_nodes: Optional[int] = 100, num_timesteps: Optional[int] = None,
+                           **kw) -> Dict[str, Any]:
+        """qm9_mol_gen_ddpm.py:747-843 -- the evaluation driver: batches of `batch_size` molecules with sizes drawn from the
+        dataset histogram, one 1000-step sampling run per batch, stability statistics.  The per-molecule host loop of the
+        reference (`check_molecular_stability` on CPU copies) is one device launch per batch here; only three integers per
+        molecule and the atom-type histogram ever leave the GPU.  `save_molecules` (xyz files) is not built."""
+        max_num_nodes = self.dataset_info.get("max_n_nodes", max_num_nodes)
+        batch_size = int(cfg_get(self._init_kwargs["dataloader_cfg"], "batch_size", 64)) if batch_size is None else batch_size
+        batch_size = min(batch_size, num_samples)
+        results, type_counts = [], torch.zeros(self.num_atom_types, dtype=torch.int64)
+        done = 0
+        while done < num_samples:
+            nb = min(batch_size, num_samples - done)
+            num_nodes = self.ddpm.num_nodes_distribution.sample(nb)
+            assert int(num_nodes.max()) <= max_num_nodes
+            ctx = context
+            if self.condition_on_context and ctx is None:
+                if self.props_distr is None:
+                    raise ValueError("context required (no props_distr attached)")
+                ctx = self.props_distr.sample_batch(num_nodes)
+            xh, _, _ = self.ddpm.mol_gen_sample(num_samples=nb, num_nodes=num_nodes, node_mask=node_mask,
+                                                context=ctx if self.condition_on_context else None, device=self.device,
+                                                num_timesteps=num_timesteps, **kw)
+            oh = xh[:, self.num_x_dims:-1] if self.include_charges else xh[:, self.num_x_dims:]
+            atom_types = oh.argmax(-1)
+            results.append(check_molecular_stability_batch(xh, atom_types, num_nodes, self.dataset_info))
+            type_counts += torch.bincount(atom_types, minlength=self.num_atom_types).cpu()
+            done += nb
+        return self.analyze_samples(torch.cat(results).cpu(), type_counts)
+
+    def analyze_samples(self, stability: torch.Tensor, atom_type_counts: torch.Tensor) -> Dict[str, Any]:
+        """qm9_mol_gen_ddpm.py:846-885 on the device results: `stability` int [M, 3] rows (stable, nr_stable_atoms, n)."""
+        st = stability.to(torch.int64)
+        q = atom_type_counts.to(torch.float64).numpy()
+        p = self.node_type_distribution.p
+        with np.errstate(divide="ignore", invalid="ignore"):
+            kl = float(-np.sum(p * np.log(q / q.sum() / p + self.node_type_distribution.EPS)))
+        out = {
+            "kl_div_atom_types": kl,
+            "mol_stable": float(st[:, 0].sum()) / float(len(st)),
+            "atm_stable": float(st[:, 1].sum()) / float(st[:, 2].sum()),
+            "validity": None, "uniqueness": None, "novelty": None,    # RDKit metrics (BasicMolecularMetrics) are outside the path
+        }
+        return out
 
 
 class QM9MoleculeGenerationDDPM(_MoleculeGenerationDDPM):

@@ -105,7 +105,7 @@ int64_t gcdm_debug_read(gcdm_handle* h, const char* name, float* host_out, int64
 int gcdm_debug_set_layer_limit(gcdm_handle* h, int32_t num_layers_to_run);
 
 /* Options.  "mfma_mode": 1 (default; env GCDM_MFMA=f16x3) evaluates the per-edge contractions with three f16 MFMAs per product
- * block on operands split as x = hi + 2^-11 lo' (fp32-equivalent accuracy, see DESIGN.md 3.5; raises GCDM_FLAG_F16_RANGE if an
+ * block on operands split as x = hi + 2^-11 lo' (fp32-equivalent accuracy, see DESIGN.md 3.4; raises GCDM_FLAG_F16_RANGE if an
  * activation exceeds 6e4, in which case the caller must re-run with mode 0); 0 (env GCDM_MFMA=f32) uses fp32 MFMA throughout.
  * "edge_tile": 64 (default) or 32 edges per workgroup of the fp32 edge kernel. */
 int gcdm_set_option(gcdm_handle* h, const char* name, int32_t value);
@@ -122,6 +122,33 @@ int64_t gcdm_num_nodes(const gcdm_handle* h);
 int64_t gcdm_num_edges(const gcdm_handle* h);
 /* Executed / algorithmic FLOPs of one forward on the current plan. */
 double gcdm_forward_flops_executed(const gcdm_handle* h);
+
+/* ---- post-sampling: molecular stability of the generated batch ---------------------------------------------------
+ * Replaces, for a whole batch at once and without leaving the device, the per-molecule host loop of
+ *   check_molecular_stability   (src/datamodules/components/edm/__init__.py:91-122)  with
+ *   get_bond_order_batch        (src/datamodules/components/edm/__init__.py:61-88)
+ * as called by analyze_samples (src/models/qm9_mol_gen_ddpm.py:859-868).  Tables are the reference's constants
+ * (src/datamodules/components/edm/constants.py:20-72) indexed by the dataset's atom vocabulary. */
+#define GCDM_STABILITY_MAX_TYPES 16
+typedef struct GcdmBondTables {
+    int32_t  num_types;                 /* T = len(dataset_info["atom_decoder"]) <= 16 */
+    int32_t  limit_bonds_to_one;        /* get_bond_order_batch(limit_bonds_to_one=...) ; check_molecular_stability uses 0 */
+    /* thrK[a*16 + b] = bondsK[a][b] + marginK in pm (bond length 0 where the pair has no entry, exactly as get_bond_length_arrays) */
+    float    thr1[GCDM_STABILITY_MAX_TYPES * GCDM_STABILITY_MAX_TYPES];
+    float    thr2[GCDM_STABILITY_MAX_TYPES * GCDM_STABILITY_MAX_TYPES];
+    float    thr3[GCDM_STABILITY_MAX_TYPES * GCDM_STABILITY_MAX_TYPES];
+    uint32_t allowed_mask[GCDM_STABILITY_MAX_TYPES];  /* bit b set <=> an atom of this type is stable with b bonds (b <= 31) */
+} GcdmBondTables;
+
+/* For every molecule m (atoms mol_offsets[m] .. mol_offsets[m+1]-1) writes out[m] = {molecule_stable, nr_stable_atoms, n}.
+ *   tables      host   (copied into the launch; nothing is retained)
+ *   x           device fp32, atom i at x[i * x_row_stride .. +2]  (pass the sampler output xh with x_row_stride = 3+F)
+ *   atom_types  device int32 [N] in [0, T)
+ *   mol_offsets device int32 [num_molecules + 1], ascending
+ *   out         device int32 [num_molecules][3]
+ * Handle-free; returns 0, -1 (bad argument) or -2 (HIP launch error). */
+int gcdm_check_stability(const GcdmBondTables* tables, const float* x, int64_t x_row_stride, const int32_t* atom_types,
+                         const int32_t* mol_offsets, int32_t num_molecules, int32_t* out, void* stream);
 
 #ifdef __cplusplus
 }
