@@ -531,7 +531,8 @@ int gcdm_finalize_weights(gcdm_handle* h) {
     if (!h->attr_set) {
         if (set_lds_attr(h, k_edge_msg<64, 16, 64>, EdgeGeo<64>::LDS_BYTES) || set_lds_attr(h, k_edge_msg<16, 8, 64>, EdgeGeo<64>::LDS_BYTES) ||
             set_lds_attr(h, k_edge_msg<64, 16, 32>, EdgeGeo<32>::LDS_BYTES) || set_lds_attr(h, k_edge_msg<16, 8, 32>, EdgeGeo<32>::LDS_BYTES) ||
-            set_lds_attr(h, k_edge_msg_x3<64, 16>, EdgeGeo<64>::LDS_BYTES) || set_lds_attr(h, k_edge_msg_x3<16, 8>, EdgeGeo<64>::LDS_BYTES) ||
+            set_lds_attr(h, k_edge_msg_x3<64, 16, 64>, EdgeGeo<64>::LDS_BYTES) || set_lds_attr(h, k_edge_msg_x3<16, 8, 64>, EdgeGeo<64>::LDS_BYTES) ||
+            set_lds_attr(h, k_edge_msg_x3<64, 16, 32>, EdgeGeo<32>::LDS_BYTES) || set_lds_attr(h, k_edge_msg_x3<16, 8, 32>, EdgeGeo<32>::LDS_BYTES) ||
             set_lds_attr(h, k_node_x3<true>, NK_LDS_BYTES) || set_lds_attr(h, k_node_x3<false>, NK_LDS_BYTES) ||
             set_lds_attr(h, k_node<true>, NK_LDS_BYTES) || set_lds_attr(h, k_node<false>, NK_LDS_BYTES))
             return -1;
@@ -683,9 +684,13 @@ int gcdm_forward(gcdm_handle* h, const float* xh, const float* t, const float* c
             xa.w0H = d.w0H; xa.w0L = d.w0L; xa.KB0 = d.KB0; xa.wg0H = d.wg0H; xa.wg0L = d.wg0L; xa.KB = d.KB;
             for (int k = 0; k < 3; ++k) { xa.wH[k] = d.wH[k]; xa.wL[k] = d.wL[k]; xa.wgH[k] = d.wgH[k]; xa.wgL[k] = d.wgL[k]; }
             xa.flags_dev = h->d_flags;
-            const int xtiles = (E + 63) / 64;
-            if (h->Se == 64) hipLaunchKernelGGL((k_edge_msg_x3<64, 16>), dim3(xtiles), dim3(512), EdgeGeo<64>::LDS_BYTES, st, xa);
-            else hipLaunchKernelGGL((k_edge_msg_x3<16, 8>), dim3(xtiles), dim3(512), EdgeGeo<64>::LDS_BYTES, st, xa);
+            if (ET == 64) {
+                if (h->Se == 64) hipLaunchKernelGGL((k_edge_msg_x3<64, 16, 64>), dim3(tiles), dim3(512), EdgeGeo<64>::LDS_BYTES, st, xa);
+                else hipLaunchKernelGGL((k_edge_msg_x3<16, 8, 64>), dim3(tiles), dim3(512), EdgeGeo<64>::LDS_BYTES, st, xa);
+            } else {
+                if (h->Se == 64) hipLaunchKernelGGL((k_edge_msg_x3<64, 16, 32>), dim3(tiles), dim3(256), EdgeGeo<32>::LDS_BYTES, st, xa);
+                else hipLaunchKernelGGL((k_edge_msg_x3<16, 8, 32>), dim3(tiles), dim3(256), EdgeGeo<32>::LDS_BYTES, st, xa);
+            }
         } else if (ET == 64) {
             if (h->Se == 64) hipLaunchKernelGGL((k_edge_msg<64, 16, 64>), dim3(tiles), dim3(EdgeGeo<64>::THREADS), EdgeGeo<64>::LDS_BYTES, st, ma);
             else hipLaunchKernelGGL((k_edge_msg<16, 8, 64>), dim3(tiles), dim3(EdgeGeo<64>::THREADS), EdgeGeo<64>::LDS_BYTES, st, ma);

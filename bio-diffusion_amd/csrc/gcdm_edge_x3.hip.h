@@ -246,9 +246,12 @@ struct EdgeMsgX3Args {
 
 #define GCDM_FLAG_F16_RANGE_BIT 8u
 
-template <int SE, int VE>
-__global__ __launch_bounds__(512) void k_edge_msg_x3(EdgeMsgX3Args ax) {
-    constexpr int ET = 64;
+// ET = 64: 8 waves, wave w owns M-tile w x both N-tiles (every weight byte is loaded once per CU and tile).
+// ET = 32: 4 waves, wave w owns M-tiles 2w, 2w+1 x one N-tile; half the LDS, so two workgroups share a CU and run out of phase
+//          (one in its GEMM while the other is in a VALU phase) at the price of streaming the weights twice per 64 edges.
+template <int SE, int VE, int ET>
+__global__ __launch_bounds__(ET * 8) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_edge_msg_x3(EdgeMsgX3Args ax) {
+    constexpr int NW = ET / 8, MT = 8 / NW, NT = ET / 32;     // waves, M-tiles and N-tiles per wave
     const EdgeMsgArgs& a = ax.base;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     using Geo = EdgeGeo<ET>;
@@ -275,7 +278,7 @@ __global__ __launch_bounds__(512) void k_edge_msg_x3(EdgeMsgX3Args ax) {
     constexpr int Q8 = N8 + H0G8;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int e = lane, part = wave;
+    const int e = (ET == 64) ? lane : (tid & (ET - 1)), part = (ET == 64) ? wave : (tid / ET);
     const int E = a.E, N = a.N;
     const int e0 = blockIdx.x * ET;
     const int nvalid = min(ET, E - e0);
@@ -284,14 +287,18 @@ __global__ __launch_bounds__(512) void k_edge_msg_x3(EdgeMsgX3Args ax) {
     const uint64_t t_start = a.prof ? __builtin_amdgcn_s_memtime() : 0;
     bool over = false;
     constexpr int PD = 2;
-    X3Ring<1, PD> ring;
-    x3_prefetch<1, PD>(ring, ax.w0H + (size_t)wave * ax.KB0 * 64, ax.w0L + (size_t)wave * ax.KB0 * 64, ax.KB0, lane);   // flies during P1
+    const int mt0 = MT * wave;   // first M-tile (32 output channels each) of this wave
+    X3Ring<MT, PD> ring;
+    x3_prefetch<MT, PD>(ring, ax.w0H + (size_t)mt0 * ax.KB0 * 64, ax.w0L + (size_t)mt0 * ax.KB0 * 64, ax.KB0, lane);   // flies during P1
 
     if (wave == 0) {
-        m_row[e] = ni;
-        m_col[e] = nj;
+        const bool own = lane < ET;
+        if (own) {
+            m_row[e] = ni;
+            m_col[e] = nj;
+        }
         const int prev = __shfl_up(ni, 1);
-        const bool start = (e < nvalid) && (e == 0 || prev != ni);
+        const bool start = own && (e < nvalid) && (e == 0 || prev != ni);
         const unsigned long long mask = __ballot(start);
         const int sid = __popcll(mask & ((2ull << lane) - 1ull)) - 1;
         if (start) m_seg[sid] = e;
@@ -379,50 +386,57 @@ __global__ __launch_bounds__(512) void k_edge_msg_x3(EdgeMsgX3Args ax) {
     STAMP(2);
 
     const int half = lane >> 5, l31 = lane & 31;
-    const int mt0 = wave;   // wave w owns M-tile w (32 output channels) for all 64 edges: every weight byte is loaded once per CU
-    f32x16 st[1][2];     // fp32 message scalars of this wave's 32 channels x 64 edges (live in registers for the whole tile)
-    f32x16 am[1][2], al2[1][2];
-    f32x16 gm[2], gl[2];
+    f32x16 st[MT][NT];   // fp32 message scalars of this wave's channels x edges (live in registers for the whole tile)
+    f32x16 am[MT][NT], al2[MT][NT];
+    f32x16 gm[NT], gl[NT];
     const h8* xh8 = (const h8*)XH;
     const h8* xl8 = (const h8*)XL;
 
     // ---- P2: msg0 GEMM ----------------------------------------------------------------------------------------------------
     {
 #pragma unroll
-        for (int n = 0; n < 2; ++n) {
+        for (int n = 0; n < NT; ++n) {
             const int ri = m_row[32 * n + l31], cj = m_col[32 * n + l31];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int g = 8 * mt0 + 2 * q + half;
-                const v4f p = a.PQ4[(size_t)g * N + ri];
-                const v4f qq = a.PQ4[(size_t)(64 + g) * N + cj];
+            for (int m = 0; m < MT; ++m)
 #pragma unroll
-                for (int t = 0; t < 4; ++t) { am[0][n][4 * q + t] = p[t] + qq[t]; al2[0][n][4 * q + t] = 0.f; }
-            }
+                for (int q = 0; q < 4; ++q) {
+                    const int g = 8 * (mt0 + m) + 2 * q + half;
+                    const v4f p = a.PQ4[(size_t)g * N + ri];
+                    const v4f qq = a.PQ4[(size_t)(64 + g) * N + cj];
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) { am[m][n][4 * q + t] = p[t] + qq[t]; al2[m][n][4 * q + t] = 0.f; }
+                }
         }
         STAMP(3);
-        tile_gemm_x3<1, 2, PD>(am, al2, ring, ax.w0H + (size_t)mt0 * ax.KB0 * 64, ax.w0L + (size_t)mt0 * ax.KB0 * 64, ax.KB0, xh8, xl8, ETP, lane);
-        x3_prefetch<1, PD>(ring, ax.wH[0] + (size_t)mt0 * ax.KB * 64, ax.wL[0] + (size_t)mt0 * ax.KB * 64, ax.KB, lane);
+        tile_gemm_x3<MT, NT, PD>(am, al2, ring, ax.w0H + (size_t)mt0 * ax.KB0 * 64, ax.w0L + (size_t)mt0 * ax.KB0 * 64, ax.KB0, xh8, xl8, ETP, lane);
+        x3_prefetch<MT, PD>(ring, ax.wH[0] + (size_t)mt0 * ax.KB * 64, ax.wL[0] + (size_t)mt0 * ax.KB * 64, ax.KB, lane);
         STAMP(4);
 #pragma unroll
-        for (int n = 0; n < 2; ++n)
+        for (int m = 0; m < MT; ++m)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) st[0][n][r] = fast_silu(am[0][n][r] + al2[0][n][r] * X3_INV_SCALE);
+            for (int n = 0; n < NT; ++n)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) st[m][n][r] = fast_silu(am[m][n][r] + al2[m][n][r] * X3_INV_SCALE);
         STAMP(5);
 #pragma unroll
-        for (int n = 0; n < 2; ++n)
+        for (int n = 0; n < NT; ++n)
 #pragma unroll
             for (int r = 0; r < 16; ++r) { gm[n][r] = 0.f; gl[n][r] = 0.f; }
-        gate_partial_x3<1, 2>(gm, gl, st, ax.wg0H, ax.wg0L, mt0, lane);
-        if (wave < 4) put_gate_partial<2>(PG, gm, gl, ETP, wave, lane, false);
-        __syncthreads();
-        if (wave >= 4) put_gate_partial<2>(PG, gm, gl, ETP, wave - 4, lane, true);
+        gate_partial_x3<MT, NT>(gm, gl, st, ax.wg0H, ax.wg0L, mt0, lane);
+        if (NW == 4) {               // four partials = the four slots vec_finish sums: no fold needed
+            put_gate_partial<NT>(PG, gm, gl, ETP, wave, lane, false);
+        } else {
+            if (wave < 4) put_gate_partial<NT>(PG, gm, gl, ETP, wave, lane, false);
+            __syncthreads();
+            if (wave >= 4) put_gate_partial<NT>(PG, gm, gl, ETP, wave - 4, lane, true);
+        }
         STAMP(6);
     }
     __syncthreads();
     STAMP(7);
     // ---- P3: state images + vector part of msg0 ---------------------------------------------------------------------------
-    over |= store_state_x3<1, 2>(XH, XL, 0, st, ETP, mt0, lane);
+    over |= store_state_x3<MT, NT>(XH, XL, 0, st, ETP, mt0, lane);
     vec_finish<ET, H0, EK_THREADS>(PG, a.bg0, a.wup0, GCDM_V, VH, e, part, [&](int c, float ox, float oy, float oz) {
         VV[(c * 3 + 0) * ETP + e] = ox;
         VV[(c * 3 + 1) * ETP + e] = oy;
@@ -439,40 +453,50 @@ __global__ __launch_bounds__(512) void k_edge_msg_x3(EdgeMsgX3Args ax) {
         if (k == 0) STAMP(10);
         __syncthreads();
         if (k == 0) STAMP(11);
-        acc_init_bias<1, 2>(am, w.b, mt0, lane);
+        acc_init_bias<MT, NT>(am, w.b, mt0, lane);
 #pragma unroll
-        for (int n = 0; n < 2; ++n)
+        for (int m = 0; m < MT; ++m)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) al2[0][n][r] = 0.f;
+            for (int n = 0; n < NT; ++n)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) al2[m][n][r] = 0.f;
         if (k == 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); STAMP(21); }
-        tile_gemm_x3<1, 2, PD>(am, al2, ring, ax.wH[k] + (size_t)mt0 * ax.KB * 64, ax.wL[k] + (size_t)mt0 * ax.KB * 64, ax.KB, xh8, xl8, ETP, lane);
+        tile_gemm_x3<MT, NT, PD>(am, al2, ring, ax.wH[k] + (size_t)mt0 * ax.KB * 64, ax.wL[k] + (size_t)mt0 * ax.KB * 64, ax.KB, xh8, xl8, ETP, lane);
         if (k == 0) STAMP(22);
-        if (k < 2) x3_prefetch<1, PD>(ring, ax.wH[k + 1] + (size_t)mt0 * ax.KB * 64, ax.wL[k + 1] + (size_t)mt0 * ax.KB * 64, ax.KB, lane);
+        if (k < 2) x3_prefetch<MT, PD>(ring, ax.wH[k + 1] + (size_t)mt0 * ax.KB * 64, ax.wL[k + 1] + (size_t)mt0 * ax.KB * 64, ax.KB, lane);
         if (k == 0) STAMP(12);
 #pragma unroll
-        for (int n = 0; n < 2; ++n)
+        for (int m = 0; m < MT; ++m)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) am[0][n][r] = fast_silu(am[0][n][r] + al2[0][n][r] * X3_INV_SCALE);
+            for (int n = 0; n < NT; ++n)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) am[m][n][r] = fast_silu(am[m][n][r] + al2[m][n][r] * X3_INV_SCALE);
         if (k == 0) STAMP(13);
 #pragma unroll
-        for (int n = 0; n < 2; ++n)
+        for (int n = 0; n < NT; ++n)
 #pragma unroll
             for (int r = 0; r < 16; ++r) { gm[n][r] = 0.f; gl[n][r] = 0.f; }
-        gate_partial_x3<1, 2>(gm, gl, am, ax.wgH[k], ax.wgL[k], mt0, lane);
-        if (wave < 4) put_gate_partial<2>(PG, gm, gl, ETP, wave, lane, false);
-        __syncthreads();
-        if (wave >= 4) put_gate_partial<2>(PG, gm, gl, ETP, wave - 4, lane, true);
+        gate_partial_x3<MT, NT>(gm, gl, am, ax.wgH[k], ax.wgL[k], mt0, lane);
+        if (NW == 4) {
+            put_gate_partial<NT>(PG, gm, gl, ETP, wave, lane, false);
+        } else {
+            if (wave < 4) put_gate_partial<NT>(PG, gm, gl, ETP, wave, lane, false);
+            __syncthreads();
+            if (wave >= 4) put_gate_partial<NT>(PG, gm, gl, ETP, wave - 4, lane, true);
+        }
         if (k == 0) STAMP(14);
         __syncthreads();                 // every wave is done reading the old XH8 / XL8 images
         if (k == 0) STAMP(15);
 #pragma unroll
-        for (int n = 0; n < 2; ++n)
+        for (int m = 0; m < MT; ++m)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) st[0][n][r] += am[0][n][r];       // residual add in fp32 (gcpnet.py:701)
+            for (int n = 0; n < NT; ++n)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) st[m][n][r] += am[m][n][r];       // residual add in fp32 (gcpnet.py:701)
         if (k < 2) {
-            over |= store_state_x3<1, 2>(XH, XL, 0, st, ETP, mt0, lane);
+            over |= store_state_x3<MT, NT>(XH, XL, 0, st, ETP, mt0, lane);
         } else {                          // last GCP2: fp32 image for attention + segment sums (aliases XH8 / XL8)
-            store_state<1, 2, false>(XS4, 0, st, ETP, mt0, lane, 0);
+            store_state<MT, NT, false>(XS4, 0, st, ETP, mt0, lane, 0);
         }
         vec_finish<ET, 8, EK_THREADS>(PG, w.bg, w.wup, GCDM_V, VH, e, part, [&](int c, float ox, float oy, float oz) {
             VV[(c * 3 + 0) * ETP + e] += ox;

@@ -105,6 +105,23 @@ def test_forward_matches_oracle_ragged(case, num_nodes, mode):
     assert (out - ref).abs().max().item() <= TOL * scale
 
 
+@pytest.mark.parametrize("mode", MODES)
+@pytest.mark.parametrize("case,num_nodes", [("qm9", [29] * 7 + [3]), ("geom", [181, 3, 90])])
+def test_forward_32_edge_tiles(case, num_nodes, mode):
+    """The 32-edge tiling of the edge-message kernels (option "edge_tile"; two workgroups per CU) gives the same result."""
+    d = _dims(case)
+    net, W, _ = _net(case, seed=23, scale=0.5, mode=mode)
+    lib, h = net._lib, net._handle
+    assert lib.gcdm_set_option(h, b"edge_tile", 32) == 0 and lib.gcdm_get_option(h, b"edge_tile") == 32
+    xh, t, bi, nn_, ctx = synth.make_inputs(num_nodes, synth.dims_feat(d), seed=31, t_value=0.63, n_ctx=d["n_ctx"])
+    ref = O.dynamics_forward(W, _ocfg(case), xh, t, bi, None, ctx)
+    out = _fwd(net, xh, t, bi, ctx)
+    assert (out - ref).abs().max().item() <= TOL * max(1.0, ref.abs().max().item())
+    assert lib.gcdm_set_option(h, b"edge_tile", 64) == 0
+    out64 = _fwd(net, xh, t, bi, ctx)
+    assert (out - out64).abs().max().item() <= TOL * max(1.0, ref.abs().max().item())
+
+
 def test_f16_range_flag_and_fp32_fallback():
     """Activations beyond the f16 range: the split-precision kernel raises GCDM_FLAG_F16_RANGE and the module-level call
     transparently recomputes with fp32 MFMA (bit-identical to fp32 mode)."""
