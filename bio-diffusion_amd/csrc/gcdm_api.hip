@@ -342,8 +342,8 @@ int gcdm_create(const GcdmConfig* cfg, gcdm_handle** out) {
     if (const char* mm = getenv("GCDM_MFMA")) h->mfma_x3 = (std::strcmp(mm, "f16x3") == 0) ? 1 : 0;
     if (h->mfma_x3) h->edge_tile = 64;
     HIP_OK(h, hipSetDevice(cfg->device));
-    HIP_OK(h, hipMalloc(&h->d_flags, sizeof(uint32_t)));
-    HIP_OK(h, hipMemset(h->d_flags, 0, sizeof(uint32_t)));
+    HIP_OK(h, hipMalloc(&h->d_flags, 4 * sizeof(uint32_t)));            // [0] flag word, [1..2] statistics of gcdm_encode_samples
+    HIP_OK(h, hipMemset(h->d_flags, 0, 4 * sizeof(uint32_t)));
     return 0;
 }
 
@@ -737,6 +737,21 @@ int gcdm_sample_init(gcdm_handle* h, float* z, const float* noise, uint64_t seed
     return launch_sample(h, sa, (hipStream_t)stream_);
 }
 
+int gcdm_encode_samples(gcdm_handle* h, const float* xh, float* z, uint32_t* flags, void* stream_) {
+    if (!h || !xh || !z || !h->N) return fail(h, "gcdm_encode_samples: bad argument / no plan");
+    hipStream_t st = (hipStream_t)stream_;
+    HIP_OK(h, hipMemsetAsync(h->d_flags + 1, 0, 2 * sizeof(uint32_t), st));
+    EncodeArgs ea{};
+    ea.xh = xh; ea.z = z; ea.noff = h->d_noff; ea.D = h->D; ea.num_atom_types = h->cfg.num_atom_types; ea.include_charges = h->cfg.include_charges;
+    ea.nv0 = h->cfg.norm_values[0]; ea.nv1 = h->cfg.norm_values[1]; ea.nv2 = h->cfg.norm_values[2];
+    ea.nb1 = h->cfg.norm_biases[1]; ea.nb2 = h->cfg.norm_biases[2];
+    ea.stat = h->d_flags + 1;
+    hipLaunchKernelGGL(k_encode, dim3(h->B), dim3(64), 0, st, ea);
+    if (flags) hipLaunchKernelGGL(k_mean_flag, dim3(1), dim3(1), 0, st, h->d_flags + 1, flags);
+    HIP_OK(h, hipGetLastError());
+    return 0;
+}
+
 static int fill_t(gcdm_handle* h, float value, hipStream_t st) {
     hipLaunchKernelGGL(k_fill, dim3((h->N + 255) / 256), dim3(256), 0, st, h->TBUF, h->N, value);
     HIP_OK(h, hipGetLastError());
@@ -796,12 +811,10 @@ int gcdm_set_option(gcdm_handle* h, const char* name, int32_t value) {
     if (k == "mfma_mode") {                 // 0: fp32 MFMA, 1: split-precision f16 x3 (fp32-equivalent, 5.3x the matrix rate)
         if (value != 0 && value != 1) return fail(h, "gcdm_set_option(mfma_mode): 0 or 1");
         h->mfma_x3 = value;
-        if (value) h->edge_tile = 64;
         return 0;
     }
     if (k == "edge_tile") {
         if (value != 32 && value != 64) return fail(h, "gcdm_set_option(edge_tile): 32 or 64");
-        if (h->mfma_x3 && value != 64) return fail(h, "gcdm_set_option(edge_tile): the split-precision kernel uses 64-edge tiles");
         h->edge_tile = value;
         return 0;
     }

@@ -1029,6 +1029,44 @@ __global__ __launch_bounds__(64) void k_cog_fix(float* out, const int* noff, int
     }
 }
 
+// normalize (variational_diffusion.py:702-732) of caller-supplied samples [x | one-hot | charge] into z, plus the statistics of
+// assert_mean_zero_with_mask (:465-474): stat[0] = max_b |sum_i z_x|, stat[1] = max |z_x| (as float bit patterns: both >= 0).
+struct EncodeArgs {
+    const float* xh; float* z; const int* noff; int D, num_atom_types, include_charges;
+    float nv0, nv1, nv2, nb1, nb2;
+    uint32_t* stat;
+};
+
+__global__ __launch_bounds__(64) void k_encode(EncodeArgs a) {
+    const int b = blockIdx.x, o = a.noff[b], n = a.noff[b + 1] - o, D = a.D;
+    float s[3] = {0.f, 0.f, 0.f}, mx = 0.f;
+    for (int idx = threadIdx.x; idx < n * D; idx += 64) {
+        const int i = idx / D, c = idx - i * D;
+        const size_t gi = (size_t)(o + i) * D + c;
+        const float v = a.xh[gi];
+        float r;
+        if (c < 3) { r = v / a.nv0; mx = fmaxf(mx, fabsf(r)); s[c] += r; }
+        else if (c < 3 + a.num_atom_types) r = (v - a.nb1) / a.nv1;
+        else r = (v - a.nb2) / a.nv2;
+        a.z[gi] = r;
+    }
+    // D is not a multiple of 3 in general, so a lane sees all three coordinates: reduce each over the wave
+#pragma unroll
+    for (int sh = 32; sh > 0; sh >>= 1) {
+        s[0] += __shfl_xor(s[0], sh); s[1] += __shfl_xor(s[1], sh); s[2] += __shfl_xor(s[2], sh);
+        mx = fmaxf(mx, __shfl_xor(mx, sh));
+    }
+    if (threadIdx.x == 0) {
+        atomicMax(a.stat, __float_as_uint(fmaxf(fabsf(s[0]), fmaxf(fabsf(s[1]), fabsf(s[2])))));
+        atomicMax(a.stat + 1, __float_as_uint(mx));
+    }
+}
+
+__global__ void k_mean_flag(const uint32_t* stat, uint32_t* user_flags) {
+    const float err = __uint_as_float(stat[0]), largest = __uint_as_float(stat[1]);
+    if (!(err / (largest + 1e-10f) < 1e-2f)) atomicOr(user_flags, 2u);      // GCDM_FLAG_MEAN_NOT_ZERO
+}
+
 __global__ __launch_bounds__(64) void k_sample(StepArgs a) {
     extern __shared__ __attribute__((aligned(16))) float ns[];  // [n][D] noise, then results
     const int b = blockIdx.x, o = a.noff[b], n = a.noff[b + 1] - o, D = a.D;

@@ -166,6 +166,27 @@ class _MoleculeGenerationDDPM(nn.Module):
 
 
     @torch.inference_mode()
+    def optimize(self, samples: List[Tuple[torch.Tensor, torch.Tensor]], num_timesteps: int, num_nodes: torch.Tensor,
+                 context: Optional[torch.Tensor], node_mask: Optional[torch.Tensor] = None, return_frames: int = 1,
+                 norm_with_original_timesteps: bool = False, **kw) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor]:
+        """qm9_mol_gen_ddpm.py:636-743 without the chain visualisation: property-guided optimisation of existing samples."""
+        if not self.condition_on_context:
+            raise Exception("Optimization requires a context conditional to optimize (e.g., `alpha`).")
+        if context is None:
+            if self.props_distr is None:
+                raise ValueError("context required (no props_distr attached)")
+            context = self.props_distr.sample_batch(num_nodes)
+        if return_frames != 1:
+            raise NotImplementedError("chain visualisation (return_frames > 1) is not built")
+        xh, batch_index, _ = self.ddpm.mol_gen_optimize(samples=samples, num_nodes=num_nodes, node_mask=node_mask, context=context,
+                                                        device=self.device, num_timesteps=num_timesteps, return_frames=return_frames,
+                                                        norm_with_original_timesteps=norm_with_original_timesteps, **kw)
+        x = xh[:, : self.num_x_dims]
+        one_hot = xh[:, self.num_x_dims:-1] if self.include_charges else xh[:, self.num_x_dims:]
+        charges = xh[:, -1:] if self.include_charges else torch.zeros(0, device=self.device)
+        return x, one_hot, charges, batch_index
+
+    @torch.inference_mode()
     def sample_and_analyze(self, num_samples: int, node_mask: Optional[torch.Tensor] = None, context: Optional[torch.Tensor] = None,
                            batch_size: Optional[int] = None, max_num_nodes: Optional[int] = 100, num_timesteps: Optional[int] = None,
                            **kw) -> Dict[str, Any]:

@@ -18,7 +18,7 @@ from __future__ import annotations
 
 import ctypes as C
 import logging
-from typing import Any, Callable, Dict, Optional, Tuple, Union
+from typing import Any, Callable, Dict, List, Optional, Tuple, Union
 
 import numpy as np
 import torch
@@ -219,14 +219,19 @@ class EquivariantVariationalDiffusion(nn.Module):
                        context: Optional[torch.Tensor] = None, fix_noise: bool = False, generate_x_only: bool = False,
                        fix_self_conditioning_noise: bool = False, norm_with_original_timesteps: bool = False,
                        noise_fn: Optional[Callable[[int], torch.Tensor]] = None, seed: int = 1234,
-                       step_callback: Optional[Callable[[int, torch.Tensor], None]] = None, _retry_fp32: bool = False
+                       step_callback: Optional[Callable[[int, torch.Tensor], None]] = None, _retry_fp32: bool = False,
+                       _init_xh: Optional[torch.Tensor] = None, _t_norm: Optional[int] = None
                        ) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
         """Draw samples.  ``noise_fn(k)`` (optional) returns the k-th raw standard-normal draw [N,3+F] on ``device``
         (k = 0 for z_T, then one per step, then one for the final decode: the reference's randn call order,
         SURVEY A.5); without it noise comes from on-device Philox(seed)."""
-        if return_frames != 1 or fix_noise or generate_x_only or norm_with_original_timesteps:
+        if return_frames != 1 or fix_noise or generate_x_only:
             raise NotImplementedError("mol_gen_sample (HIP): return_frames>1 / fix_noise / generate_x_only are not built")
         num_timesteps = self.T if num_timesteps is None else num_timesteps
+        # time normalisation of the loop (:1333-1341): s / T_norm with T_norm = self.T if norm_with_original_timesteps else num_timesteps
+        t_norm = _t_norm if _t_norm is not None else (self.T if norm_with_original_timesteps else num_timesteps)
+        if num_timesteps > t_norm:
+            raise ValueError("num_timesteps exceeds the normalising number of timesteps")
         device = torch.device(device)
         dyn, lib, h = self._native(device)
         num_nodes = torch.as_tensor(num_nodes)
@@ -259,11 +264,18 @@ class EquivariantVariationalDiffusion(nn.Module):
             k += 1
             return nz, C.c_void_p(nz.data_ptr())
 
-        keep, p = nptr()
-        _native.check(lib, h, lib.gcdm_sample_init(h, C.c_void_p(z.data_ptr()), p, C.c_uint64(seed), stream), "gcdm_sample_init")
+        if _init_xh is None:
+            keep, p = nptr()
+            _native.check(lib, h, lib.gcdm_sample_init(h, C.c_void_p(z.data_ptr()), p, C.c_uint64(seed), stream), "gcdm_sample_init")
+        else:                                # optimisation loop: z = normalize(samples) (:1451-1464), no initial draw
+            xin = _init_xh.to(device, torch.float32).contiguous()
+            if xin.shape != (N, D):
+                raise ValueError(f"samples have shape {tuple(xin.shape)}, expected {(N, D)}")
+            _native.check(lib, h, lib.gcdm_encode_samples(h, C.c_void_p(xin.data_ptr()), C.c_void_p(z.data_ptr()), fptr, stream),
+                          "gcdm_encode_samples")
         for s in reversed(range(0, num_timesteps)):
             keep, p = nptr()
-            st = lib.gcdm_sample_step(h, C.c_void_p(z.data_ptr()), ctx_ptr, s, num_timesteps, p, C.c_uint64(seed), fptr, stream)
+            st = lib.gcdm_sample_step(h, C.c_void_p(z.data_ptr()), ctx_ptr, s, t_norm, p, C.c_uint64(seed), fptr, stream)
             _native.check(lib, h, st, "gcdm_sample_step")
             if step_callback is not None:
                 step_callback(s, z)
@@ -279,12 +291,36 @@ class EquivariantVariationalDiffusion(nn.Module):
             try:
                 return self.mol_gen_sample(num_samples, num_nodes, device, return_frames, num_timesteps, None, context_in, fix_noise,
                                            generate_x_only, fix_self_conditioning_noise, norm_with_original_timesteps,
-                                           noise_fn=noise_fn, seed=seed, step_callback=step_callback, _retry_fp32=True)
+                                           noise_fn=noise_fn, seed=seed, step_callback=step_callback, _retry_fp32=True,
+                                           _init_xh=_init_xh, _t_norm=t_norm)
             finally:
                 dyn.set_mfma_mode(1)
+        if fl & _native.FLAG_MEAN_NOT_ZERO:
+            raise AssertionError("Mean is not zero: the supplied samples are not centred (assert_mean_zero_with_mask, relative error >= 1e-2)")
         if fl & _native.FLAG_NAN_VEL:
             log.warning("Detected NaN in `vel` -> GCPNet `vel` output was reset to zero for at least one time step.")
         if fl & _native.FLAG_COG_DRIFT:
             log.warning("CoG drift above 5e-2. Projected the positions down.")
         self.last_flags = fl
         return out, batch_index, node_mask
+
+    @torch.inference_mode()
+    def mol_gen_optimize(self, samples: List[Tuple[torch.Tensor, torch.Tensor]], num_nodes: torch.Tensor, device: Union[torch.device, str],
+                         return_frames: int = 1, num_timesteps: Optional[int] = None, node_mask: Optional[torch.Tensor] = None,
+                         context: Optional[torch.Tensor] = None, generate_x_only: bool = False, norm_with_original_timesteps: bool = False,
+                         noise_fn: Optional[Callable[[int], torch.Tensor]] = None, seed: int = 1234
+                         ) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+        """Optimise existing samples with the generative model (variational_diffusion.py:1416-1546): the samples
+        ``[(x [n,3], one_hot [n,F]), ...]`` are normalised and taken as z at t = num_timesteps / T_norm, denoised for ``num_timesteps``
+        steps and decoded.  As in the reference z carries no charge column (``"integer": torch.tensor([])``, :1457), so the model must
+        have ``include_charges=False`` (the property-conditional QM9 models).  ``noise_fn(k)``: k = 0 is the first step's draw."""
+        if return_frames != 1 or generate_x_only:
+            raise NotImplementedError("mol_gen_optimize (HIP): return_frames>1 / generate_x_only are not built")
+        if self.include_charges:
+            raise NotImplementedError("mol_gen_optimize builds z without the charge column (reference :1457): include_charges must be False")
+        if len(samples) != len(num_nodes):
+            raise ValueError("one (x, h) pair per molecule")
+        xh = torch.cat([torch.cat((x.to(torch.float32), h.to(torch.float32)), dim=-1) for x, h in samples], dim=0)
+        return self.mol_gen_sample(num_samples=len(samples), num_nodes=num_nodes, device=device, num_timesteps=num_timesteps,
+                                   node_mask=node_mask, context=context, norm_with_original_timesteps=norm_with_original_timesteps,
+                                   noise_fn=noise_fn, seed=seed, _init_xh=xh)

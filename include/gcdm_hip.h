@@ -97,6 +97,13 @@ int gcdm_sample_final(gcdm_handle* h, const float* z0, const float* context, con
 /* Draws z_T (variational_diffusion.py:795-819) into z [N,3+F] from `noise` (device) or Philox(seed). */
 int gcdm_sample_init(gcdm_handle* h, float* z, const float* noise, uint64_t seed, void* stream);
 
+/* Start of the optimisation loop (mol_gen_optimize, variational_diffusion.py:1451-1464): z = normalize(xh) (:702-732) for caller-supplied
+ * samples xh [N,3+F] = [x | one-hot | charge] (device), and the reference's assert_mean_zero_with_mask (:465-474) on the positions:
+ * GCDM_FLAG_MEAN_NOT_ZERO is OR-ed into `flags` (device, may be NULL) when max_b|sum_i x| / (max|x| + 1e-10) >= 1e-2.
+ * The loop itself is gcdm_sample_step for s = num_timesteps-1 .. 0 (num_steps = T for norm_with_original_timesteps, else
+ * num_timesteps) followed by gcdm_sample_final. */
+int gcdm_encode_samples(gcdm_handle* h, const float* xh, float* z, uint32_t* flags, void* stream);
+
 /* Introspection for the parity tests: copies an internal buffer of the LAST forward to host (synchronises).
  * names: "h","chi","x","agg","ep","alpha","frames","pq","hin","fbar","chi0".  Returns number of floats written
  * (or needed if host_out is NULL), <0 on error.  Layouts are documented in DESIGN.md. */
@@ -107,7 +114,8 @@ int gcdm_debug_set_layer_limit(gcdm_handle* h, int32_t num_layers_to_run);
 /* Options.  "mfma_mode": 1 (default; env GCDM_MFMA=f16x3) evaluates the per-edge contractions with three f16 MFMAs per product
  * block on operands split as x = hi + 2^-11 lo' (fp32-equivalent accuracy; raises GCDM_FLAG_F16_RANGE if an
  * activation exceeds 6e4, in which case the caller must re-run with mode 0); 0 (env GCDM_MFMA=f32) uses fp32 MFMA throughout.
- * "edge_tile": 64 (default) or 32 edges per workgroup of the fp32 edge kernel. */
+ * "edge_tile": 64 (default) or 32 edges per workgroup of the edge-message kernels (env GCDM_EDGE_TILE; 32 = two workgroups per CU,
+ * same throughput on MI355X -- DESIGN.md 3.4). */
 int gcdm_set_option(gcdm_handle* h, const char* name, int32_t value);
 int gcdm_get_option(const gcdm_handle* h, const char* name);
 

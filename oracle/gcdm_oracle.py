@@ -403,6 +403,47 @@ def mol_gen_sample(P: Params, cfg: OracleConfig, num_nodes: Tensor, noise, conte
     return torch.cat(parts, dim=-1), bi
 
 
+def normalize(cfg: OracleConfig, x: Tensor, h_cat: Tensor, mask: Tensor) -> Tuple[Tensor, Tensor]:
+    """EquivariantVariationalDiffusion.normalize, variational_diffusion.py:702-732 (x and the categorical part)."""
+    nv, nb = cfg.norm_values, cfg.norm_biases
+    return x / nv[0], (h_cat.to(x.dtype) - nb[1]) / nv[1] * mask.to(x.dtype)[:, None]
+
+
+def assert_mean_zero_with_mask(x: Tensor, batch_index: Tensor, B: int, eps: float = 1e-10) -> float:
+    """variational_diffusion.py:465-474: relative CoM error of the whole batch (the reference asserts < 1e-2)."""
+    largest = x.abs().max().item()
+    err = torch.zeros(B, x.shape[1], dtype=x.dtype).index_add_(0, batch_index, x).abs().max().item()
+    return err / (largest + eps)
+
+
+def mol_gen_optimize(P: Params, cfg: OracleConfig, x: Tensor, h_cat: Tensor, num_nodes: Tensor, noise,
+                     context: Optional[Tensor] = None, num_timesteps: Optional[int] = None,
+                     norm_with_original_timesteps: bool = False, dtype=torch.float32) -> Tuple[Tensor, Tensor]:
+    """EquivariantVariationalDiffusion.mol_gen_optimize, variational_diffusion.py:1416-1546 (return_frames=1, no self-conditioning):
+    the given samples are normalised and used as z at t = num_timesteps / T_norm, then denoised for num_timesteps steps and decoded.
+    As in the reference the charge column is not part of z (`"integer": torch.tensor([])`, :1457), so include_charges must be False."""
+    assert not cfg.include_charges
+    T = cfg.num_timesteps if num_timesteps is None else num_timesteps
+    Tn = cfg.num_timesteps if norm_with_original_timesteps else T
+    B = len(num_nodes)
+    bi = num_nodes_to_batch_index(num_nodes)
+    mask = torch.ones_like(bi).bool()
+    ctx = None
+    if context is not None:
+        ctx = context.to(dtype)[bi] * mask.to(dtype)[:, None]
+    gam = gamma_table(cfg)
+    xn, hn = normalize(cfg, x.to(dtype), h_cat, mask)
+    z = torch.cat((xn, hn), dim=-1)
+    assert assert_mean_zero_with_mask(z[:, :3], bi, B) < 1e-2                       # :1464
+    for s in reversed(range(T)):
+        z, _ = sample_p_zs_given_zt(P, cfg, gam, s / Tn, (s + 1) / Tn, z, bi, B, mask, ctx, noise)
+    xo, one_hot, charges = sample_p_xh_given_z0(P, cfg, gam, z, bi, B, mask, ctx, noise)
+    cog = torch.zeros(B, 3, dtype=dtype).index_add_(0, bi, xo).abs().max().item()
+    if cog > 5e-2:                                                                  # :1527-1537
+        xo = centralize(xo, bi, B, mask)
+    return torch.cat((xo, one_hot.to(dtype)), dim=-1), bi
+
+
 # ------------------------------------------------------------------------------------------------
 # algorithmic FLOP count (SURVEY A.4) -- used by bench.py for the roofline line
 # ------------------------------------------------------------------------------------------------

@@ -237,6 +237,48 @@ def test_free_running_sampling_short(case):
     assert (ddpm.last_flags & 1) == 0
 
 
+@pytest.mark.parametrize("orig", [False, True])
+def test_mol_gen_optimize_matches_oracle(orig):
+    """Property-guided optimisation loop (variational_diffusion.py:1416-1546; oracle pinned by tests/golden/optimize_small_qm9cond.npz):
+    normalize -> T' steps -> decode on the alpha-conditional QM9 model, both time normalisations, same noise tape."""
+    d = _dims("qm9cond")
+    net, W, cfgs = _net("qm9cond", seed=47, scale=0.25)
+    ocfg = _ocfg("qm9cond")
+    model_ddpm = pkg.EquivariantVariationalDiffusion(net, cfgs["diffusion_cfg"], cfgs["dataloader_cfg"], pkg.dataset_info("qm9")).cuda()
+    nn_ = torch.tensor([7, 19, 4, 12])
+    B, N, F = len(nn_), int(nn_.sum()), ocfg.num_node_scalar_features
+    g = torch.Generator().manual_seed(9)
+    ctx_b = torch.randn((B, 1), generator=g)
+    samples = []
+    for n in nn_.tolist():
+        x = torch.randn((n, 3), generator=g) * 1.2
+        x = x - x.mean(0, keepdim=True)
+        samples.append((x, torch.nn.functional.one_hot(torch.randint(0, F, (n,), generator=g), F).float()))
+    Tp = 9
+    X, Hc = torch.cat([s_[0] for s_ in samples]), torch.cat([s_[1] for s_ in samples])
+    want, bi = O.mol_gen_optimize(W, ocfg, X, Hc, nn_, O.TapeNoise(77), context=ctx_b, num_timesteps=Tp, norm_with_original_timesteps=orig)
+    tape = O.TapeNoise(77)
+    draws = [torch.cat((tape(N, 3), tape(N, F)), dim=-1) for _ in range(Tp + 1)]
+    out, bi2, _ = model_ddpm.mol_gen_optimize(samples=[(x.cuda(), h_.cuda()) for x, h_ in samples], num_nodes=nn_, device="cuda", num_timesteps=Tp,
+                                              context=ctx_b.cuda(), norm_with_original_timesteps=orig, noise_fn=lambda k: draws[k])
+    out = out.cpu()
+    assert torch.equal(bi2.cpu(), bi)
+    scale = max(1.0, want[:, :3].abs().max().item())
+    assert (out[:, :3] - want[:, :3]).abs().max().item() <= TOL * scale
+    assert torch.equal(out[:, 3:], want[:, 3:])
+    # un-centred input: the reference's assert_mean_zero_with_mask
+    bad = [(x.cuda() + 0.5, h_.cuda()) for x, h_ in samples]
+    with pytest.raises(AssertionError):
+        model_ddpm.mol_gen_optimize(samples=bad, num_nodes=nn_, device="cuda", num_timesteps=2, context=ctx_b.cuda())
+    # the whole-model stand-in
+    model = pkg.QM9MoleculeGenerationDDPM(**cfgs)
+    model.ddpm.dynamics_network.load_state_dict(W)
+    model = model.cuda()
+    x2, oh2, ch2, bi3 = model.optimize(samples=[(x.cuda(), h_.cuda()) for x, h_ in samples], num_timesteps=Tp, num_nodes=nn_, context=ctx_b.cuda(),
+                                       norm_with_original_timesteps=orig, noise_fn=lambda k: draws[k])
+    assert (x2.cpu() - want[:, :3]).abs().max().item() <= TOL * scale and torch.equal(oh2.cpu(), want[:, 3:]) and ch2.numel() == 0
+
+
 def test_philox_noise_statistics_and_determinism():
     net, W, cfgs = _net("qm9", seed=45, scale=0.25)
     ddpm = pkg.EquivariantVariationalDiffusion(net, cfgs["diffusion_cfg"], cfgs["dataloader_cfg"], pkg.dataset_info("qm9")).cuda()

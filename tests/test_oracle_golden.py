@@ -115,6 +115,23 @@ def test_schedule_and_sampler_small(golden_dir, case):
     assert torch.equal(out[:, 3:], ref[:, 3:])
 
 
+def test_mol_gen_optimize_small(golden_dir):
+    """Property-guided optimisation loop (variational_diffusion.py:1416-1546) vs the reference's own outputs, both time normalisations."""
+    gw = load(golden_dir, "sampler_small_qm9cond")          # same reduced-width weights (weight seed 4)
+    g = load(golden_dir, "optimize_small_qm9cond")
+    P = weights_of(gw)
+    assert torch.equal(P["gcp_embedding.edge_embedding.vector_down.weight"], g["weight_check"])     # first state-dict entry of the same model
+    cfg = cfg_for("qm9cond", O.infer_num_layers(P))
+    for tag in ("a", "b"):
+        out, _ = O.mol_gen_optimize(P, cfg, g["x"], g["h"], g["num_nodes"], O.TapeNoise(int(g["noise_seed"])), context=g["ctx"],
+                                    num_timesteps=int(g[f"{tag}_T"]), norm_with_original_timesteps=bool(int(g[f"{tag}_orig"])))
+        ref = g[f"{tag}_out"]
+        assert (out[:, :3] - ref[:, :3]).abs().max().item() <= 1e-4 * max(1.0, ref[:, :3].abs().max().item())
+        assert torch.equal(out[:, 3:], ref[:, 3:])
+    # the two normalisations really are different trajectories
+    assert (g["a_out"][:, :3] - g["b_out"][:, :3]).abs().max().item() > 1e-3
+
+
 @pytest.mark.parametrize("case", CASES)
 def test_dynamics_full_width(golden_dir, case):
     """Full-width production architecture; weights re-created from the seed recipe (tests/synth.py)."""
