@@ -57,8 +57,14 @@ def build(force: bool = False) -> str:
     if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in deps):
         return LIB_PATH
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-o", LIB_PATH] + SOURCES
-    subprocess.run(cmd, check=True)
+    tmp = f"{LIB_PATH}.{os.getpid()}.tmp"          # concurrent builders (one per rank) never see a half-written library
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-o", tmp] + SOURCES
+    try:
+        subprocess.run(cmd, check=True)
+        os.replace(tmp, LIB_PATH)
+    finally:
+        if os.path.exists(tmp):
+            os.remove(tmp)
     return LIB_PATH
 
 

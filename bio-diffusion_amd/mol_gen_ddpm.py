@@ -11,6 +11,7 @@ molecule and hands them to an optional ``molecule_builder`` (the reference's ``b
 from __future__ import annotations
 
 import io
+import os
 import pickle
 from typing import Any, Callable, Dict, List, Optional, Tuple
 
@@ -21,6 +22,7 @@ from torch import nn
 from .config import cfg_get, dataset_info as _dataset_info
 from .gcpnet import GCPNetDynamics
 from .stability import CategoricalDistribution, check_molecular_stability_batch
+from .xyz import save_xyz_file
 from .variational_diffusion import EquivariantVariationalDiffusion
 
 
@@ -164,6 +166,18 @@ class _MoleculeGenerationDDPM(nn.Module):
             o += n
         return mols
 
+
+    @torch.inference_mode()
+    def sample_and_save(self, num_samples: int, num_nodes: Optional[torch.Tensor] = None, node_mask: Optional[torch.Tensor] = None,
+                        context: Optional[torch.Tensor] = None, num_timesteps: Optional[int] = None, id_from: int = 0,
+                        name: str = "molecule", sampling_output_dir: Optional[str] = None,
+                        norm_with_original_timesteps: bool = False, **kw) -> None:
+        """qm9_mol_gen_ddpm.py:887-947 without the matplotlib / wandb visualisation: sample, write one XYZ file per molecule."""
+        x, one_hot, charges, batch_index = self.sample(num_samples, num_nodes=num_nodes, node_mask=node_mask, context=context,
+                                                       num_timesteps=num_timesteps, norm_with_original_timesteps=norm_with_original_timesteps, **kw)
+        out_dir = str(sampling_output_dir) if sampling_output_dir is not None else os.path.join("sampling_output", "epoch_0")
+        save_xyz_file(path=out_dir + "/", positions=x, one_hot=one_hot, charges=charges, dataset_info=self.dataset_info,
+                      id_from=id_from, name=name, batch_index=batch_index)
 
     @torch.inference_mode()
     def optimize(self, samples: List[Tuple[torch.Tensor, torch.Tensor]], num_timesteps: int, num_nodes: torch.Tensor,

@@ -143,3 +143,19 @@ def test_mfma_operand_mapping_of_the_packing():
         for q in range(4):
             ch = [(r & 3) + 8 * (r >> 2) + 4 * (lane >> 5) for r in range(4 * q, 4 * q + 4)]
             assert ch == list(range(4 * (2 * q + (lane >> 5)), 4 * (2 * q + (lane >> 5)) + 4))
+
+
+def test_xyz_writers_match_reference_files(tmp_path):
+    """save_xyz_file / write_xyz_file produce the reference's files byte for byte (tests/golden/xyz.npz, written by the reference)."""
+    g = np.load(os.path.join(ROOT, "tests", "golden", "xyz.npz"))
+    nn_ = torch.tensor(g["num_nodes"])
+    bi = torch.repeat_interleave(torch.arange(len(nn_)), nn_)
+    d = str(tmp_path) + "/out/"
+    pkg.save_xyz_file(d, torch.tensor(g["pos"]), torch.tensor(g["one_hot"]), torch.zeros(0), pkg.dataset_info("qm9"), id_from=7, name="mol",
+                      batch_index=bi)
+    assert sorted(os.listdir(d)) == list(g["names"])
+    for nme, txt in zip(g["names"], g["texts"]):
+        assert open(os.path.join(d, str(nme))).read() == str(txt)
+    types = torch.tensor(g["one_hot"]).argmax(-1)
+    pkg.write_xyz_file(torch.tensor(g["pos"])[:3], types[:3], str(tmp_path) + "/single.xyz")
+    assert open(str(tmp_path) + "/single.xyz").read() == str(g["single"])
