@@ -61,6 +61,7 @@ struct gcdm_handle {
     float *X0 = nullptr, *XC = nullptr, *FBAR = nullptr, *CHI0 = nullptr, *HIN4 = nullptr, *H4 = nullptr, *CHI = nullptr, *PQ4 = nullptr,
           *VDI = nullptr, *VDJ = nullptr, *AGG = nullptr, *VEL = nullptr, *EPS = nullptr, *TBUF = nullptr, *EP4 = nullptr, *AL = nullptr, *U = nullptr, *FR = nullptr, *PROF = nullptr;
     uint32_t* d_flags = nullptr;
+    int cog_fix = 1;                 // gcdm_sample_final re-projects drifting centres of gravity (off for chain frames, reference :1389)
     int layer_limit = -1;
     int edge_tile = 64;              // 64: one 8-wave workgroup per CU; 32: two 4-wave workgroups per CU (env GCDM_EDGE_TILE)
     int mfma_x3 = 1;                 // 1: split-precision f16 x3 edge kernel (default; env GCDM_MFMA=f16x3|f32), 0: fp32 MFMA
@@ -799,8 +800,17 @@ int gcdm_sample_final(gcdm_handle* h, const float* z0, const float* context, con
     sa.nb1 = h->cfg.norm_biases[1]; sa.nb2 = h->cfg.norm_biases[2];
     sa.user_flags = flags; sa.flags_dev = h->d_flags;
     if (launch_sample(h, sa, st)) return -1;
-    // CoG drift re-projection is a whole-batch decision in the reference (:1389-1402)
-    hipLaunchKernelGGL(k_cog_fix, dim3(h->B), dim3(64), 0, st, out, h->d_noff, h->D, h->d_flags, flags);
+    // CoG drift re-projection is a whole-batch decision in the reference (:1389-1402); only "for examples without intermediate states"
+    if (h->cog_fix) hipLaunchKernelGGL(k_cog_fix, dim3(h->B), dim3(64), 0, st, out, h->d_noff, h->D, h->d_flags, flags);
+    HIP_OK(h, hipGetLastError());
+    return 0;
+}
+
+int gcdm_unnormalize_z(gcdm_handle* h, const float* z, float* out, void* stream_) {
+    if (!h || !z || !out || !h->N) return fail(h, "gcdm_unnormalize_z: bad argument / no plan");
+    const int total = h->N * h->D;
+    hipLaunchKernelGGL(k_unnormalize, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream_, z, out, h->N, h->D, h->cfg.num_atom_types,
+                       h->cfg.norm_values[0], h->cfg.norm_values[1], h->cfg.norm_values[2], h->cfg.norm_biases[1], h->cfg.norm_biases[2]);
     HIP_OK(h, hipGetLastError());
     return 0;
 }
@@ -813,6 +823,7 @@ int gcdm_set_option(gcdm_handle* h, const char* name, int32_t value) {
         h->mfma_x3 = value;
         return 0;
     }
+    if (k == "cog_fix") { h->cog_fix = value ? 1 : 0; return 0; }
     if (k == "edge_tile") {
         if (value != 32 && value != 64) return fail(h, "gcdm_set_option(edge_tile): 32 or 64");
         h->edge_tile = value;
@@ -826,6 +837,7 @@ int gcdm_get_option(const gcdm_handle* h, const char* name) {
     const std::string k(name);
     if (k == "mfma_mode") return h->mfma_x3;
     if (k == "edge_tile") return h->edge_tile;
+    if (k == "cog_fix") return h->cog_fix;
     return -1;
 }
 

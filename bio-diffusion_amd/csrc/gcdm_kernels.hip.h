@@ -1062,6 +1062,16 @@ __global__ __launch_bounds__(64) void k_encode(EncodeArgs a) {
     }
 }
 
+// unnormalize_z (variational_diffusion.py:735-792): continuous frame of the chain visualisation, no argmax / rounding
+__global__ __launch_bounds__(256) void k_unnormalize(const float* __restrict__ z, float* __restrict__ out, int N, int D, int num_atom_types,
+                                                     float nv0, float nv1, float nv2, float nb1, float nb2) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= N * D) return;
+    const int c = idx % D;
+    const float v = z[idx];
+    out[idx] = c < 3 ? v * nv0 : (c < 3 + num_atom_types ? v * nv1 + nb1 : v * nv2 + nb2);
+}
+
 __global__ void k_mean_flag(const uint32_t* stat, uint32_t* user_flags) {
     const float err = __uint_as_float(stat[0]), largest = __uint_as_float(stat[1]);
     if (!(err / (largest + 1e-10f) < 1e-2f)) atomicOr(user_flags, 2u);      // GCDM_FLAG_MEAN_NOT_ZERO

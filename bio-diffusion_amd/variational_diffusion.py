@@ -225,9 +225,11 @@ class EquivariantVariationalDiffusion(nn.Module):
         """Draw samples.  ``noise_fn(k)`` (optional) returns the k-th raw standard-normal draw [N,3+F] on ``device``
         (k = 0 for z_T, then one per step, then one for the final decode: the reference's randn call order,
         SURVEY A.5); without it noise comes from on-device Philox(seed)."""
-        if return_frames != 1 or fix_noise or generate_x_only:
-            raise NotImplementedError("mol_gen_sample (HIP): return_frames>1 / fix_noise / generate_x_only are not built")
+        if fix_noise or generate_x_only:
+            raise NotImplementedError("mol_gen_sample (HIP): fix_noise / generate_x_only are not built")
         num_timesteps = self.T if num_timesteps is None else num_timesteps
+        assert 0 < return_frames <= num_timesteps, "Number of frames cannot be greater than number of timesteps."
+        assert num_timesteps % return_frames == 0, "Number of frames must be evenly divisible by number of timesteps."
         # time normalisation of the loop (:1333-1341): s / T_norm with T_norm = self.T if norm_with_original_timesteps else num_timesteps
         t_norm = _t_norm if _t_norm is not None else (self.T if norm_with_original_timesteps else num_timesteps)
         if num_timesteps > t_norm:
@@ -252,7 +254,8 @@ class EquivariantVariationalDiffusion(nn.Module):
         flags = torch.zeros(1, dtype=torch.int32, device=device)
         fptr = C.c_void_p(flags.data_ptr())
         z = torch.empty((N, D), dtype=torch.float32, device=device)
-        out = torch.empty_like(z)
+        frames = torch.zeros((return_frames, N, D), dtype=torch.float32, device=device)     # frame 0 = the final sample (:1404-1410)
+        out = frames[0]
         k = 0
 
         def nptr():
@@ -277,10 +280,15 @@ class EquivariantVariationalDiffusion(nn.Module):
             keep, p = nptr()
             st = lib.gcdm_sample_step(h, C.c_void_p(z.data_ptr()), ctx_ptr, s, t_norm, p, C.c_uint64(seed), fptr, stream)
             _native.check(lib, h, st, "gcdm_sample_step")
+            if return_frames > 1 and (s * return_frames) % num_timesteps == 0:             # save frame (:1354-1361)
+                fr = frames[(s * return_frames) // num_timesteps]
+                _native.check(lib, h, lib.gcdm_unnormalize_z(h, C.c_void_p(z.data_ptr()), C.c_void_p(fr.data_ptr()), stream), "gcdm_unnormalize_z")
             if step_callback is not None:
                 step_callback(s, z)
         keep, p = nptr()
+        _native.check(lib, h, lib.gcdm_set_option(h, b"cog_fix", 1 if return_frames == 1 else 0), "gcdm_set_option")   # :1389
         st = lib.gcdm_sample_final(h, C.c_void_p(z.data_ptr()), ctx_ptr, p, C.c_uint64(seed), C.c_void_p(out.data_ptr()), fptr, stream)
+        lib.gcdm_set_option(h, b"cog_fix", 1)
         _native.check(lib, h, st, "gcdm_sample_final")
         fl = int(flags.item())   # the one host sync of the run
         if fl & _native.FLAG_F16_RANGE:
@@ -302,7 +310,7 @@ class EquivariantVariationalDiffusion(nn.Module):
         if fl & _native.FLAG_COG_DRIFT:
             log.warning("CoG drift above 5e-2. Projected the positions down.")
         self.last_flags = fl
-        return out, batch_index, node_mask
+        return (out if return_frames == 1 else frames), batch_index, node_mask
 
     @torch.inference_mode()
     def mol_gen_optimize(self, samples: List[Tuple[torch.Tensor, torch.Tensor]], num_nodes: torch.Tensor, device: Union[torch.device, str],

@@ -104,6 +104,11 @@ int gcdm_sample_init(gcdm_handle* h, float* z, const float* noise, uint64_t seed
  * num_timesteps) followed by gcdm_sample_final. */
 int gcdm_encode_samples(gcdm_handle* h, const float* xh, float* z, uint32_t* flags, void* stream);
 
+/* unnormalize_z (variational_diffusion.py:759-792): out [N,3+F] = continuous, un-normalised copy of the latent z -- one frame of the
+ * chain visualisation (`mol_gen_sample(return_frames > 1)`, :1354-1361).  With frames the reference skips the final CoG re-projection
+ * (:1389): set option "cog_fix" to 0 before gcdm_sample_final (default 1). */
+int gcdm_unnormalize_z(gcdm_handle* h, const float* z, float* out, void* stream);
+
 /* Introspection for the parity tests: copies an internal buffer of the LAST forward to host (synchronises).
  * names: "h","chi","x","agg","ep","alpha","frames","pq","hin","fbar","chi0".  Returns number of floats written
  * (or needed if host_out is NULL), <0 on error.  Layouts are documented in DESIGN.md. */
@@ -115,7 +120,7 @@ int gcdm_debug_set_layer_limit(gcdm_handle* h, int32_t num_layers_to_run);
  * block on operands split as x = hi + 2^-11 lo' (fp32-equivalent accuracy; raises GCDM_FLAG_F16_RANGE if an
  * activation exceeds 6e4, in which case the caller must re-run with mode 0); 0 (env GCDM_MFMA=f32) uses fp32 MFMA throughout.
  * "edge_tile": 64 (default) or 32 edges per workgroup of the edge-message kernels (env GCDM_EDGE_TILE; 32 = two workgroups per CU,
- * same throughput on MI355X -- DESIGN.md 3.4). */
+ * same throughput on MI355X -- DESIGN.md 3.4).  "cog_fix": 1 (default) / 0, see gcdm_unnormalize_z. */
 int gcdm_set_option(gcdm_handle* h, const char* name, int32_t value);
 int gcdm_get_option(const gcdm_handle* h, const char* name);
 

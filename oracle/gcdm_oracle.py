@@ -377,12 +377,24 @@ def sample_p_xh_given_z0(P: Params, cfg: OracleConfig, gam: Tensor, z0: Tensor, 
     return x, one_hot, charges
 
 
+def unnormalize_z(cfg: OracleConfig, z: Tensor, mask: Tensor) -> Tensor:
+    """variational_diffusion.py:735-792 (unnormalize + unnormalize_z): continuous values, no argmax / rounding."""
+    nv, nb = cfg.norm_values, cfg.norm_biases
+    mf = mask.to(z.dtype)[:, None]
+    F_ = cfg.num_atom_types
+    parts = [z[:, :3] * nv[0], (z[:, 3:3 + F_] * nv[1] + nb[1]) * mf]
+    if cfg.include_charges:
+        parts.append((z[:, 3 + F_:] * nv[2] + nb[2]) * mf)
+    return torch.cat(parts, dim=-1)
+
+
 def mol_gen_sample(P: Params, cfg: OracleConfig, num_nodes: Tensor, noise, context: Optional[Tensor] = None,
                    num_timesteps: Optional[int] = None, dtype=torch.float32,
-                   record: Optional[List[Tensor]] = None) -> Tuple[Tensor, Tensor]:
+                   record: Optional[List[Tensor]] = None, return_frames: int = 1) -> Tuple[Tensor, Tensor]:
     """EquivariantVariationalDiffusion.mol_gen_sample, variational_diffusion.py:1282-1412
-    (return_frames=1, no self-conditioning, fix_noise False).  Returns (out [N,3+F], batch_index)."""
+    (no self-conditioning, fix_noise False).  Returns (out [N,3+F] or [return_frames,N,3+F], batch_index)."""
     T = cfg.num_timesteps if num_timesteps is None else num_timesteps
+    assert 0 < return_frames <= T and T % return_frames == 0
     B = len(num_nodes)
     bi = num_nodes_to_batch_index(num_nodes)
     mask = torch.ones_like(bi).bool()
@@ -391,16 +403,21 @@ def mol_gen_sample(P: Params, cfg: OracleConfig, num_nodes: Tensor, noise, conte
         ctx = context.to(dtype)[bi] * mask.to(dtype)[:, None]
     gam = gamma_table(cfg)
     z = sample_combined_noise(noise, bi, B, mask, cfg.num_node_scalar_features, dtype)
+    frames = torch.zeros((return_frames,) + tuple(z.shape), dtype=dtype)
     for s in reversed(range(T)):
         z, _ = sample_p_zs_given_zt(P, cfg, gam, s / T, (s + 1) / T, z, bi, B, mask, ctx, noise)
         if record is not None:
             record.append(z.clone())
+        if (s * return_frames) % T == 0:                          # :1354-1361
+            frames[(s * return_frames) // T] = unnormalize_z(cfg, z, mask)
     x, one_hot, charges = sample_p_xh_given_z0(P, cfg, gam, z, bi, B, mask, ctx, noise)
-    cog = torch.zeros(B, 3, dtype=dtype).index_add_(0, bi, x).abs().max().item()
-    if cog > 5e-2:                                               # :1392-1402
-        x = centralize(x, bi, B, mask)
+    if return_frames == 1:
+        cog = torch.zeros(B, 3, dtype=dtype).index_add_(0, bi, x).abs().max().item()
+        if cog > 5e-2:                                            # :1392-1402
+            x = centralize(x, bi, B, mask)
     parts = [x, one_hot.to(dtype)] + ([charges.to(dtype)] if cfg.include_charges else [])
-    return torch.cat(parts, dim=-1), bi
+    frames[0] = torch.cat(parts, dim=-1)
+    return (frames[0] if return_frames == 1 else frames), bi
 
 
 def normalize(cfg: OracleConfig, x: Tensor, h_cat: Tensor, mask: Tensor) -> Tuple[Tensor, Tensor]:

@@ -237,6 +237,28 @@ def test_free_running_sampling_short(case):
     assert (ddpm.last_flags & 1) == 0
 
 
+def test_sampling_with_chain_frames():
+    """mol_gen_sample(return_frames=5): un-normalised intermediate frames (gcdm_unnormalize_z) + final decode without CoG re-projection,
+    against the oracle (pinned by tests/golden/chain_small_qm9.npz) on the same noise tape."""
+    net, W, cfgs = _net("qm9", seed=43, scale=0.25)
+    ocfg = _ocfg("qm9")
+    ddpm = pkg.EquivariantVariationalDiffusion(net, cfgs["diffusion_cfg"], cfgs["dataloader_cfg"], pkg.dataset_info("qm9")).cuda()
+    nn_ = torch.tensor([7, 19, 4, 12])
+    N, F = int(nn_.sum()), ocfg.num_node_scalar_features
+    Tp, RF = 10, 5
+    want, bi = O.mol_gen_sample(W, ocfg, nn_, O.TapeNoise(1234), num_timesteps=Tp, return_frames=RF)
+    tape = O.TapeNoise(1234)
+    draws = [torch.cat((tape(N, 3), tape(N, F)), dim=-1) for _ in range(Tp + 2)]
+    out, _, _ = ddpm.mol_gen_sample(num_samples=len(nn_), num_nodes=nn_, device="cuda", num_timesteps=Tp, return_frames=RF, noise_fn=lambda k: draws[k])
+    out = out.cpu()
+    assert out.shape == want.shape == (RF, N, 3 + F)
+    scale = max(1.0, want.abs().max().item())
+    assert (out[1:] - want[1:]).abs().max().item() <= TOL * scale
+    assert (out[0, :, :3] - want[0, :, :3]).abs().max().item() <= TOL * scale and torch.equal(out[0, :, 3:], want[0, :, 3:])
+    with pytest.raises(AssertionError):
+        ddpm.mol_gen_sample(num_samples=len(nn_), num_nodes=nn_, device="cuda", num_timesteps=10, return_frames=3)
+
+
 @pytest.mark.parametrize("orig", [False, True])
 def test_mol_gen_optimize_matches_oracle(orig):
     """Property-guided optimisation loop (variational_diffusion.py:1416-1546; oracle pinned by tests/golden/optimize_small_qm9cond.npz):

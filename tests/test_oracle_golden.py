@@ -115,6 +115,21 @@ def test_schedule_and_sampler_small(golden_dir, case):
     assert torch.equal(out[:, 3:], ref[:, 3:])
 
 
+def test_sampling_chain_frames_small(golden_dir):
+    """mol_gen_sample(return_frames=4): intermediate un-normalised frames + final decode vs the reference's own output."""
+    gw = load(golden_dir, "sampler_small_qm9")
+    g = load(golden_dir, "chain_small_qm9")
+    P = weights_of(gw)
+    assert torch.equal(P["gcp_embedding.edge_embedding.vector_down.weight"], g["weight_check"])
+    cfg = cfg_for("qm9", O.infer_num_layers(P))
+    frames, _ = O.mol_gen_sample(P, cfg, g["num_nodes"], O.TapeNoise(int(g["seed"])), num_timesteps=int(g["T"]), return_frames=int(g["return_frames"]))
+    ref = g["frames"]
+    assert frames.shape == ref.shape
+    scale = max(1.0, ref.abs().max().item())
+    assert (frames[1:] - ref[1:]).abs().max().item() <= 1e-4 * scale
+    assert (frames[0, :, :3] - ref[0, :, :3]).abs().max().item() <= 1e-4 * scale and torch.equal(frames[0, :, 3:], ref[0, :, 3:])
+
+
 def test_mol_gen_optimize_small(golden_dir):
     """Property-guided optimisation loop (variational_diffusion.py:1416-1546) vs the reference's own outputs, both time normalisations."""
     gw = load(golden_dir, "sampler_small_qm9cond")          # same reduced-width weights (weight seed 4)
