@@ -151,11 +151,12 @@ __global__ __launch_bounds__(NX_THREADS) void k_node_x3(NodeX3Args ax) {
             const v4f v = g < a.FinG ? a.HIN4[(size_t)g * N + nid] : (v4f){0.f, 0.f, 0.f, 0.f};
             h4 vh, vl;
 #pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                _Float16 hi, lo;
-                split16(v[t], hi, lo);
-                vh[t] = hi; vl[t] = lo;
-                over |= fabsf(v[t]) > X3_RANGE;
+            for (int t = 0; t < 4; t += 2) {
+                h2 hi, lo;
+                split16x2(v[t], v[t + 1], hi, lo);
+                vh[t] = hi[0]; vh[t + 1] = hi[1];
+                vl[t] = lo[0]; vl[t + 1] = lo[1];
+                over |= fmaxf(fabsf(v[t]), fabsf(v[t + 1])) > X3_RANGE;
             }
             const int off = ((g >> 1) * NTP + e) * 16 + 8 * (g & 1);
             *(h4*)(XH + off) = vh;
