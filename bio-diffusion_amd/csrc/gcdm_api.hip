@@ -651,11 +651,17 @@ int gcdm_forward(gcdm_handle* h, const float* xh, const float* t, const float* c
     };
     const int ngrid = (N + NT_ - 1) / NT_;
     NodeX3Args nx{};
+    bool node_kb_ok = true;
     auto launch_node = [&](bool embed, int next_layer, const LayerDev* cur) {
         if (h->mfma_x3) {
             nx.base = na;
             nx.emb = h->embx; nx.proj = h->projx;
             if (cur) { nx.ff = cur->ffx; nx.pos = cur->posx; }
+            if ((cur && (nx.ff.KB != 34 || nx.pos.KB != 18)) || nx.proj.KB != 19) {     // compile-time k-block counts of k_node_x3
+                (void)fail(h, "internal: node k-block counts differ from the kernel's compile-time constants");
+                node_kb_ok = false;
+                return;
+            }
             if (next_layer < h->L) { nx.wpqH = h->layers[next_layer].wpqH; nx.wpqL = h->layers[next_layer].wpqL; }
             if (embed) hipLaunchKernelGGL(k_node_x3<true>, dim3(ngrid), dim3(NX_THREADS), NK_LDS_BYTES, st, nx);
             else hipLaunchKernelGGL(k_node_x3<false>, dim3(ngrid), dim3(NX_THREADS), NK_LDS_BYTES, st, nx);
@@ -666,6 +672,7 @@ int gcdm_forward(gcdm_handle* h, const float* xh, const float* t, const float* c
     };
     set_next(0);
     launch_node(true, 0, nullptr);
+    if (!node_kb_ok) return -1;
     const int ET = h->edge_tile;
     const int tiles = (E + ET - 1) / ET;
     for (int l = 0; l < L; ++l) {
@@ -685,6 +692,7 @@ int gcdm_forward(gcdm_handle* h, const float* xh, const float* t, const float* c
             xa.w0H = d.w0H; xa.w0L = d.w0L; xa.KB0 = d.KB0; xa.wg0H = d.wg0H; xa.wg0L = d.wg0L; xa.KB = d.KB;
             for (int k = 0; k < 3; ++k) { xa.wH[k] = d.wH[k]; xa.wL[k] = d.wL[k]; xa.wgH[k] = d.wgH[k]; xa.wgL[k] = d.wgL[k]; }
             xa.flags_dev = h->d_flags;
+            if (d.KB != 18 || d.KB0 != (h->Se == 64 ? 7 : 4)) return fail(h, "internal: k-block counts differ from the kernel's compile-time constants");
             if (ET == 64) {
                 if (h->Se == 64) hipLaunchKernelGGL((k_edge_msg_x3<64, 16, 64>), dim3(tiles), dim3(512), EdgeGeo<64>::LDS_BYTES, st, xa);
                 else hipLaunchKernelGGL((k_edge_msg_x3<16, 8, 64>), dim3(tiles), dim3(512), EdgeGeo<64>::LDS_BYTES, st, xa);

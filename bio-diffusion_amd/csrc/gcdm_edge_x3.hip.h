@@ -68,10 +68,12 @@ __device__ __forceinline__ void x3_prefetch(X3Ring<MT, PD>& ring, const h8* __re
     }
 }
 
-template <int MT, int NT, int PD>
+// KBC > 0: the number of k-blocks is a compile-time constant (no tail branches, no accumulator copies at their joins)
+template <int MT, int NT, int PD, int KBC = 0>
 __device__ __forceinline__ void tile_gemm_x3(f32x16 (&am)[MT][NT], f32x16 (&al)[MT][NT], X3Ring<MT, PD>& ring, const h8* __restrict__ wH,
-                                             const h8* __restrict__ wL, int KB, const h8* xh8, const h8* xl8, int TP, int lane) {
+                                             const h8* __restrict__ wL, int KBrt, const h8* xh8, const h8* xl8, int TP, int lane) {
     constexpr int R = PD + 1;
+    const int KB = KBC ? KBC : KBrt;
     const int wstride = KB * 64;
     const h8* wh = wH + lane + PD * 64;          // running pointers: one add per k-block, no clamping
     const h8* wl = wL + lane + PD * 64;
@@ -294,6 +296,7 @@ __global__ __launch_bounds__(ET * 8) __attribute__((amdgpu_waves_per_eu(2, 2))) 
     constexpr int N8 = SE / 8;                           // first 8-group of the norm rows in msg0
     constexpr int H0G8 = (H0 + 7) / 8;
     constexpr int Q8 = N8 + H0G8;
+    constexpr int KB0C = (8 * (Q8 + 2) + 15) / 16;       // k-blocks of the msg0 per-edge part (host: gcdm_api.hip, same formula); msg1..3: 18
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int e = (ET == 64) ? lane : (tid & (ET - 1)), part = (ET == 64) ? wave : (tid / ET);
@@ -307,7 +310,7 @@ __global__ __launch_bounds__(ET * 8) __attribute__((amdgpu_waves_per_eu(2, 2))) 
     constexpr int PD = 2;
     const int mt0 = MT * wave;   // first M-tile (32 output channels each) of this wave
     X3Ring<MT, PD> ring;
-    x3_prefetch<MT, PD>(ring, ax.w0H + (size_t)mt0 * ax.KB0 * 64, ax.w0L + (size_t)mt0 * ax.KB0 * 64, ax.KB0, lane);   // flies during P1
+    x3_prefetch<MT, PD>(ring, ax.w0H + (size_t)mt0 * KB0C * 64, ax.w0L + (size_t)mt0 * KB0C * 64, KB0C, lane);   // flies during P1
 
     if (wave == 0) {
         const bool own = lane < ET;
@@ -394,7 +397,7 @@ __global__ __launch_bounds__(ET * 8) __attribute__((amdgpu_waves_per_eu(2, 2))) 
         if (part == PARTS - 1) {
             for (int hh = H0; hh < 8 * H0G8; ++hh) put16(XH, XL, ETP, N8 + (hh >> 3), hh & 7, e, 0.f);
             for (int idx = 9; idx < 16; ++idx) put16(XH, XL, ETP, Q8 + (idx >> 3), idx & 7, e, 0.f);
-            for (int g = Q8 + 2; g < 2 * ax.KB0; ++g) {
+            for (int g = Q8 + 2; g < 2 * KB0C; ++g) {
                 *(v4f*)(XH + (g * ETP + e) * 16) = (v4f){0.f, 0.f, 0.f, 0.f};
                 *(v4f*)(XL + (g * ETP + e) * 16) = (v4f){0.f, 0.f, 0.f, 0.f};
             }
@@ -428,8 +431,8 @@ __global__ __launch_bounds__(ET * 8) __attribute__((amdgpu_waves_per_eu(2, 2))) 
                 }
         }
         STAMP(3);
-        tile_gemm_x3<MT, NT, PD>(am, al2, ring, ax.w0H + (size_t)mt0 * ax.KB0 * 64, ax.w0L + (size_t)mt0 * ax.KB0 * 64, ax.KB0, xh8, xl8, ETP, lane);
-        x3_prefetch<MT, PD>(ring, ax.wH[0] + (size_t)mt0 * ax.KB * 64, ax.wL[0] + (size_t)mt0 * ax.KB * 64, ax.KB, lane);
+        tile_gemm_x3<MT, NT, PD, KB0C>(am, al2, ring, ax.w0H + (size_t)mt0 * KB0C * 64, ax.w0L + (size_t)mt0 * KB0C * 64, KB0C, xh8, xl8, ETP, lane);
+        x3_prefetch<MT, PD>(ring, ax.wH[0] + (size_t)mt0 * 18 * 64, ax.wL[0] + (size_t)mt0 * 18 * 64, 18, lane);
         STAMP(4);
 #pragma unroll
         for (int m = 0; m < MT; ++m)
@@ -468,7 +471,7 @@ __global__ __launch_bounds__(ET * 8) __attribute__((amdgpu_waves_per_eu(2, 2))) 
     // ---- residual message GCP2s k = 1..3 ---------------------------------------------------------------------------------
     for (int k = 0; k < 3; ++k) {
         const GcpW& w = a.mk[k];
-        over |= gcp2_pre_x3<ET, EK_THREADS>(w.wdd, VV, FR, XH, XL, 32, 33, 2 * ax.KB, VH, e, part);
+        over |= gcp2_pre_x3<ET, EK_THREADS>(w.wdd, VV, FR, XH, XL, 32, 33, 36, VH, e, part);
         if (k == 0) STAMP(10);
         __syncthreads();
         if (k == 0) STAMP(11);
@@ -480,9 +483,9 @@ __global__ __launch_bounds__(ET * 8) __attribute__((amdgpu_waves_per_eu(2, 2))) 
 #pragma unroll
                 for (int r = 0; r < 16; ++r) al2[m][n][r] = 0.f;
         if (k == 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); STAMP(21); }
-        tile_gemm_x3<MT, NT, PD>(am, al2, ring, ax.wH[k] + (size_t)mt0 * ax.KB * 64, ax.wL[k] + (size_t)mt0 * ax.KB * 64, ax.KB, xh8, xl8, ETP, lane);
+        tile_gemm_x3<MT, NT, PD, 18>(am, al2, ring, ax.wH[k] + (size_t)mt0 * 18 * 64, ax.wL[k] + (size_t)mt0 * 18 * 64, 18, xh8, xl8, ETP, lane);
         if (k == 0) STAMP(22);
-        if (k < 2) x3_prefetch<MT, PD>(ring, ax.wH[k + 1] + (size_t)mt0 * ax.KB * 64, ax.wL[k + 1] + (size_t)mt0 * ax.KB * 64, ax.KB, lane);
+        if (k < 2) x3_prefetch<MT, PD>(ring, ax.wH[k + 1] + (size_t)mt0 * 18 * 64, ax.wL[k + 1] + (size_t)mt0 * 18 * 64, 18, lane);
         if (k == 0) STAMP(12);
 #pragma unroll
         for (int m = 0; m < MT; ++m)

@@ -5,6 +5,7 @@
 // operands split as x = hi + 2^-11 lo' (see gcdm_edge_x3.hip.h).  One workgroup = 32 nodes, 512 threads: wave w owns M-tile w
 // (32 output channels); the fp32 node scalars h of those channels stay in its registers, LDS holds the hi / lo' images.
 #pragma once
+#include <type_traits>
 #include "gcdm_edge_x3.hip.h"
 
 struct GcpX3 {
@@ -124,12 +125,16 @@ __global__ __launch_bounds__(NX_THREADS) void k_node_x3(NodeX3Args ax) {
     const h8* xh8 = (const h8*)XH;
     const h8* xl8 = (const h8*)XL;
 
-    auto gemm = [&](const h8* wH, const h8* wL, int KB, int g8base) {
+    // kbc: compile-time k-block count (0 = use KBrt); the production widths fix all of them except the embedding's
+    auto gemm = [&](auto kbc, const h8* wH, const h8* wL, int KBrt, int g8base) {
+        constexpr int KBC = decltype(kbc)::value;
+        const int KB = KBC ? KBC : KBrt;
         const h8* wh = wH + (size_t)wave * KB * 64;
         const h8* wl = wL + (size_t)wave * KB * 64;
         x3_prefetch<1, PD>(ring, wh, wl, KB, lane);
-        tile_gemm_x3<1, 1, PD>(am, al, ring, wh, wl, KB, xh8 + g8base * NTP, xl8 + g8base * NTP, NTP, lane);
+        tile_gemm_x3<1, 1, PD, KBC>(am, al, ring, wh, wl, KB, xh8 + g8base * NTP, xl8 + g8base * NTP, NTP, lane);
     };
+    using std::integral_constant;
     auto acc_bias = [&](const float* b) {
         acc_init_bias<1, 1>(am, b, wave, lane);
 #pragma unroll
@@ -168,7 +173,7 @@ __global__ __launch_bounds__(NX_THREADS) void k_node_x3(NodeX3Args ax) {
         over |= gcp2_pre_x3g<NT_, 32, 2, NX_THREADS>(w.wdd, VV, 0, FR, XH, XL, G8in, G8in + 4, 2 * ax.emb.KB, VH, e, part);
         __syncthreads();
         acc_bias(w.b);
-        gemm(ax.emb.wH, ax.emb.wL, ax.emb.KB, 0);
+        gemm(integral_constant<int, 0>{}, ax.emb.wH, ax.emb.wL, ax.emb.KB, 0);
 #pragma unroll
         for (int r = 0; r < 16; ++r) am[0][0][r] += al[0][0][r] * X3_INV_SCALE;     // nonlinearities (None, None): h = p
         hst = am[0][0];
@@ -215,14 +220,14 @@ __global__ __launch_bounds__(NX_THREADS) void k_node_x3(NodeX3Args ax) {
             over |= gcp2_pre_x3g<NT_, 16, 2 * GCDM_V, NX_THREADS>(w.wdd, VV, 0, FR, XH, XL, 64, 66, 2 * ax.ff.KB, VH, e, part);
             __syncthreads();
             acc_bias(w.b);
-            gemm(ax.ff.wH, ax.ff.wL, ax.ff.KB, 0);
+            gemm(integral_constant<int, 34>{}, ax.ff.wH, ax.ff.wL, ax.ff.KB, 0);        // K' = 512 + 16 + 16
 #pragma unroll
             for (int r = 0; r < 16; ++r) am[0][0][r] = fast_silu(am[0][0][r] + al[0][0][r] * X3_INV_SCALE);
             __syncthreads();                                      // every wave is done reading agg.s (8-groups 0..31)
             over |= store_block_x3(XH, XL, 4 * wave, am[0][0], NTP, lane);   // hidden activations of Linear-SiLU-Linear
             __syncthreads();
             acc_bias(w.b2);
-            gemm(ax.ff.w2H, ax.ff.w2L, 16, 0);
+            gemm(integral_constant<int, 16>{}, ax.ff.w2H, ax.ff.w2L, 16, 0);
 #pragma unroll
             for (int r = 0; r < 16; ++r) am[0][0][r] += al[0][0][r] * X3_INV_SCALE;   // nonlinearities (None, None)
             fold_gate(ax.ff.wgH, ax.ff.wgL, am);
@@ -243,7 +248,7 @@ __global__ __launch_bounds__(NX_THREADS) void k_node_x3(NodeX3Args ax) {
             over |= gcp2_pre_x3g<NT_, 8, GCDM_V, NX_THREADS>(w.wdd, VV, CB, FR, XH, XL, 64, 65, HB8 + 2 * ax.pos.KB, VH, e, part);
             __syncthreads();
             acc_bias(w.b);
-            gemm(ax.pos.wH, ax.pos.wL, ax.pos.KB, HB8);
+            gemm(integral_constant<int, 18>{}, ax.pos.wH, ax.pos.wL, ax.pos.KB, HB8);    // K' = 256 + 8 + 16 -> 288
 #pragma unroll
             for (int r = 0; r < 16; ++r) am[0][0][r] = fast_silu(am[0][0][r] + al[0][0][r] * X3_INV_SCALE);
             fold_gate(ax.pos.wgH, ax.pos.wgL, am);
@@ -279,7 +284,7 @@ __global__ __launch_bounds__(NX_THREADS) void k_node_x3(NodeX3Args ax) {
             const h8* wh = ax.wpqH + (size_t)mt * 16 * 64;
             const h8* wl = ax.wpqL + (size_t)mt * 16 * 64;
             x3_prefetch<1, PD>(r2, wh, wl, 16, lane);
-            tile_gemm_x3<1, 1, PD>(am, al, r2, wh, wl, 16, xh8 + HB8 * NTP, xl8 + HB8 * NTP, NTP, lane);
+            tile_gemm_x3<1, 1, PD, 16>(am, al, r2, wh, wl, 16, xh8 + HB8 * NTP, xl8 + HB8 * NTP, NTP, lane);
             if (validl) {
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
@@ -315,7 +320,7 @@ __global__ __launch_bounds__(NX_THREADS) void k_node_x3(NodeX3Args ax) {
         __syncthreads();
         if (wave == 0) {
             acc_bias(w.b);
-            gemm(ax.proj.wH, ax.proj.wL, ax.proj.KB, HB8);
+            gemm(integral_constant<int, 19>{}, ax.proj.wH, ax.proj.wL, ax.proj.KB, HB8);  // K' = 256 + 32 + 16
             if (validl) {
                 float* dst = a.OUT + (size_t)(n0 + l31) * a.Dout + 3;
 #pragma unroll
