@@ -267,7 +267,7 @@ def main():
                        "step_tflops_executed": exe_total / (ms_per_step * 1e-3) / 1e12},
             "roofline": {"bound": "mfma", "kernel": "k_edge_msg_x3" if x3 else "k_edge_msg", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
                          "frac": achieved / peak, "traffic": pmc.get("hbm_bytes_per_launch"), "avg_launch_ms": edge_ms,
-                         "algorithmic_flop_per_launch": alg_edge_layer, "launches_per_step": d["L"],
+                         "algorithmic_flop_per_launch": alg_edge_layer, "launches_per_step": d["L"], "edges_per_workgroup": int(lib.gcdm_get_option(h, b"edge_tile")),
                          "mfma": ("f16 x3 split (x = hi + 2^-11 lo', fp32 accumulate, fp32-equivalent accuracy); peak = 2500/3" if x3
                                   else "fp32 32x32x2"),
                          "mfma_busy_frac_pmc": pmc.get("mfma_busy_frac"), "pmc_source": pmc.get("source")},

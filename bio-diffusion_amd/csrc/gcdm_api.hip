@@ -63,7 +63,11 @@ struct gcdm_handle {
     uint32_t* d_flags = nullptr;
     int cog_fix = 1;                 // gcdm_sample_final re-projects drifting centres of gravity (off for chain frames, reference :1389)
     int layer_limit = -1;
-    int edge_tile = 64;              // 64: one 8-wave workgroup per CU; 32: two 4-wave workgroups per CU (env GCDM_EDGE_TILE)
+    int edge_tile = 0;               // 64: one 8-wave workgroup per CU; 32: two 4-wave workgroups per CU; 0: automatic (env GCDM_EDGE_TILE)
+    // automatic = 64.  The 32-edge split-precision kernel is 5 % (QM9) to 12 % (100-molecule batches) faster, but its results are not
+    // bit-reproducible from run to run (differences ~1e-5 relative, far inside the parity bar; cause not found yet -- DESIGN.md 3.4),
+    // so it stays opt-in until that is understood.
+    int tile() const { return edge_tile ? edge_tile : 64; }
     int mfma_x3 = 1;                 // 1: split-precision f16 x3 edge kernel (default; env GCDM_MFMA=f16x3|f32), 0: fp32 MFMA
     bool attr_set = false;
     // profiling (HIP events around the k_edge_msg launches of one forward)
@@ -327,6 +331,8 @@ int gcdm_create(const GcdmConfig* cfg, gcdm_handle** out) {
     if (cfg->h_hidden_dim != GCDM_S || cfg->chi_hidden_dim != GCDM_V) return fail(h, "only h_hidden_dim=256, chi_hidden_dim=32 are built");
     if (cfg->bottleneck != 4) return fail(h, "only bottleneck=4 is built");
     if (!cfg->condition_on_time) return fail(h, "condition_on_time must be true");
+    if (cfg->num_layers < 1 || cfg->num_layers > 64) return fail(h, "num_layers must be in 1..64");
+    if (cfg->num_atom_types < 1 || cfg->num_context < 0 || cfg->num_timesteps < 1) return fail(h, "bad num_atom_types / num_context / num_timesteps");
     if (!((cfg->e_hidden_dim == 64 && cfg->xi_hidden_dim == 16) || (cfg->e_hidden_dim == 16 && cfg->xi_hidden_dim == 8)))
         return fail(h, "edge dims must be (64,16) [QM9] or (16,8) [GEOM]");
     h->F = cfg->num_atom_types + (cfg->include_charges ? 1 : 0);
@@ -341,7 +347,6 @@ int gcdm_create(const GcdmConfig* cfg, gcdm_handle** out) {
     h->H0 = (2 * GCDM_V + h->Ve) / 4;
     if (const char* et = getenv("GCDM_EDGE_TILE")) h->edge_tile = (atoi(et) == 32) ? 32 : 64;
     if (const char* mm = getenv("GCDM_MFMA")) h->mfma_x3 = (std::strcmp(mm, "f16x3") == 0) ? 1 : 0;
-    if (h->mfma_x3) h->edge_tile = 64;
     HIP_OK(h, hipSetDevice(cfg->device));
     HIP_OK(h, hipMalloc(&h->d_flags, 4 * sizeof(uint32_t)));            // [0] flag word, [1..2] statistics of gcdm_encode_samples
     HIP_OK(h, hipMemset(h->d_flags, 0, 4 * sizeof(uint32_t)));
@@ -673,7 +678,7 @@ int gcdm_forward(gcdm_handle* h, const float* xh, const float* t, const float* c
     set_next(0);
     launch_node(true, 0, nullptr);
     if (!node_kb_ok) return -1;
-    const int ET = h->edge_tile;
+    const int ET = h->tile();
     const int tiles = (E + ET - 1) / ET;
     for (int l = 0; l < L; ++l) {
         const LayerDev& d = h->layers[l];
@@ -833,7 +838,7 @@ int gcdm_set_option(gcdm_handle* h, const char* name, int32_t value) {
     }
     if (k == "cog_fix") { h->cog_fix = value ? 1 : 0; return 0; }
     if (k == "edge_tile") {
-        if (value != 32 && value != 64) return fail(h, "gcdm_set_option(edge_tile): 32 or 64");
+        if (value != 0 && value != 32 && value != 64) return fail(h, "gcdm_set_option(edge_tile): 0 (automatic), 32 or 64");
         h->edge_tile = value;
         return 0;
     }
@@ -844,7 +849,7 @@ int gcdm_get_option(const gcdm_handle* h, const char* name) {
     if (!h || !name) return -1;
     const std::string k(name);
     if (k == "mfma_mode") return h->mfma_x3;
-    if (k == "edge_tile") return h->edge_tile;
+    if (k == "edge_tile") return h->tile();
     if (k == "cog_fix") return h->cog_fix;
     return -1;
 }
@@ -898,7 +903,7 @@ int64_t gcdm_debug_read(gcdm_handle* h, const char* name, float* host_out, int64
     else if (k == "fbar") { p = h->FBAR; cnt = 9 * n; }
     else if (k == "chi0") { p = h->CHI0; cnt = 6 * n; }
     else if (k == "vel") { p = h->VEL; cnt = 3 * n; }
-    else if (k == "phase") { p = h->PROF; cnt = ((e + h->edge_tile - 1) / h->edge_tile) * 192; }
+    else if (k == "phase") { p = h->PROF; cnt = ((e + h->tile() - 1) / h->tile()) * 192; }
     else return fail(h, "gcdm_debug_read: unknown buffer " + k);
     if (!host_out) return cnt;
     if (capacity < cnt) return fail(h, "gcdm_debug_read: capacity too small");

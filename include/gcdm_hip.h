@@ -119,8 +119,10 @@ int gcdm_debug_set_layer_limit(gcdm_handle* h, int32_t num_layers_to_run);
 /* Options.  "mfma_mode": 1 (default; env GCDM_MFMA=f16x3) evaluates the per-edge contractions with three f16 MFMAs per product
  * block on operands split as x = hi + 2^-11 lo' (fp32-equivalent accuracy; raises GCDM_FLAG_F16_RANGE if an
  * activation exceeds 6e4, in which case the caller must re-run with mode 0); 0 (env GCDM_MFMA=f32) uses fp32 MFMA throughout.
- * "edge_tile": 64 (default) or 32 edges per workgroup of the edge-message kernels (env GCDM_EDGE_TILE; 32 = two workgroups per CU,
- * same throughput on MI355X -- DESIGN.md 3.4).  "cog_fix": 1 (default) / 0, see gcdm_unnormalize_z. */
+ * "edge_tile": edges per workgroup of the edge-message kernels: 64 (one 8-wave workgroup per CU), 32 (two 4-wave workgroups per CU) or
+ * 0 = automatic (default; env GCDM_EDGE_TILE) = 64.  32 is faster for small / QM9 batches but, in split-precision mode, not bit-reproducible
+ * from run to run.
+ * "cog_fix": 1 (default) / 0, see gcdm_unnormalize_z. */
 int gcdm_set_option(gcdm_handle* h, const char* name, int32_t value);
 int gcdm_get_option(const gcdm_handle* h, const char* name);
 

@@ -36,7 +36,7 @@ lib, h = net._lib, net._handle
 lib.gcdm_profile_enable(h, 2)
 net.native_forward(xh, t)
 torch.cuda.synchronize()
-nw = 4 if os.environ.get("GCDM_EDGE_TILE") == "32" else 8
+nw = 4 if lib.gcdm_get_option(h, b"edge_tile") == 32 else 8
 ph = net.debug_read("phase").view(-1, 8, 24)[:, :nw]
 lib.gcdm_profile_enable(h, 0)
 names = {1: "P1 msg0 pre", 2: "barrier", 3: "PQ gather", 4: "GEMM0", 5: "silu", 6: "gate+PG", 7: "barrier", 8: "state+vecfinish", 9: "barrier",

@@ -162,6 +162,60 @@ def test_forward_input_validation():
         net(dict(batch=bi.to(dev), mask=mask), xh.to(dev), t.to(dev), xh_self_cond=xh.to(dev))
 
 
+def test_cabi_error_paths():
+    """Every misuse of the C ABI returns a negative status with a message (no exception, no crash, no silent fallback)."""
+    native = pkg._native
+    lib = native.load()
+    H = C.c_void_p
+    good = native.GcdmConfig(1, 5, 1, 0, 1, 9, 256, 32, 64, 16, 4, 1000, 1.0, (C.c_float * 3)(1, 4, 10), (C.c_float * 3)(0, 0, 0), 0)
+    for field, bad in (("abi_version", 99), ("h_hidden_dim", 128), ("chi_hidden_dim", 16), ("e_hidden_dim", 48), ("bottleneck", 2),
+                       ("condition_on_time", 0), ("num_layers", 0)):
+        cfg = native.GcdmConfig.from_buffer_copy(good)
+        setattr(cfg, field, bad)
+        h = H()
+        assert lib.gcdm_create(C.byref(cfg), C.byref(h)) < 0, field
+    h = H()
+    assert lib.gcdm_create(C.byref(good), C.byref(h)) == 0
+    stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    x = torch.zeros((8, 9), device="cuda")
+    t = torch.zeros(8, device="cuda")
+    ptr = lambda a: C.c_void_p(a.data_ptr())
+    # forward / sampling before weights and plan
+    assert lib.gcdm_forward(h, ptr(x), ptr(t), None, ptr(x), None, stream) < 0 and lib.gcdm_last_error(h)
+    assert lib.gcdm_sample_init(h, ptr(x), None, C.c_uint64(1), stream) < 0
+    assert lib.gcdm_finalize_weights(h) < 0 and b"missing" in lib.gcdm_last_error(h).lower()
+    w = torch.zeros(10)
+    assert lib.gcdm_set_weight(h, b"no.such.key", ptr(w), 10) < 0 or lib.gcdm_finalize_weights(h) < 0
+    assert lib.gcdm_plan_batch(h, 0, None) < 0
+    nn_bad = torch.tensor([3, 0, 2], dtype=torch.int32)
+    assert lib.gcdm_plan_batch(h, 3, C.c_void_p(nn_bad.data_ptr())) < 0
+    assert lib.gcdm_set_option(h, b"nonsense", 1) < 0 and lib.gcdm_set_option(h, b"edge_tile", 48) < 0 and lib.gcdm_get_option(h, b"nonsense") < 0
+    assert lib.gcdm_set_gamma(h, ptr(w), 10) < 0                                   # wrong table length
+    lib.gcdm_destroy(h)
+    # a working handle: bad step indices, missing gamma table, bad buffers
+    net, W, cfgs = _net("qm9", seed=3, scale=0.25)
+    dev = torch.device("cuda")
+    net._ensure_handle(dev); net.sync_weights(); net.plan(torch.tensor([4, 5]))
+    lib, h = net._lib, net._handle
+    z = torch.zeros((9, 9), device=dev)
+    assert lib.gcdm_sample_step(h, ptr(z), None, 5, 1000, None, C.c_uint64(1), None, stream) < 0 and b"gamma" in lib.gcdm_last_error(h)
+    ddpm = pkg.EquivariantVariationalDiffusion(net, cfgs["diffusion_cfg"], cfgs["dataloader_cfg"], pkg.dataset_info("qm9")).cuda()
+    dyn, lib, h = ddpm._native(dev)
+    dyn.plan(torch.tensor([4, 5]))
+    assert lib.gcdm_sample_step(h, ptr(z), None, 10, 10, None, C.c_uint64(1), None, stream) < 0
+    assert lib.gcdm_sample_step(h, ptr(z), None, -1, 10, None, C.c_uint64(1), None, stream) < 0
+    assert lib.gcdm_sample_final(h, None, None, None, C.c_uint64(1), ptr(z), None, stream) < 0
+    assert lib.gcdm_encode_samples(h, None, ptr(z), None, stream) < 0 and lib.gcdm_unnormalize_z(h, ptr(z), None, stream) < 0
+    assert lib.gcdm_debug_read(h, b"no_such_buffer", None, 0) < 0
+    tb = native.GcdmBondTables()
+    tb.num_types = 99
+    assert lib.gcdm_check_stability(tb, ptr(z), 9, ptr(z), ptr(z), 1, ptr(z), stream) == -1
+    # and the handle still works afterwards
+    assert lib.gcdm_sample_step(h, ptr(z), None, 3, 10, None, C.c_uint64(1), None, stream) == 0
+    torch.cuda.synchronize()
+    assert torch.isfinite(z).all()
+
+
 def _raw_noise(seed, N, F):
     """One draw in the reference's randn order: x-part [N,3] then h-part [N,F] (variational_diffusion.py:804-817)."""
     tape = O.TapeNoise(seed)
