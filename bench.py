@@ -49,12 +49,25 @@ WORKLOADS = {
 }
 
 
+def _gcp2_flops(M, S_in, V_in, S_out, V_out, bn, ff=False):
+    """2 x MAC of one GCP2 over M entities as the reference evaluates it (gcpnet.py:378-491) + 54 for the 3x3 scalarisation."""
+    H = V_in // bn if bn > 1 else max(V_in, V_out)
+    f = 3 * V_in * H + 9 * V_in + 27 + (S_in + H + 9) * S_out
+    if ff:
+        f += S_out * S_out
+    if V_out:
+        f += 3 * H * V_out + S_out * V_out
+    return 2 * M * f
+
+
 def algorithmic_flops(N, E, dims):
-    """SURVEY A.4 closed form (2 x MAC of every nn.Linear as the reference evaluates them + 54 per scalarisation)."""
-    from oracle.gcdm_oracle import forward_flops, _gcp2_flops
+    """SURVEY A.4 closed form (no credit for the msg0 split).  Returns (whole forward, the per-layer edge-message part = what one launch
+    of the dominant kernel stands for).  tests/test_host_cpu.py checks it against the oracle's count."""
     S, V, Se, Ve, L, h_in = dims
-    total = forward_flops(N, E, S, V, Se, Ve, L, h_in)
     edge_layer = _gcp2_flops(E, 2 * S + Se, 2 * V + Ve, S, V, 4) + 3 * _gcp2_flops(E, S, V, S, V, 4) + 2 * E * S
+    node_layer = _gcp2_flops(N, 2 * S, 2 * V, S, V, 4, ff=True) + _gcp2_flops(N, S, V, S, 1, 4)
+    total = (_gcp2_flops(E, 1, 1, Se, Ve, 1) + _gcp2_flops(N, h_in, 2, S, V, 1) + L * (edge_layer + node_layer)
+             + _gcp2_flops(N, S, V, h_in, 0, 1))
     return total, edge_layer
 
 

@@ -159,3 +159,17 @@ def test_xyz_writers_match_reference_files(tmp_path):
     types = torch.tensor(g["one_hot"]).argmax(-1)
     pkg.write_xyz_file(torch.tensor(g["pos"])[:3], types[:3], str(tmp_path) + "/single.xyz")
     assert open(str(tmp_path) + "/single.xyz").read() == str(g["single"])
+
+
+def test_bench_flop_count_matches_oracle_closed_form():
+    """bench.py carries its own copy of the SURVEY A.4 closed form (the product side must not import oracle/ outside the cpu_baseline leg)."""
+    import sys
+    sys.path.insert(0, ROOT)
+    import bench
+    from oracle import gcdm_oracle as O
+    for N, E, dims in ((19456, 369664, (256, 32, 64, 16, 9, 7)), (11264, 495616, (256, 32, 16, 8, 4, 17)), (1216, 23104, (256, 32, 64, 16, 9, 7))):
+        total, edge = bench.algorithmic_flops(N, E, dims)
+        S, V, Se, Ve, L, h_in = dims
+        assert total == O.forward_flops(N, E, S, V, Se, Ve, L, h_in)
+        assert edge == O._gcp2_flops(E, 2 * S + Se, 2 * V + Ve, S, V, 4) + 3 * O._gcp2_flops(E, S, V, S, V, 4) + 2 * E * S
+    assert abs(bench.algorithmic_flops(19456, 369664, (256, 32, 64, 16, 9, 7))[0] / 2836.5e9 - 1) < 1e-3      # SURVEY 8(d): C2 = 2 836.5 GFLOP
