@@ -135,6 +135,8 @@ def main():
     ap.add_argument("--workload", default="qm9", choices=sorted(WORKLOADS))
     ap.add_argument("--batch", type=int, default=0, help="molecules per GPU (default: the workload's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--streams", type=int, default=1, help="independent batches in flight per GPU, each on its own handle and HIP stream "
+                                                           "(the evaluation driver's concurrent_batches; for small batches)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -190,10 +192,23 @@ def main():
     zp, fp = C.c_void_p(z.data_ptr()), C.c_void_p(flags.data_ptr())
     T = 1000
 
+    lanes = []                                     # extra batches in flight: own handle, stream, state
+    for k in range(1, max(1, args.streams)):
+        ln = ddpm._Lane(ddpm, dev)
+        native.check(ln.lib, ln.h, ln.lib.gcdm_plan_batch(ln.h, B, C.c_void_p(num_nodes.data_ptr())), "gcdm_plan_batch")
+        zk = torch.empty_like(z)
+        fk = torch.zeros(1, dtype=torch.int32, device=dev)
+        lanes.append((ln, zk, fk, C.c_uint64(1234 + rank + 1000 * k)))
+        native.check(ln.lib, ln.h, ln.lib.gcdm_sample_init(ln.h, C.c_void_p(zk.data_ptr()), None, lanes[-1][3], C.c_void_p(ln.stream.cuda_stream)), "gcdm_sample_init")
+
     def step(s):
         st = lib.gcdm_sample_step(h, zp, cptr, s, T, None, seed, fp, stream)
         if st < 0:
             native.check(lib, h, st, "gcdm_sample_step")
+        for ln, zk, fk, sk in lanes:
+            st = ln.lib.gcdm_sample_step(ln.h, C.c_void_p(zk.data_ptr()), cptr, s, T, None, sk, C.c_void_p(fk.data_ptr()), C.c_void_p(ln.stream.cuda_stream))
+            if st < 0:
+                native.check(ln.lib, ln.h, st, "gcdm_sample_step")
 
     log(f"plan: N={N} E={E} cpu_count={os.cpu_count()}")
     native.check(lib, h, lib.gcdm_sample_init(h, zp, None, seed, stream), "gcdm_sample_init")
@@ -269,15 +284,15 @@ def main():
         peak = PEAK_F16_MFMA_TFLOPS / 3.0 if x3 else PEAK_FP32_MFMA_TFLOPS
         pmc = load_pmc_summary(args.workload, x3)
         res = {
-            "metric": "molecules/sec (1000-step DDPM sample)", "value": world * B / (ms_per_step * 1e-3 * NET_EVALS_PER_SAMPLE),
+            "metric": "molecules/sec (1000-step DDPM sample)", "value": world * B * max(1, args.streams) / (ms_per_step * 1e-3 * NET_EVALS_PER_SAMPLE),
             "unit": "molecules/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": wl["name"], "molecules_per_gpu": B, "atoms_per_molecule": wl["n"] if wl["n"] is not None else round(N / B, 2), "nodes_per_gpu": N,
+            "config": {"workload": wl["name"], "molecules_per_gpu": B * max(1, args.streams), "batches_in_flight": max(1, args.streams), "atoms_per_molecule": wl["n"] if wl["n"] is not None else round(N / B, 2), "nodes_per_gpu": N,
                        "edges_per_gpu": E, "noise": "on-device Philox", "weights": "default init, 2-D x0.25 (SURVEY 8d)",
                        "value_definition": f"molecules / ({NET_EVALS_PER_SAMPLE} x measured s/step)", "parallelism": f"shard{world}",
                        "final_gather_ms": gather_ms, "stability_check_ms": stability_ms, "outputs_finite": finite, "flags": fl,
-                       "step_tflops_algorithmic": alg_total / (ms_per_step * 1e-3) / 1e12,
-                       "step_tflops_executed": exe_total / (ms_per_step * 1e-3) / 1e12},
+                       "step_tflops_algorithmic": max(1, args.streams) * alg_total / (ms_per_step * 1e-3) / 1e12,
+                       "step_tflops_executed": max(1, args.streams) * exe_total / (ms_per_step * 1e-3) / 1e12},
             "roofline": {"bound": "mfma", "kernel": "k_edge_msg_x3" if x3 else "k_edge_msg", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
                          "frac": achieved / peak, "traffic": pmc.get("hbm_bytes_per_launch"), "avg_launch_ms": edge_ms,
                          "algorithmic_flop_per_launch": alg_edge_layer, "launches_per_step": d["L"], "edges_per_workgroup": int(lib.gcdm_get_option(h, b"edge_tile")),

@@ -312,6 +312,96 @@ class EquivariantVariationalDiffusion(nn.Module):
         self.last_flags = fl
         return (out if return_frames == 1 else frames), batch_index, node_mask
 
+    # ---- several independent batches in flight (evaluation driver) -------------------------------------------------------------
+    class _Lane:
+        """One extra library handle + stream: its own packed weights (26 MB) and workspace, so that the launches of different
+        batches are independent and the GPU can fill the CUs a 100-molecule batch leaves idle."""
+
+        def __init__(self, ddpm: "EquivariantVariationalDiffusion", device: torch.device):
+            dyn = ddpm.dynamics_network
+            self.lib = _native.load()
+            self.h = C.c_void_p()
+            idx = device.index if device.index is not None else torch.cuda.current_device()
+            cfg = dyn._native_config(idx)
+            _native.check(self.lib, self.h, self.lib.gcdm_create(C.byref(cfg), C.byref(self.h)), "gcdm_create")
+            for key, val in dyn.state_dict().items():
+                w = val.detach().to("cpu", torch.float32).contiguous()
+                _native.check(self.lib, self.h, self.lib.gcdm_set_weight(self.h, key.encode(), C.c_void_p(w.data_ptr()), w.numel()), "gcdm_set_weight")
+            _native.check(self.lib, self.h, self.lib.gcdm_finalize_weights(self.h), "gcdm_finalize_weights")
+            g = ddpm.gamma.gamma.detach().to("cpu", torch.float32).contiguous()
+            _native.check(self.lib, self.h, self.lib.gcdm_set_gamma(self.h, C.c_void_p(g.data_ptr()), g.numel()), "gcdm_set_gamma")
+            self.lib.gcdm_set_option(self.h, b"mfma_mode", dyn.mfma_mode)
+            self.stream = torch.cuda.Stream(device)
+
+        def close(self):
+            if self.h:
+                self.lib.gcdm_destroy(self.h)
+                self.h = None
+
+    @torch.inference_mode()
+    def mol_gen_sample_concurrent(self, num_nodes_list: List[torch.Tensor], device: Union[torch.device, str],
+                                  num_timesteps: Optional[int] = None, contexts: Optional[List[Optional[torch.Tensor]]] = None,
+                                  seeds: Optional[List[int]] = None) -> List[Tuple[torch.Tensor, torch.Tensor, torch.Tensor]]:
+        """`mol_gen_sample` for several independent batches at once: batch b runs on its own handle and HIP stream, the step
+        launches of all batches are interleaved on the host.  Results are those of `mol_gen_sample(..., seed=seeds[b])` called one
+        after the other (bit-identical); small batches (the evaluation driver's 100 molecules) no longer leave CUs idle."""
+        device = torch.device(device)
+        K = len(num_nodes_list)
+        T = self.T if num_timesteps is None else num_timesteps
+        contexts = contexts if contexts is not None else [None] * K
+        seeds = seeds if seeds is not None else [1234 + b for b in range(K)]
+        self._native(device)                                   # validates the dynamics network, uploads the primary handle
+        lanes = getattr(self, "_lanes", None) or []
+        while len(lanes) < K:
+            lanes.append(self._Lane(self, device))
+        self._lanes = lanes
+        D = self.num_x_dims + self.num_node_scalar_features
+        work = []
+        for b in range(K):
+            ln = lanes[b]
+            nn_ = torch.as_tensor(num_nodes_list[b], dtype=torch.int32, device="cpu").contiguous()
+            _native.check(ln.lib, ln.h, ln.lib.gcdm_plan_batch(ln.h, len(nn_), C.c_void_p(nn_.data_ptr())), "gcdm_plan_batch")
+            bi = num_nodes_to_batch_index(len(nn_), nn_.to(device), device=device)
+            N = int(bi.shape[0])
+            ctx = contexts[b]
+            if ctx is not None:
+                ctx = ctx.to(device, torch.float32)[bi].contiguous()
+            elif self.dynamics_network.condition_on_context:
+                raise ValueError("context required by a context-conditioned model")
+            work.append(dict(lane=ln, bi=bi, z=torch.empty((N, D), dtype=torch.float32, device=device), out=torch.empty((N, D), dtype=torch.float32, device=device),
+                             flags=torch.zeros(1, dtype=torch.int32, device=device), ctx=ctx, seed=C.c_uint64(seeds[b])))
+        torch.cuda.synchronize(device)
+        ptr = lambda t: None if t is None else C.c_void_p(t.data_ptr())
+        for w in work:
+            ln = w["lane"]
+            _native.check(ln.lib, ln.h, ln.lib.gcdm_sample_init(ln.h, ptr(w["z"]), None, w["seed"], C.c_void_p(ln.stream.cuda_stream)), "gcdm_sample_init")
+        for s in reversed(range(T)):
+            for w in work:
+                ln = w["lane"]
+                st = ln.lib.gcdm_sample_step(ln.h, ptr(w["z"]), ptr(w["ctx"]), s, T, None, w["seed"], ptr(w["flags"]), C.c_void_p(ln.stream.cuda_stream))
+                _native.check(ln.lib, ln.h, st, "gcdm_sample_step")
+        for w in work:
+            ln = w["lane"]
+            st = ln.lib.gcdm_sample_final(ln.h, ptr(w["z"]), ptr(w["ctx"]), None, w["seed"], ptr(w["out"]), ptr(w["flags"]), C.c_void_p(ln.stream.cuda_stream))
+            _native.check(ln.lib, ln.h, st, "gcdm_sample_final")
+        torch.cuda.synchronize(device)
+        results = []
+        for b, w in enumerate(work):
+            fl = int(w["flags"].item())
+            if fl & _native.FLAG_F16_RANGE:                    # rare: redo this batch on the primary handle (which falls back to fp32 MFMA)
+                log.warning("An activation left the f16 range in a concurrent batch; re-running it with fp32 MFMA.")
+                results.append(self.mol_gen_sample(len(num_nodes_list[b]), num_nodes_list[b], device, num_timesteps=T, context=contexts[b], seed=seeds[b]))
+                continue
+            if fl & _native.FLAG_NAN_VEL:
+                log.warning("Detected NaN in `vel` -> GCPNet `vel` output was reset to zero for at least one time step.")
+            results.append((w["out"], w["bi"], torch.ones_like(w["bi"]).bool()))
+        return results
+
+    def release_lanes(self):
+        for ln in getattr(self, "_lanes", None) or []:
+            ln.close()
+        self._lanes = []
+
     @torch.inference_mode()
     def mol_gen_optimize(self, samples: List[Tuple[torch.Tensor, torch.Tensor]], num_nodes: torch.Tensor, device: Union[torch.device, str],
                          return_frames: int = 1, num_timesteps: Optional[int] = None, node_mask: Optional[torch.Tensor] = None,
