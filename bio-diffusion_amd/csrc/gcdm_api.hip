@@ -61,6 +61,8 @@ struct gcdm_handle {
     float *X0 = nullptr, *XC = nullptr, *FBAR = nullptr, *CHI0 = nullptr, *HIN4 = nullptr, *H4 = nullptr, *CHI = nullptr, *PQ4 = nullptr,
           *VDI = nullptr, *VDJ = nullptr, *AGG = nullptr, *VEL = nullptr, *EPS = nullptr, *TBUF = nullptr, *EP4 = nullptr, *AL = nullptr, *U = nullptr, *FR = nullptr, *PROF = nullptr;
     uint32_t* d_flags = nullptr;
+    int flat_prev = 0, flat_next = 0;   // the plan is a slice of a larger flat batch (options "flat_prev" / "flat_next"; include/gcdm_hip.h)
+    uint32_t node_base = 0;             // option "node_base": flat index of the slice's first node (Philox counter)
     int cog_fix = 1;                 // gcdm_sample_final re-projects drifting centres of gravity (off for chain frames, reference :1389)
     int layer_limit = -1;
     int edge_tile = 0;               // 64: one 8-wave workgroup per CU; 32: two 4-wave workgroups per CU; 0: automatic (env GCDM_EDGE_TILE)
@@ -630,7 +632,7 @@ int gcdm_forward(gcdm_handle* h, const float* xh, const float* t, const float* c
     const int N = h->N, B = h->B;
     const int E = (int)h->E;
     HIP_OK(h, hipMemsetAsync(h->d_flags, 0, sizeof(uint32_t), st));
-    PrepArgs pa{xh, t, context, h->d_noff, N, h->F, h->C, h->FinG, h->X0, h->XC, h->FBAR, h->CHI0, (v4f*)h->HIN4};
+    PrepArgs pa{xh, t, context, h->d_noff, N, h->F, h->C, h->FinG, h->X0, h->XC, h->FBAR, h->CHI0, (v4f*)h->HIN4, h->flat_prev, h->flat_next};
     hipLaunchKernelGGL(k_prep, dim3(B), dim3(64), 3 * h->max_n * sizeof(float), st, pa);
     EdgeEmbedArgs ea{h->X0, h->XC, N, h->d_erow, h->d_ecol, E, h->ee_ws, h->ee_bs, h->ee_wd, h->ee_wdf, h->ee_kappa, h->ee_wg, h->ee_bg,
                      (v4f*)h->EP4, h->AL, h->U, h->FR};
@@ -738,7 +740,7 @@ static float gamma_lookup(const gcdm_handle* h, float t) {
 }
 
 static int launch_sample(gcdm_handle* h, StepArgs& sa, hipStream_t st) {
-    sa.noff = h->d_noff; sa.N = h->N; sa.D = h->D;
+    sa.noff = h->d_noff; sa.N = h->N; sa.D = h->D; sa.node_base = h->node_base;
     hipLaunchKernelGGL(k_sample, dim3(h->B), dim3(64), (size_t)h->max_n * h->D * sizeof(float), st, sa);
     HIP_OK(h, hipGetLastError());
     return 0;
@@ -774,7 +776,13 @@ static int fill_t(gcdm_handle* h, float value, hipStream_t st) {
 
 int gcdm_sample_step(gcdm_handle* h, float* z, const float* context, int32_t s_index, int32_t num_steps, const float* noise, uint64_t seed,
                      uint32_t* flags, void* stream_) {
-    if (!h || !z || num_steps <= 0 || s_index < 0 || s_index >= num_steps) return fail(h, "gcdm_sample_step: bad argument");
+    return gcdm_sample_step_to(h, z, z, context, s_index, num_steps, noise, seed, flags, stream_);
+}
+
+int gcdm_sample_step_to(gcdm_handle* h, const float* z_in, float* z_out, const float* context, int32_t s_index, int32_t num_steps,
+                        const float* noise, uint64_t seed, uint32_t* flags, void* stream_) {
+    float* z = const_cast<float*>(z_in);
+    if (!h || !z || !z_out || num_steps <= 0 || s_index < 0 || s_index >= num_steps) return fail(h, "gcdm_sample_step: bad argument");
     if ((int64_t)h->gamma.size() != (int64_t)h->cfg.num_timesteps + 1) return fail(h, "gcdm_sample_step: gamma table not set");
     hipStream_t st = (hipStream_t)stream_;
     // s = s_index / num_steps, t = (s_index + 1) / num_steps (variational_diffusion.py:1335-1341); t [N] = t[batch_index] (:1239)
@@ -787,7 +795,7 @@ int gcdm_sample_step(gcdm_handle* h, float* z, const float* context, int32_t s_i
     const float alpha_ts = expf(0.5f * (logsigmoidf(-gt) - logsigmoidf(-gs)));
     const float sts = sqrtf(s2ts), sig_s = sqrtf(sigmoidf_(gs)), sig_t = sqrtf(sigmoidf_(gt));
     StepArgs sa{};
-    sa.z = z; sa.eps = h->EPS; sa.noise = noise; sa.seed = seed; sa.draw = (uint32_t)s_index; sa.mode = 0;
+    sa.z = z; sa.z_out = z_out; sa.eps = h->EPS; sa.noise = noise; sa.seed = seed; sa.draw = (uint32_t)s_index; sa.mode = 0;
     sa.alpha_coef = alpha_ts;
     sa.c_eps = s2ts / alpha_ts / sig_t;
     sa.sigma = sts * sig_s / sig_t;
@@ -837,6 +845,9 @@ int gcdm_set_option(gcdm_handle* h, const char* name, int32_t value) {
         return 0;
     }
     if (k == "cog_fix") { h->cog_fix = value ? 1 : 0; return 0; }
+    if (k == "flat_prev") { h->flat_prev = value ? 1 : 0; return 0; }
+    if (k == "flat_next") { h->flat_next = value ? 1 : 0; return 0; }
+    if (k == "node_base") { if (value < 0) return fail(h, "gcdm_set_option(node_base): >= 0"); h->node_base = (uint32_t)value; return 0; }
     if (k == "edge_tile") {
         if (value != 0 && value != 32 && value != 64) return fail(h, "gcdm_set_option(edge_tile): 0 (automatic), 32 or 64");
         h->edge_tile = value;
@@ -851,6 +862,9 @@ int gcdm_get_option(const gcdm_handle* h, const char* name) {
     if (k == "mfma_mode") return h->mfma_x3;
     if (k == "edge_tile") return h->tile();
     if (k == "cog_fix") return h->cog_fix;
+    if (k == "flat_prev") return h->flat_prev;
+    if (k == "flat_next") return h->flat_next;
+    if (k == "node_base") return (int)h->node_base;
     return -1;
 }
 

@@ -304,6 +304,7 @@ struct PrepArgs {
     float* FBAR;       // [9][N] mean_j f_ij
     float* CHI0;       // [6][N] orientations (flat-batch adjacency)
     v4f* HIN4;         // [FinG][N]
+    int has_prev, has_next;   // this plan is a slice of a larger flat batch: rows -1 / N of xh exist and are its flat neighbours
 };
 
 __global__ __launch_bounds__(64) void k_prep(PrepArgs a) {
@@ -325,12 +326,12 @@ __global__ __launch_bounds__(64) void k_prep(PrepArgs a) {
         xs[i] = c0; xs[n + i] = c1; xs[2 * n + i] = c2;
         // orientations (protein_graph_dataset.py:217-225): flat neighbours, zero padded at the global ends
         float fw[3] = {0.f, 0.f, 0.f}, bw[3] = {0.f, 0.f, 0.f};
-        if (g + 1 < a.N) {
+        if (g + 1 < a.N || a.has_next) {
             const float* q = p + D;
             const float e0 = q[0] - x0, e1 = q[1] - x1, e2 = q[2] - x2, nr = sqrtf(e0 * e0 + e1 * e1 + e2 * e2);
             if (nr > 0.f) { fw[0] = e0 / nr; fw[1] = e1 / nr; fw[2] = e2 / nr; }
         }
-        if (g > 0) {
+        if (g > 0 || a.has_prev) {
             const float* q = p - D;
             const float e0 = q[0] - x0, e1 = q[1] - x1, e2 = q[2] - x2, nr = sqrtf(e0 * e0 + e1 * e1 + e2 * e2);
             if (nr > 0.f) { bw[0] = e0 / nr; bw[1] = e1 / nr; bw[2] = e2 / nr; }
@@ -998,6 +999,8 @@ __device__ __forceinline__ float philox_normal(uint64_t seed, uint32_t draw, uin
 
 struct StepArgs {
     float* z;            // [N][D] in/out
+    float* z_out;        // step / init: where the new latent goes (null = in place)
+    uint32_t node_base;  // flat index of node 0 in the whole batch (Philox counter), for plans that are slices of a flat batch
     const float* eps;    // [N][D] network output (null for init)
     const float* noise;  // [N][D] or null -> Philox
     const int* noff; int N, D;
@@ -1082,7 +1085,7 @@ __global__ __launch_bounds__(64) void k_sample(StepArgs a) {
     const int b = blockIdx.x, o = a.noff[b], n = a.noff[b + 1] - o, D = a.D;
     for (int idx = threadIdx.x; idx < n * D; idx += 64) {
         const int i = idx / D, c = idx - i * D;
-        ns[idx] = a.noise ? a.noise[(size_t)(o + i) * D + c] : philox_normal(a.seed, a.draw, (uint32_t)(o + i), (uint32_t)c);
+        ns[idx] = a.noise ? a.noise[(size_t)(o + i) * D + c] : philox_normal(a.seed, a.draw, a.node_base + (uint32_t)(o + i), (uint32_t)c);
     }
     __syncthreads();
     // CoM-free x-noise (sample_center_gravity_zero_gaussian_with_mask, :396-420)
@@ -1111,14 +1114,16 @@ __global__ __launch_bounds__(64) void k_sample(StepArgs a) {
         float s[3] = {0.f, 0.f, 0.f};
         for (int i = 0; i < n; ++i) { s[0] += ns[i * D]; s[1] += ns[i * D + 1]; s[2] += ns[i * D + 2]; }
         s[0] /= (float)n; s[1] /= (float)n; s[2] /= (float)n;
+        float* zo = a.z_out ? a.z_out : a.z;
         for (int idx = threadIdx.x; idx < n * D; idx += 64) {
             const int i = idx / D, c = idx - i * D;
-            a.z[(size_t)(o + i) * D + c] = ns[idx] - (c < 3 ? s[c] : 0.f);
+            zo[(size_t)(o + i) * D + c] = ns[idx] - (c < 3 ? s[c] : 0.f);
         }
     } else if (a.mode == 1) {
+        float* zo = a.z_out ? a.z_out : a.z;
         for (int idx = threadIdx.x; idx < n * D; idx += 64) {
             const int i = idx / D, c = idx - i * D;
-            a.z[(size_t)(o + i) * D + c] = ns[idx];
+            zo[(size_t)(o + i) * D + c] = ns[idx];
         }
     } else {
         // unnormalize (:735-757), argmax one-hot / rounded charge (:902-905), CoG drift re-projection (:1389-1402)

@@ -214,7 +214,8 @@ class GCPNetDynamics(nn.Module):
         _native.check(self._lib, h, st, "gcdm_create")
         self._weights_version = None
         self._plan_key = None
-        self._flags = torch.zeros(1, dtype=torch.int32, device=device)
+        with torch.inference_mode(False):       # a normal tensor even when the handle is first created under inference_mode
+            self._flags = torch.zeros(1, dtype=torch.int32, device=device)
 
     def _params_fingerprint(self):
         return tuple(p._version for p in self.parameters()) + tuple(p.data_ptr() for p in self.parameters())

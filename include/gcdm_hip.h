@@ -97,6 +97,13 @@ int gcdm_sample_final(gcdm_handle* h, const float* z0, const float* context, con
 /* Draws z_T (variational_diffusion.py:795-819) into z [N,3+F] from `noise` (device) or Philox(seed). */
 int gcdm_sample_init(gcdm_handle* h, float* z, const float* noise, uint64_t seed, void* stream);
 
+/* Out-of-place form of gcdm_sample_step: reads z_in, writes the new latent to z_out (z_out == z_in is the in-place call above).
+ * Used when one flat batch is sampled as several slices on separate handles / streams (options "flat_prev", "flat_next", "node_base"
+ * below): a slice's first / last node reads the position of its flat neighbour (protein_graph_dataset.py:217-225) from the row just
+ * outside its own range of z_in, which the neighbouring slice must not overwrite during the step. */
+int gcdm_sample_step_to(gcdm_handle* h, const float* z_in, float* z_out, const float* context, int32_t s_index, int32_t num_steps,
+                        const float* noise, uint64_t seed, uint32_t* flags, void* stream);
+
 /* Start of the optimisation loop (mol_gen_optimize, variational_diffusion.py:1451-1464): z = normalize(xh) (:702-732) for caller-supplied
  * samples xh [N,3+F] = [x | one-hot | charge] (device), and the reference's assert_mean_zero_with_mask (:465-474) on the positions:
  * GCDM_FLAG_MEAN_NOT_ZERO is OR-ed into `flags` (device, may be NULL) when max_b|sum_i x| / (max|x| + 1e-10) >= 1e-2.
@@ -122,7 +129,11 @@ int gcdm_debug_set_layer_limit(gcdm_handle* h, int32_t num_layers_to_run);
  * "edge_tile": edges per workgroup of the edge-message kernels: 64 (one 8-wave workgroup per CU), 32 (two 4-wave workgroups per CU) or
  * 0 = automatic (default; env GCDM_EDGE_TILE) = 64.  32 is faster for small / QM9 batches but, in split-precision mode, not bit-reproducible
  * from run to run.
- * "cog_fix": 1 (default) / 0, see gcdm_unnormalize_z. */
+ * "cog_fix": 1 (default) / 0, see gcdm_unnormalize_z.
+ * "flat_prev" / "flat_next" (0/1) and "node_base" (>= 0): the handle's plan is a contiguous slice of molecules of a larger flat batch whose
+ * xh / z / out pointers point at the slice's first row inside the whole array: the rows just before / after the slice exist and provide
+ * the flat-batch neighbours of its first / last node; node_base = index of the slice's first node in the whole batch (Philox counter, so that
+ * a sliced run draws exactly the noise of the unsliced one). */
 int gcdm_set_option(gcdm_handle* h, const char* name, int32_t value);
 int gcdm_get_option(const gcdm_handle* h, const char* name);
 

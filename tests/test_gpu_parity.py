@@ -291,6 +291,49 @@ def test_free_running_sampling_short(case):
     assert (ddpm.last_flags & 1) == 0
 
 
+@pytest.mark.parametrize("case,sizes,K", [("qm9", [19] * 40, 2), ("qm9", [5, 19, 7, 29, 3, 12, 19, 8, 21, 4, 17], 3), ("geom", [44] * 12 + [7, 91], 2)])
+def test_sampling_in_lanes_equals_single_handle(case, sizes, K):
+    """One flat batch sampled as K slices on K handles / streams (mol_gen_sample(lanes=K)): same Philox noise, flat-batch neighbours read
+    across the seams -> the samples of the single-handle run (continuous part within the bar: only the edge-tile boundaries move)."""
+    d = _dims(case)
+    net, W, cfgs = _net(case, seed=43, scale=0.25)
+    ds = "geom" if case == "geom" else "qm9"
+    ddpm = pkg.EquivariantVariationalDiffusion(net, cfgs["diffusion_cfg"], cfgs["dataloader_cfg"], pkg.dataset_info(ds)).cuda()
+    nn_ = torch.tensor(sizes)
+    kw = dict(num_samples=len(nn_), num_nodes=nn_, device="cuda", num_timesteps=8, norm_with_original_timesteps=True, seed=99)
+    one, bi1, _ = ddpm.mol_gen_sample(**kw)
+    one = one.clone()
+    assert (ddpm.last_flags & pkg._native.FLAG_F16_RANGE) == 0
+    many, bi2, _ = ddpm.mol_gen_sample(lanes=K, **kw)
+    assert (ddpm.last_flags & pkg._native.FLAG_F16_RANGE) == 0 and len(ddpm._lanes) == K      # really ran in K split-precision lanes
+    assert torch.equal(bi1, bi2)
+    scale = max(1.0, one[:, :3].abs().max().item())
+    assert (one[:, :3] - many[:, :3]).abs().max().item() <= TOL * scale
+    assert torch.equal(one[:, 3:], many[:, 3:])
+    # a single forward through a slice handle reproduces the whole-batch forward on its rows, including the seam nodes' orientations
+    dyn, lib, h = ddpm._native(torch.device("cuda"))
+    xh, t, bi, _, _ = synth.make_inputs(sizes, synth.dims_feat(d), seed=5, t_value=0.37)
+    want = _fwd(net, xh, t, bi)
+    ln = ddpm._lanes[0]
+    cut = len(sizes) // 2
+    n0 = int(sum(sizes[:cut]))
+    part = torch.tensor(sizes[cut:], dtype=torch.int32)
+    assert ln.lib.gcdm_plan_batch(ln.h, len(part), C.c_void_p(part.data_ptr())) == 0
+    for name, val in ((b"flat_prev", 1), (b"flat_next", 0), (b"node_base", n0)):
+        assert ln.lib.gcdm_set_option(ln.h, name, val) == 0
+    xd, td = xh.cuda().contiguous(), t.reshape(-1).cuda().contiguous()
+    od = torch.zeros_like(xd)
+    D = xd.shape[1]
+    st = ln.lib.gcdm_forward(ln.h, C.c_void_p(xd.data_ptr() + 4 * n0 * D), C.c_void_p(td.data_ptr() + 4 * n0), None, C.c_void_p(od.data_ptr() + 4 * n0 * D), None,
+                             C.c_void_p(torch.cuda.current_stream().cuda_stream))
+    assert st == 0
+    torch.cuda.synchronize()
+    for name in (b"flat_prev", b"flat_next", b"node_base"):
+        ln.lib.gcdm_set_option(ln.h, name, 0)
+    assert (od[n0:].cpu() - want[n0:]).abs().max().item() <= TOL * max(1.0, want.abs().max().item())
+    ddpm.release_lanes()
+
+
 def test_sampling_with_chain_frames():
     """mol_gen_sample(return_frames=5): un-normalised intermediate frames (gcdm_unnormalize_z) + final decode without CoG re-projection,
     against the oracle (pinned by tests/golden/chain_small_qm9.npz) on the same noise tape."""
