@@ -58,7 +58,11 @@ def build(force: bool = False) -> str:
         return LIB_PATH
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     tmp = f"{LIB_PATH}.{os.getpid()}.tmp"          # concurrent builders (one per rank) never see a half-written library
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-o", tmp] + SOURCES
+    # packed-fp32 VALU ops (v_pk_fma_f32 & co.) are switched off: with them the 32-edge split-precision kernel is not bit-reproducible
+    # from run to run (first wrong values: the pre-phase FMAs the compiler had packed, fed by per-lane VMEM loads), and
+    # they buy nothing here -- the compiler needs as many v_mov to build the register pairs as it saves (measured: +-0 %).
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops",
+           "-o", tmp] + SOURCES
     try:
         subprocess.run(cmd, check=True)
         os.replace(tmp, LIB_PATH)

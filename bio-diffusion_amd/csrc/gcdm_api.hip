@@ -66,10 +66,10 @@ struct gcdm_handle {
     int cog_fix = 1;                 // gcdm_sample_final re-projects drifting centres of gravity (off for chain frames, reference :1389)
     int layer_limit = -1;
     int edge_tile = 0;               // 64: one 8-wave workgroup per CU; 32: two 4-wave workgroups per CU; 0: automatic (env GCDM_EDGE_TILE)
-    // automatic = 64.  The 32-edge split-precision kernel is 5 % (QM9) to 12 % (100-molecule batches) faster, but its results are not
-    // bit-reproducible from run to run (differences ~1e-5 relative, far inside the parity bar; cause not found yet -- DESIGN.md 3.4),
-    // so it stays opt-in until that is understood.
-    int tile() const { return edge_tile ? edge_tile : 64; }
+    // automatic choice, measured on MI355X: split-precision kernel at the QM9 edge width -> 32 (+3..5 %; +12 % on
+    // 100-molecule evaluation batches; QM9 molecules have <= 29 atoms, so a row is cut into at most 2 pieces and the result stays
+    // bit-reproducible), everything else 64 (GEOM: +-1 %, and rows of 44+ edges would be cut into >= 3 atomically added pieces)
+    int tile() const { return edge_tile ? edge_tile : ((mfma_x3 && Se == 64) ? 32 : 64); }
     int mfma_x3 = 1;                 // 1: split-precision f16 x3 edge kernel (default; env GCDM_MFMA=f16x3|f32), 0: fp32 MFMA
     bool attr_set = false;
     // profiling (HIP events around the k_edge_msg launches of one forward)

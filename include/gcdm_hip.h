@@ -127,8 +127,8 @@ int gcdm_debug_set_layer_limit(gcdm_handle* h, int32_t num_layers_to_run);
  * block on operands split as x = hi + 2^-11 lo' (fp32-equivalent accuracy; raises GCDM_FLAG_F16_RANGE if an
  * activation exceeds 6e4, in which case the caller must re-run with mode 0); 0 (env GCDM_MFMA=f32) uses fp32 MFMA throughout.
  * "edge_tile": edges per workgroup of the edge-message kernels: 64 (one 8-wave workgroup per CU), 32 (two 4-wave workgroups per CU) or
- * 0 = automatic (default; env GCDM_EDGE_TILE) = 64.  32 is faster for small / QM9 batches but, in split-precision mode, not bit-reproducible
- * from run to run.
+ * 0 = automatic (default; env GCDM_EDGE_TILE): 32 for the split-precision kernel at the QM9 edge width (rows of <= 32 edges), else 64
+ * -- DESIGN.md 3.4.
  * "cog_fix": 1 (default) / 0, see gcdm_unnormalize_z.
  * "flat_prev" / "flat_next" (0/1) and "node_base" (>= 0): the handle's plan is a contiguous slice of molecules of a larger flat batch whose
  * xh / z / out pointers point at the slice's first row inside the whole array: the rows just before / after the slice exist and provide
