@@ -264,9 +264,13 @@ def main():
     else:
         sliced_flags, sliced_finite = 0, True
     # dominant-kernel timing (HIP events on the launch stream, separate un-timed steps)
+    for _ in range(3):          # settle clocks / caches on the single-handle path before measuring it
+        step(max(s_idx, 0))
+        s_idx -= 1
+    torch.cuda.synchronize(dev)
     lib.gcdm_profile_enable(h, 1)
     tot, cnt = 0.0, 0
-    for _ in range(3):
+    for _ in range(5):
         step(max(s_idx, 0))
         s_idx -= 1
         ms, nl = C.c_double(), C.c_int32()
@@ -323,7 +327,9 @@ def main():
                          "algorithmic_flop_per_launch": alg_edge_layer, "launches_per_step": d["L"], "edges_per_workgroup": int(lib.gcdm_get_option(h, b"edge_tile")),
                          "mfma": ("f16 x3 split (x = hi + 2^-11 lo', fp32 accumulate, fp32-equivalent accuracy); peak = 2500/3" if x3
                                   else "fp32 32x32x2"),
-                         "mfma_busy_frac_pmc": pmc.get("mfma_busy_frac"), "pmc_source": pmc.get("source")},
+                         "mfma_busy_frac_pmc": pmc.get("mfma_busy_frac"), "pmc_source": pmc.get("source"),
+                         "measured_on": "whole-batch launches on one handle, HIP events, un-timed steps after the timed loop (= bench.py --lanes 1, the command "
+                                        "profiled under profiles/); the timed loop runs the batch as config.slices_of_the_batch slices"},
         }
         if not args.no_cpu_baseline and world == 1:
             log("cpu baseline ...")
