@@ -7,7 +7,7 @@
 // HBM/latency bound, ~ microseconds for a whole batch; it exists so that the evaluation loop never leaves the device.
 //
 // Distances: sqrt(dx^2 + dy^2 + dz^2) in fp32, sequentially summed without FMA contraction -- the direct formula ATen's cdist uses
-// for n <= 25; for n > 25 the reference switches to the matmul expansion, whose result differs in the last bits (DESIGN.md 8).
+// for n <= 25; for n > 25 the reference switches to the matmul expansion, whose result differs in the last bits (DESIGN.md 7).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
