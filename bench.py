@@ -328,6 +328,10 @@ def main():
                          "mfma": ("f16 x3 split (x = hi + 2^-11 lo', fp32 accumulate, fp32-equivalent accuracy); peak = 2500/3" if x3
                                   else "fp32 32x32x2"),
                          "mfma_busy_frac_pmc": pmc.get("mfma_busy_frac"), "pmc_source": pmc.get("source"),
+                         # north_star also asks for the HBM side: measured traffic / launch time vs 8 TB/s (the segment reduce is fused, so there is
+                         # no stand-alone scatter kernel whose HBM rate could be quoted)
+                         "hbm_gbps": (pmc["hbm_bytes_per_launch"] / (edge_ms * 1e-3) / 1e9) if pmc.get("hbm_bytes_per_launch") else None,
+                         "hbm_frac_of_8TBps": (pmc["hbm_bytes_per_launch"] / (edge_ms * 1e-3) / 8e12) if pmc.get("hbm_bytes_per_launch") else None,
                          "measured_on": "whole-batch launches on one handle, HIP events, un-timed steps after the timed loop (= bench.py --lanes 1, the command "
                                         "profiled under profiles/); the timed loop runs the batch as config.slices_of_the_batch slices"},
         }
