@@ -204,8 +204,8 @@ def main():
         native.check(ln.lib, ln.h, ln.lib.gcdm_sample_init(ln.h, C.c_void_p(zk.data_ptr()), None, lanes[-1][3], C.c_void_p(ln.stream.cuda_stream)), "gcdm_sample_init")
 
     sliced = None
-    if args.streams > 1:
-        args.lanes = 1                               # several batches in flight already fill the chip
+    if args.streams > 1 or B < 4 * max(1, args.lanes):
+        args.lanes = 1                               # several batches in flight already fill the chip / too few molecules to slice
     if args.lanes > 1:
         ctx_b = None if ctx is None else ctx[torch.cumsum(num_nodes.long(), 0).to(dev) - 1]       # per-molecule context back from per-node
         sliced = ddpm._SlicedBatch(ddpm, num_nodes, dev, ctx_b, 1234 + rank, args.lanes)
