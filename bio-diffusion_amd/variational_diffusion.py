@@ -406,6 +406,12 @@ class EquivariantVariationalDiffusion(nn.Module):
             ln.close()
         self._lanes = []
 
+    def __del__(self):
+        try:
+            self.release_lanes()
+        except Exception:
+            pass
+
     class _SlicedBatch:
         """One flat batch sampled as K contiguous slices of molecules, each on its own handle and HIP stream (same semantics and the
         same Philox noise as the single-handle run: a slice's boundary nodes read their flat neighbours from the adjacent slice,
