@@ -123,7 +123,11 @@ std::vector<float> pack_mfma(Dense& W) {
 }
 
 // split-precision images: x = hi + 2^-11 lo', both f16.  packed[mt][kb][lane][8] = W[32 mt + (lane & 31)][16 kb + 8 (lane >> 5) + s]
+// Packed split-precision weights carry a factor 2^8 (exact): the kernels keep every activation image pre-multiplied by 2^-8 (X3_PRE,
+// gcdm_edge_x3.hip.h), which moves the f16 overflow bound of the activations from 6.5e4 to 1.7e7 at no cost in accuracy (f16
+// denormals are honoured by the MFMA, tools/mfma_denorm.hip); weights stay representable while |W| < 255.
 void split_f16(float x, uint16_t& hi, uint16_t& lo) {
+    x *= 256.0f;
     const _Float16 h = (_Float16)x;
     const _Float16 l = (_Float16)((x - (float)h) * 2048.0f);
     std::memcpy(&hi, &h, 2);

@@ -20,28 +20,31 @@ typedef _Float16 h4 __attribute__((ext_vector_type(4)));
 #define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16((a), (b), (c), 0, 0, 0)
 #define X3_SCALE 2048.0f
 #define X3_INV_SCALE (1.0f / 2048.0f)
-#define X3_RANGE 6.0e4f
+#define X3_PRE (1.0f / 256.0f)           // every image holds x * 2^-8, the packed weights carry the 2^8 (gcdm_api.hip: split_f16)
+#define X3_RANGE (6.0e4f * 256.0f)       // bound on the un-scaled activation
 
 __device__ __forceinline__ void split16(float x, _Float16& hi, _Float16& lo) {
-    hi = (_Float16)x;
-    // (x - hi) * 2^11, written so that it maps to one mixed-precision FMA (v_fma_mixlo_f16): both products are exact (powers of two)
-    lo = (_Float16)__builtin_fmaf((float)hi, -X3_SCALE, x * X3_SCALE);
+    hi = (_Float16)(x * X3_PRE);
+    // (x 2^-8 - hi) * 2^11, written so that it maps to one mixed-precision FMA (v_fma_mixlo_f16): both products are exact (powers of two)
+    lo = (_Float16)__builtin_fmaf((float)hi, -X3_SCALE, x * (X3_SCALE * X3_PRE));
 }
 
-// Two values at once: 1 packed convert (hi, round-to-nearest), 1 packed multiply, 2 mixed-precision FMAs that read hi as f16 and write
-// the two halves of the lo' pair -- 2 VALU instructions per value instead of ~4 (the compiler does not form v_fma_mix* reliably).
-// Bit-identical to split16: (x - hi) * 2^11 is exact in fp32 either way, one rounding to f16 at the end.
+// Two values at once, 3 VALU instructions per value: one multiply (x * 2^3) and two mixed-precision FMAs -- v_fma_mix{lo,hi}_f16 writes
+// f16(x * 2^-8) resp. f16(x * 2^3 - hi * 2^11) into one half of the destination, reading hi as f16 (the compiler does not form these
+// reliably).  Bit-identical to split16: all products are by powers of two, one rounding to f16 at the end of each.
 typedef _Float16 h2 __attribute__((ext_vector_type(2)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void split16x2(float x0, float x1, h2& hi, h2& lo) {
-    const f32x2 xs = {x0, x1};
-    hi = __builtin_convertvector(xs, h2);
-    const f32x2 sc = xs * X3_SCALE;
-    const float neg = -X3_SCALE;
+    const float pre = X3_PRE, neg = -X3_SCALE;
+    const float s0 = x0 * (X3_SCALE * X3_PRE), s1 = x1 * (X3_SCALE * X3_PRE);
     uint32_t hiu, lou;
-    __builtin_memcpy(&hiu, &hi, 4);
-    asm("v_fma_mixlo_f16 %0, %1, %2, %3 op_sel_hi:[1,0,0]" : "=v"(lou) : "v"(hiu), "s"(neg), "v"(sc[0]));
-    asm("v_fma_mixhi_f16 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(lou) : "v"(hiu), "s"(neg), "v"(sc[1]));
+    // hi = f16(x * 2^-8) (round to nearest), both halves of one register
+    asm("v_fma_mixlo_f16 %0, %1, %2, 0 op_sel_hi:[0,0,0]" : "=v"(hiu) : "v"(x0), "s"(pre));
+    asm("v_fma_mixhi_f16 %0, %1, %2, 0 op_sel_hi:[0,0,0]" : "+v"(hiu) : "v"(x1), "s"(pre));
+    // lo' = f16(x * 2^3 - hi * 2^11): hi is read as f16 from the low / high half
+    asm("v_fma_mixlo_f16 %0, %1, %2, %3 op_sel_hi:[1,0,0]" : "=v"(lou) : "v"(hiu), "s"(neg), "v"(s0));
+    asm("v_fma_mixhi_f16 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(lou) : "v"(hiu), "s"(neg), "v"(s1));
+    __builtin_memcpy(&hi, &hiu, 4);
     __builtin_memcpy(&lo, &lou, 4);
 }
 
