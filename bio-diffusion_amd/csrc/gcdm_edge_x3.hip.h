@@ -10,7 +10,8 @@
 //   * weights are split once on the host (two packed f16 arrays, same bytes as fp32);
 //   * the message scalars live as fp32 in REGISTERS of the wave that owns their 64 channels (residual adds are exact fp32);
 //     LDS holds only their hi / lo' images in 8-channel groups (XH8 / XL8: 16 B per group, same footprint as fp32);
-//   * f16 range: |x| >= 6e4 cannot be represented -> GCDM_FLAG_F16_RANGE is raised and the caller re-runs in fp32 mode.
+//   * f16 range: images hold x * 2^-8 (the packed weights carry the 2^8), so |x| up to 1.5e7 is representable; beyond that
+//     GCDM_FLAG_F16_RANGE is raised and the caller re-runs in fp32 mode.
 #pragma once
 #include "gcdm_kernels.hip.h"
 
