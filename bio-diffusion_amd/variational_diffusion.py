@@ -62,6 +62,22 @@ def polynomial_gamma(num_timesteps: int, noise_precision: float, power: float) -
     return -(np.log(a2) - np.log(1 - a2))
 
 
+def slice_cuts(num_nodes: torch.Tensor, K: int) -> List[int]:
+    """Molecule indices [c_0 = 0, c_1, ..., c_K = B] that cut a flat batch into K contiguous, non-empty slices of roughly equal work
+    (edges, i.e. sum of n^2) -- used when one batch is sampled on K handles / streams."""
+    nn_ = torch.as_tensor(num_nodes).long().cpu()
+    Bm = len(nn_)
+    if not 1 <= K <= Bm:
+        raise ValueError(f"cannot cut {Bm} molecules into {K} non-empty slices")
+    work_cum = (nn_ ** 2).cumsum(0)
+    cuts = [0]
+    for k in range(1, K):
+        c = int(torch.searchsorted(work_cum, work_cum[-1] * k // K).item()) + 1
+        cuts.append(min(max(c, cuts[-1] + 1), Bm - (K - k)))
+    cuts.append(Bm)
+    return cuts
+
+
 class PredefinedNoiseSchedule(nn.Module):
     def __init__(self, noise_schedule: str, num_timesteps: int, noise_precision: float, verbose: bool = False, **kwargs):
         super().__init__()
@@ -425,12 +441,7 @@ class EquivariantVariationalDiffusion(nn.Module):
             self.dyn = dyn
             nn_ = torch.as_tensor(num_nodes, dtype=torch.int32, device="cpu")
             Bm = len(nn_)
-            work_cum = (nn_.long() ** 2).cumsum(0)
-            cuts = [0]
-            for k in range(1, K):                               # balance by edges, keep every slice non-empty
-                c = int(torch.searchsorted(work_cum, work_cum[-1] * k // K).item()) + 1
-                cuts.append(min(max(c, cuts[-1] + 1), Bm - (K - k)))
-            cuts.append(Bm)
+            cuts = slice_cuts(nn_, K)
             self.cuts = cuts
             self.node_off = torch.cat((torch.zeros(1, dtype=torch.long), nn_.long().cumsum(0))).tolist()
             lanes = getattr(ddpm, "_lanes", None) or []
