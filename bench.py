@@ -135,6 +135,8 @@ def main():
     ap.add_argument("--workload", default="qm9", choices=sorted(WORKLOADS))
     ap.add_argument("--batch", type=int, default=0, help="molecules per GPU (default: the workload's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-fp32-timing", action="store_true", help="skip the few un-timed fp32-MFMA-mode steps (config.fp32_mfma_mode_ms_per_step); "
+                                                                   "used when profiling so that the kernel statistics show the default mode only")
     ap.add_argument("--lanes", type=int, default=2, help="sample the ONE flat batch as this many slices of molecules on separate handles / HIP "
                                                          "streams (same semantics, same noise; fills the round-quantisation tails)")
     ap.add_argument("--streams", type=int, default=1, help="independent batches in flight per GPU, each on its own handle and HIP stream "
@@ -289,7 +291,7 @@ def main():
     # guard (GCDM_FLAG_F16_RANGE) makes the caller re-run it (a few un-timed steps on the whole batch; reported for transparency)
     x3_mode = int(lib.gcdm_get_option(h, b"mfma_mode"))
     fallback_ms = None
-    if x3_mode == 1:
+    if x3_mode == 1 and not args.no_fp32_timing:
         lib.gcdm_set_option(h, b"mfma_mode", 0)
         for _ in range(2):
             step(max(s_idx, 0)); s_idx -= 1
