@@ -115,7 +115,7 @@ def load_pmc_summary(workload, x3):
     with open(files[-1]) as f:
         d = json.load(f)
     for k, v in d.items():
-        if k.startswith("k_edge_msg"):
+        if k.startswith("k_edge_msg_x3" if x3 else "k_edge_msg<"):
             out = dict(v)
             out["source"] = os.path.relpath(files[-1], ROOT)
             return out
