@@ -51,3 +51,22 @@ def gather_samples(out: torch.Tensor, num_nodes_local: torch.Tensor, group: Opti
     xs: List[torch.Tensor] = [o[: int(m[0].item())] for o, m in zip(outs, metas)]
     ns: List[torch.Tensor] = [n[: int(m[1].item())] for n, m in zip(nns, metas)]
     return torch.cat(xs, dim=0), torch.cat(ns, dim=0)
+
+
+def sample_sharded(ddpm, num_nodes: torch.Tensor, device, context: Optional[torch.Tensor] = None, num_timesteps: Optional[int] = None,
+                   seed: int = 1234, lanes: int = 2, group: Optional[dist.ProcessGroup] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+    """The whole multi-GPU recipe: this rank samples its block of molecules (``EquivariantVariationalDiffusion.mol_gen_sample`` on
+    ``device``, its own Philox stream ``seed + rank``), then one gather.  Returns (xh [N_total, 3+F], num_nodes [B_total]) on every rank,
+    molecules in the original order.  Works without an initialised process group (single GPU)."""
+    if dist.is_available() and dist.is_initialized():
+        rank, world = dist.get_rank(group), dist.get_world_size(group)
+    else:
+        rank, world = 0, 1
+    lo, hi = shard_range(len(num_nodes), rank, world)
+    local = num_nodes[lo:hi]
+    ctx = None if context is None else context[lo:hi]
+    xh, _, _ = ddpm.mol_gen_sample(num_samples=len(local), num_nodes=local, device=device, num_timesteps=num_timesteps, context=ctx,
+                                   seed=seed + rank, lanes=lanes)
+    if world == 1:
+        return xh, torch.as_tensor(local).to(torch.int64)
+    return gather_samples(xh, torch.as_tensor(local), group)
