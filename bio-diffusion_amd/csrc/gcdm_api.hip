@@ -61,8 +61,10 @@ struct gcdm_handle {
     float *X0 = nullptr, *XC = nullptr, *FBAR = nullptr, *CHI0 = nullptr, *HIN4 = nullptr, *H4 = nullptr, *CHI = nullptr, *PQ4 = nullptr,
           *VDI = nullptr, *VDJ = nullptr, *AGG = nullptr, *VEL = nullptr, *EPS = nullptr, *TBUF = nullptr, *EP4 = nullptr, *AL = nullptr, *U = nullptr, *FR = nullptr, *PROF = nullptr;
     uint32_t* d_flags = nullptr;
+    float* d_gmean = nullptr;
     int flat_prev = 0, flat_next = 0;   // the plan is a slice of a larger flat batch (options "flat_prev" / "flat_next"; include/gcdm_hip.h)
     uint32_t node_base = 0;             // option "node_base": flat index of the slice's first node (Philox counter)
+    int fix_noise = 0;                  // option "fix_noise": x-noise centred over the whole flat batch (mol_gen_sample(fix_noise=True))
     int cog_fix = 1;                 // gcdm_sample_final re-projects drifting centres of gravity (off for chain frames, reference :1389)
     int layer_limit = -1;
     int edge_tile = 0;               // 64: one 8-wave workgroup per CU; 32: two 4-wave workgroups per CU; 0: automatic (env GCDM_EDGE_TILE)
@@ -366,6 +368,7 @@ int gcdm_destroy(gcdm_handle* h) {
     for (auto& e : h->ev) (void)hipEventDestroy(e);
     if (h->wpool) (void)hipFree(h->wpool);
     if (h->d_flags) (void)hipFree(h->d_flags);
+    if (h->d_gmean) (void)hipFree(h->d_gmean);
     delete h;
     return 0;
 }
@@ -745,6 +748,11 @@ static float gamma_lookup(const gcdm_handle* h, float t) {
 
 static int launch_sample(gcdm_handle* h, StepArgs& sa, hipStream_t st) {
     sa.noff = h->d_noff; sa.N = h->N; sa.D = h->D; sa.node_base = h->node_base;
+    if (h->fix_noise) {                 // pre-pass: mean of this draw over all nodes (deterministic order)
+        if (!h->d_gmean) HIP_OK(h, hipMalloc(&h->d_gmean, 4 * sizeof(float)));
+        hipLaunchKernelGGL(k_noise_mean, dim3(1), dim3(1024), 0, st, sa.noise, sa.seed, sa.draw, h->node_base, h->N, h->D, h->d_gmean);
+        sa.gmean = h->d_gmean;
+    }
     hipLaunchKernelGGL(k_sample, dim3(h->B), dim3(64), (size_t)h->max_n * h->D * sizeof(float), st, sa);
     HIP_OK(h, hipGetLastError());
     return 0;
@@ -849,6 +857,7 @@ int gcdm_set_option(gcdm_handle* h, const char* name, int32_t value) {
         return 0;
     }
     if (k == "cog_fix") { h->cog_fix = value ? 1 : 0; return 0; }
+    if (k == "fix_noise") { h->fix_noise = value ? 1 : 0; return 0; }
     if (k == "flat_prev") { h->flat_prev = value ? 1 : 0; return 0; }
     if (k == "flat_next") { h->flat_next = value ? 1 : 0; return 0; }
     if (k == "node_base") { if (value < 0) return fail(h, "gcdm_set_option(node_base): >= 0"); h->node_base = (uint32_t)value; return 0; }
@@ -866,6 +875,7 @@ int gcdm_get_option(const gcdm_handle* h, const char* name) {
     if (k == "mfma_mode") return h->mfma_x3;
     if (k == "edge_tile") return h->tile();
     if (k == "cog_fix") return h->cog_fix;
+    if (k == "fix_noise") return h->fix_noise;
     if (k == "flat_prev") return h->flat_prev;
     if (k == "flat_next") return h->flat_next;
     if (k == "node_base") return (int)h->node_base;

@@ -1001,6 +1001,7 @@ struct StepArgs {
     float* z;            // [N][D] in/out
     float* z_out;        // step / init: where the new latent goes (null = in place)
     uint32_t node_base;  // flat index of node 0 in the whole batch (Philox counter), for plans that are slices of a flat batch
+    const float* gmean;  // fix_noise (variational_diffusion.py:832-834, 1323-1325): x-noise is centred over the WHOLE flat batch -> its mean [3], else null
     const float* eps;    // [N][D] network output (null for init)
     const float* noise;  // [N][D] or null -> Philox
     const int* noff; int N, D;
@@ -1080,6 +1081,25 @@ __global__ void k_mean_flag(const uint32_t* stat, uint32_t* user_flags) {
     if (!(err / (largest + 1e-10f) < 1e-2f)) atomicOr(user_flags, 2u);      // GCDM_FLAG_MEAN_NOT_ZERO
 }
 
+// fix_noise: mean of the x-part of one noise draw over all N nodes, in a fixed order (one workgroup; thread i takes nodes i, i+1024, ...)
+__global__ __launch_bounds__(1024) void k_noise_mean(const float* __restrict__ noise, uint64_t seed, uint32_t draw, uint32_t node_base, int N, int D, float* __restrict__ gmean) {
+    __shared__ float red[3][1024];
+    float s[3] = {0.f, 0.f, 0.f};
+    for (int i = threadIdx.x; i < N; i += 1024)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) s[c] += noise ? noise[(size_t)i * D + c] : philox_normal(seed, draw, node_base + (uint32_t)i, (uint32_t)c);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) red[c][threadIdx.x] = s[c];
+    __syncthreads();
+    for (int w = 512; w > 0; w >>= 1) {
+        if ((int)threadIdx.x < w)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) red[c][threadIdx.x] += red[c][threadIdx.x + w];
+        __syncthreads();
+    }
+    if (threadIdx.x < 3) gmean[threadIdx.x] = red[threadIdx.x][0] / (float)N;
+}
+
 __global__ __launch_bounds__(64) void k_sample(StepArgs a) {
     extern __shared__ __attribute__((aligned(16))) float ns[];  // [n][D] noise, then results
     const int b = blockIdx.x, o = a.noff[b], n = a.noff[b + 1] - o, D = a.D;
@@ -1092,6 +1112,7 @@ __global__ __launch_bounds__(64) void k_sample(StepArgs a) {
     float m[3] = {0.f, 0.f, 0.f};
     for (int i = 0; i < n; ++i) { m[0] += ns[i * D]; m[1] += ns[i * D + 1]; m[2] += ns[i * D + 2]; }
     m[0] /= (float)n; m[1] /= (float)n; m[2] /= (float)n;
+    if (a.gmean) { m[0] = a.gmean[0]; m[1] = a.gmean[1]; m[2] = a.gmean[2]; }
     __syncthreads();
     for (int idx = threadIdx.x; idx < n * D; idx += 64) {
         const int i = idx / D, c = idx - i * D;

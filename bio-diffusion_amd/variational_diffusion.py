@@ -241,8 +241,10 @@ class EquivariantVariationalDiffusion(nn.Module):
         """Draw samples.  ``noise_fn(k)`` (optional) returns the k-th raw standard-normal draw [N,3+F] on ``device``
         (k = 0 for z_T, then one per step, then one for the final decode: the reference's randn call order,
         SURVEY A.5); without it noise comes from on-device Philox(seed)."""
-        if fix_noise or generate_x_only:
-            raise NotImplementedError("mol_gen_sample (HIP): fix_noise / generate_x_only are not built")
+        if generate_x_only:
+            raise NotImplementedError("mol_gen_sample (HIP): generate_x_only is not built")
+        if fix_noise:
+            lanes = 1                  # the noise is centred over the whole flat batch: one handle sees all of it
         num_timesteps = self.T if num_timesteps is None else num_timesteps
         assert 0 < return_frames <= num_timesteps, "Number of frames cannot be greater than number of timesteps."
         assert num_timesteps % return_frames == 0, "Number of frames must be evenly divisible by number of timesteps."
@@ -274,6 +276,7 @@ class EquivariantVariationalDiffusion(nn.Module):
         flags = torch.zeros(1, dtype=torch.int32, device=device)
         fptr = C.c_void_p(flags.data_ptr())
         z = torch.empty((N, D), dtype=torch.float32, device=device)
+        _native.check(lib, h, lib.gcdm_set_option(h, b"fix_noise", int(bool(fix_noise))), "gcdm_set_option")
         frames = torch.zeros((return_frames, N, D), dtype=torch.float32, device=device)     # frame 0 = the final sample (:1404-1410)
         out = frames[0]
         k = 0
@@ -309,6 +312,7 @@ class EquivariantVariationalDiffusion(nn.Module):
         _native.check(lib, h, lib.gcdm_set_option(h, b"cog_fix", 1 if return_frames == 1 else 0), "gcdm_set_option")   # :1389
         st = lib.gcdm_sample_final(h, C.c_void_p(z.data_ptr()), ctx_ptr, p, C.c_uint64(seed), C.c_void_p(out.data_ptr()), fptr, stream)
         lib.gcdm_set_option(h, b"cog_fix", 1)
+        lib.gcdm_set_option(h, b"fix_noise", 0)
         _native.check(lib, h, st, "gcdm_sample_final")
         fl = int(flags.item())   # the one host sync of the run
         if fl & _native.FLAG_F16_RANGE:

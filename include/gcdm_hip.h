@@ -130,6 +130,8 @@ int gcdm_debug_set_layer_limit(gcdm_handle* h, int32_t num_layers_to_run);
  * 0 = automatic (default; env GCDM_EDGE_TILE): 32 for the split-precision kernel at the QM9 edge width (rows of <= 32 edges), else 64
  * -- DESIGN.md 3.4.
  * "cog_fix": 1 (default) / 0, see gcdm_unnormalize_z.
+ * "fix_noise" (0/1): the x-part of every noise draw is centred over the whole flat batch instead of per molecule, as the reference's
+ * `fix_noise=True` does (variational_diffusion.py:832-834, 1323-1325; used by sample_sweep_conditionally, src/models/__init__.py:200-226).
  * "flat_prev" / "flat_next" (0/1) and "node_base" (>= 0): the handle's plan is a contiguous slice of molecules of a larger flat batch whose
  * xh / z / out pointers point at the slice's first row inside the whole array: the rows just before / after the slice exist and provide
  * the flat-batch neighbours of its first / last node; node_base = index of the slice's first node in the whole batch (Philox counter, so that

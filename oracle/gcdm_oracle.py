@@ -324,18 +324,19 @@ class TapeNoise:
         return torch.randn((n, k), generator=self.gen, dtype=torch.float32).to(dtype)
 
 
-def sample_combined_noise(noise, batch_index: Tensor, B: int, mask: Tensor, F_: int, dtype) -> Tensor:
-    """variational_diffusion.py:795-819: CoM-free x-noise, plain h-noise."""
+def sample_combined_noise(noise, batch_index: Tensor, B: int, mask: Tensor, F_: int, dtype, fix_noise: bool = False) -> Tensor:
+    """variational_diffusion.py:795-819: CoM-free x-noise, plain h-noise.  `fix_noise` (:832-834, 1323-1325): the reference passes an all-zero
+    batch index, i.e. the x-noise is centred over the whole flat batch as if it were one molecule."""
     N = batch_index.shape[0]
     zx = noise(N, 3, dtype) * mask.to(dtype)[:, None]
-    zx = centralize(zx, batch_index, B, mask)
+    zx = centralize(zx, torch.zeros_like(batch_index), 1, mask) if fix_noise else centralize(zx, batch_index, B, mask)
     zh = noise(N, F_, dtype) * mask.to(dtype)[:, None]
     return torch.cat((zx, zh), dim=-1)
 
 
 def sample_p_zs_given_zt(P: Params, cfg: OracleConfig, gam: Tensor, s: float, t: float, z: Tensor,
                          batch_index: Tensor, B: int, mask: Tensor, context: Optional[Tensor], noise,
-                         eps_override: Optional[Tensor] = None) -> Tuple[Tensor, Tensor]:
+                         eps_override: Optional[Tensor] = None, fix_noise: bool = False) -> Tuple[Tensor, Tensor]:
     """variational_diffusion.py:1204-1278.  Returns (z_s, eps_t)."""
     dt = z.dtype
     sv = torch.full((B, 1), s, dtype=dt)
@@ -346,13 +347,13 @@ def sample_p_zs_given_zt(P: Params, cfg: OracleConfig, gam: Tensor, s: float, t:
     eps = dynamics_forward(P, cfg, z, tv[batch_index], batch_index, mask, context) if eps_override is None else eps_override
     mu = z / ats[batch_index] - (s2ts[batch_index] / ats[batch_index] / sig_t[batch_index]) * eps
     sigma = sts * sig_s / sig_t
-    zs = mu + sigma[batch_index] * sample_combined_noise(noise, batch_index, B, mask, cfg.num_node_scalar_features, dt)
+    zs = mu + sigma[batch_index] * sample_combined_noise(noise, batch_index, B, mask, cfg.num_node_scalar_features, dt, fix_noise)
     zs = torch.cat((centralize(zs[:, :3], batch_index, B, mask), zs[:, 3:]), dim=-1)
     return zs, eps
 
 
 def sample_p_xh_given_z0(P: Params, cfg: OracleConfig, gam: Tensor, z0: Tensor, batch_index: Tensor, B: int,
-                         mask: Tensor, context: Optional[Tensor], noise):
+                         mask: Tensor, context: Optional[Tensor], noise, fix_noise: bool = False):
     """variational_diffusion.py:840-907 (+ unnormalize :735-757)."""
     dt = z0.dtype
     t0 = torch.zeros((B, 1), dtype=dt)
@@ -361,7 +362,7 @@ def sample_p_xh_given_z0(P: Params, cfg: OracleConfig, gam: Tensor, z0: Tensor, 
     eps = dynamics_forward(P, cfg, z0, t0[batch_index], batch_index, mask, context)
     sig0, alp0 = torch.sqrt(torch.sigmoid(g0)), torch.sqrt(torch.sigmoid(-g0))
     mu = 1.0 / alp0[batch_index] * (z0 - sig0[batch_index] * eps)
-    xh = mu + sigma_x[batch_index] * sample_combined_noise(noise, batch_index, B, mask, cfg.num_node_scalar_features, dt)
+    xh = mu + sigma_x[batch_index] * sample_combined_noise(noise, batch_index, B, mask, cfg.num_node_scalar_features, dt, fix_noise)
     x = xh[:, :3] * cfg.norm_values[0]
     mf = mask.to(dt)[:, None]
     if cfg.include_charges:
@@ -390,7 +391,7 @@ def unnormalize_z(cfg: OracleConfig, z: Tensor, mask: Tensor) -> Tensor:
 
 def mol_gen_sample(P: Params, cfg: OracleConfig, num_nodes: Tensor, noise, context: Optional[Tensor] = None,
                    num_timesteps: Optional[int] = None, dtype=torch.float32,
-                   record: Optional[List[Tensor]] = None, return_frames: int = 1) -> Tuple[Tensor, Tensor]:
+                   record: Optional[List[Tensor]] = None, return_frames: int = 1, fix_noise: bool = False) -> Tuple[Tensor, Tensor]:
     """EquivariantVariationalDiffusion.mol_gen_sample, variational_diffusion.py:1282-1412
     (no self-conditioning, fix_noise False).  Returns (out [N,3+F] or [return_frames,N,3+F], batch_index)."""
     T = cfg.num_timesteps if num_timesteps is None else num_timesteps
@@ -402,15 +403,15 @@ def mol_gen_sample(P: Params, cfg: OracleConfig, num_nodes: Tensor, noise, conte
     if context is not None:
         ctx = context.to(dtype)[bi] * mask.to(dtype)[:, None]
     gam = gamma_table(cfg)
-    z = sample_combined_noise(noise, bi, B, mask, cfg.num_node_scalar_features, dtype)
+    z = sample_combined_noise(noise, bi, B, mask, cfg.num_node_scalar_features, dtype, fix_noise)
     frames = torch.zeros((return_frames,) + tuple(z.shape), dtype=dtype)
     for s in reversed(range(T)):
-        z, _ = sample_p_zs_given_zt(P, cfg, gam, s / T, (s + 1) / T, z, bi, B, mask, ctx, noise)
+        z, _ = sample_p_zs_given_zt(P, cfg, gam, s / T, (s + 1) / T, z, bi, B, mask, ctx, noise, fix_noise=fix_noise)
         if record is not None:
             record.append(z.clone())
         if (s * return_frames) % T == 0:                          # :1354-1361
             frames[(s * return_frames) // T] = unnormalize_z(cfg, z, mask)
-    x, one_hot, charges = sample_p_xh_given_z0(P, cfg, gam, z, bi, B, mask, ctx, noise)
+    x, one_hot, charges = sample_p_xh_given_z0(P, cfg, gam, z, bi, B, mask, ctx, noise, fix_noise)
     if return_frames == 1:
         cog = torch.zeros(B, 3, dtype=dtype).index_add_(0, bi, x).abs().max().item()
         if cog > 5e-2:                                            # :1392-1402

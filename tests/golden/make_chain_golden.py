@@ -1,5 +1,5 @@
 """Golden vectors for sampling with intermediate frames (`return_frames > 1`, the chain-visualisation mode of
-`mol_gen_sample`, src/models/components/variational_diffusion.py:1282-1412), produced by the REFERENCE itself on the reduced-width QM9
+`mol_gen_sample`, src/models/components/variational_diffusion.py:1282-1412) and with `fix_noise=True` (:1323-1325, 832-834), produced by the REFERENCE itself on the reduced-width QM9
 model of `sampler_small_qm9.npz` (same weight seed; weights not stored again).  -> tests/golden/chain_small_qm9.npz
 
     python tests/golden/make_chain_golden.py        (build container only)
@@ -24,7 +24,9 @@ def main():
     nn_ = torch.tensor([5, 7, 3, 6])
     with rh.NoiseTape(1234) as tape, torch.no_grad():
         frames, bi, _ = ddpm.mol_gen_sample(num_samples=len(nn_), num_nodes=nn_, device="cpu", num_timesteps=12, return_frames=4)
-    out = dict(num_nodes=nn_.numpy(), T=12, return_frames=4, seed=1234, frames=frames.numpy(),
+    with rh.NoiseTape(1234) as tape2, torch.no_grad():
+        fixed, _, _ = ddpm.mol_gen_sample(num_samples=len(nn_), num_nodes=nn_, device="cpu", num_timesteps=12, fix_noise=True)
+    out = dict(num_nodes=nn_.numpy(), T=12, return_frames=4, seed=1234, frames=frames.numpy(), fix_noise_out=fixed.numpy(),
                weight_check=next(iter(net.state_dict().values())).float().numpy())
     np.savez_compressed(os.path.join(HERE, "chain_small_qm9.npz"), **out)
     print("frames", tuple(frames.shape), "calls", len(tape.calls))

@@ -354,6 +354,20 @@ def test_sampling_with_chain_frames():
     assert (out[0, :, :3] - want[0, :, :3]).abs().max().item() <= TOL * scale and torch.equal(out[0, :, 3:], want[0, :, 3:])
     with pytest.raises(AssertionError):
         ddpm.mol_gen_sample(num_samples=len(nn_), num_nodes=nn_, device="cuda", num_timesteps=10, return_frames=3)
+    # fix_noise=True (sample_sweep_conditionally): every draw's x-part centred over the whole flat batch, tape and Philox noise
+    wantf, _ = O.mol_gen_sample(W, ocfg, nn_, O.TapeNoise(1234), num_timesteps=Tp, fix_noise=True)
+    outf, _, _ = ddpm.mol_gen_sample(num_samples=len(nn_), num_nodes=nn_, device="cuda", num_timesteps=Tp, fix_noise=True, noise_fn=lambda k: draws[k])
+    outf = outf.cpu()
+    sc = max(1.0, wantf[:, :3].abs().max().item())
+    assert (outf[:, :3] - wantf[:, :3]).abs().max().item() <= TOL * sc and torch.equal(outf[:, 3:], wantf[:, 3:])
+    dyn, lib, h = ddpm._native(torch.device("cuda"))
+    dyn.plan(nn_)
+    z = torch.empty((N, 3 + F), device="cuda")
+    assert lib.gcdm_set_option(h, b"fix_noise", 1) == 0
+    assert lib.gcdm_sample_init(h, C.c_void_p(z.data_ptr()), None, C.c_uint64(3), C.c_void_p(torch.cuda.current_stream().cuda_stream)) == 0
+    assert lib.gcdm_set_option(h, b"fix_noise", 0) == 0
+    torch.cuda.synchronize()
+    assert z[:, :3].sum(0).abs().max().item() < 1e-4 and z[:7, :3].sum(0).abs().max().item() > 1e-2     # zero mean over the batch, not per molecule
 
 
 @pytest.mark.parametrize("orig", [False, True])

@@ -128,6 +128,11 @@ def test_sampling_chain_frames_small(golden_dir):
     scale = max(1.0, ref.abs().max().item())
     assert (frames[1:] - ref[1:]).abs().max().item() <= 1e-4 * scale
     assert (frames[0, :, :3] - ref[0, :, :3]).abs().max().item() <= 1e-4 * scale and torch.equal(frames[0, :, 3:], ref[0, :, 3:])
+    # fix_noise=True: x-noise centred over the whole flat batch
+    fixed, _ = O.mol_gen_sample(P, cfg, g["num_nodes"], O.TapeNoise(int(g["seed"])), num_timesteps=int(g["T"]), fix_noise=True)
+    rf = g["fix_noise_out"]
+    assert (fixed[:, :3] - rf[:, :3]).abs().max().item() <= 1e-4 * max(1.0, rf[:, :3].abs().max().item()) and torch.equal(fixed[:, 3:], rf[:, 3:])
+    assert (rf[:, :3] - ref[0, :, :3]).abs().max().item() > 1e-3       # and it is a different sample than the per-molecule centring gives
 
 
 def test_mol_gen_optimize_small(golden_dir):
