@@ -55,6 +55,7 @@ class OracleConfig:
     noise_precision: float = 1e-5
     norm_values: Sequence[float] = (1.0, 4.0, 10.0)
     norm_biases: Sequence[Optional[float]] = (None, 0.0, 0.0)
+    self_condition: bool = False         # diffusion_cfg.self_condition (False in both production configs)
 
     @property
     def num_node_scalar_features(self) -> int:
@@ -237,10 +238,12 @@ def infer_num_layers(P: Params) -> int:
 
 def dynamics_forward(P: Params, cfg: OracleConfig, xh: Tensor, t: Tensor, batch_index: Tensor,
                      mask: Optional[Tensor] = None, context: Optional[Tensor] = None,
-                     return_intermediates: bool = False):
-    """GCPNetDynamics.atom_types_and_coords_forward, gcpnet.py:1069-1232 (self_condition False).
+                     return_intermediates: bool = False, xh_self_cond: Optional[Tensor] = None):
+    """GCPNetDynamics.atom_types_and_coords_forward, gcpnet.py:1069-1232.
 
     xh [N,3+F], t [N,1], batch_index [N] sorted, context [N,C] or None  ->  net_out [N,3+F].
+    With cfg.self_condition (:1112-1139) the previous estimate `xh_self_cond` (zeros if None) contributes its features, orientations and
+    edge features to the embedding inputs: h -> [h | h_sc], chi -> 4 vectors, e -> 2 scalars, xi -> 2 vectors.
     """
     N = xh.shape[0]
     mask = torch.ones(N, dtype=torch.bool) if mask is None else mask
@@ -252,6 +255,14 @@ def dynamics_forward(P: Params, cfg: OracleConfig, xh: Tensor, t: Tensor, batch_
     chi = orientations(x0)                                      # :1105
     e, xi = edge_features(x0, row, col)                         # :1109 (un-centralised x)
     h = h0
+    if cfg.self_condition:                                      # :1112-1139 (x_self_cond is NOT masked / centralised)
+        x_sc = xh_self_cond[:, :3].clone() if xh_self_cond is not None else torch.zeros_like(x0)
+        h_sc = xh_self_cond[:, 3:].clone() if xh_self_cond is not None else torch.zeros_like(h0)
+        e_sc, xi_sc = edge_features(x_sc, row, col)
+        h = torch.cat((h, h_sc), dim=-1)
+        chi = torch.cat((chi, orientations(x_sc)), dim=1)
+        e = torch.cat((e, e_sc), dim=-1)
+        xi = torch.cat((xi, xi_sc), dim=1)
     if cfg.condition_on_time:
         h = torch.cat((h, t.view(N, 1)), dim=-1)               # :1142-1150
     if cfg.num_context:
@@ -336,7 +347,8 @@ def sample_combined_noise(noise, batch_index: Tensor, B: int, mask: Tensor, F_: 
 
 def sample_p_zs_given_zt(P: Params, cfg: OracleConfig, gam: Tensor, s: float, t: float, z: Tensor,
                          batch_index: Tensor, B: int, mask: Tensor, context: Optional[Tensor], noise,
-                         eps_override: Optional[Tensor] = None, fix_noise: bool = False) -> Tuple[Tensor, Tensor]:
+                         eps_override: Optional[Tensor] = None, fix_noise: bool = False,
+                         xh_self_cond: Optional[Tensor] = None) -> Tuple[Tensor, Tensor]:
     """variational_diffusion.py:1204-1278.  Returns (z_s, eps_t)."""
     dt = z.dtype
     sv = torch.full((B, 1), s, dtype=dt)
@@ -344,7 +356,8 @@ def sample_p_zs_given_zt(P: Params, cfg: OracleConfig, gam: Tensor, s: float, t:
     gs, gt = gamma_at(gam, sv, cfg.num_timesteps).to(dt), gamma_at(gam, tv, cfg.num_timesteps).to(dt)
     s2ts, sts, ats = sigma_and_alpha_t_given_s(gt, gs)
     sig_s, sig_t = torch.sqrt(torch.sigmoid(gs)), torch.sqrt(torch.sigmoid(gt))
-    eps = dynamics_forward(P, cfg, z, tv[batch_index], batch_index, mask, context) if eps_override is None else eps_override
+    eps = (dynamics_forward(P, cfg, z, tv[batch_index], batch_index, mask, context, xh_self_cond=xh_self_cond)
+           if eps_override is None else eps_override)
     mu = z / ats[batch_index] - (s2ts[batch_index] / ats[batch_index] / sig_t[batch_index]) * eps
     sigma = sts * sig_s / sig_t
     zs = mu + sigma[batch_index] * sample_combined_noise(noise, batch_index, B, mask, cfg.num_node_scalar_features, dt, fix_noise)
@@ -353,13 +366,13 @@ def sample_p_zs_given_zt(P: Params, cfg: OracleConfig, gam: Tensor, s: float, t:
 
 
 def sample_p_xh_given_z0(P: Params, cfg: OracleConfig, gam: Tensor, z0: Tensor, batch_index: Tensor, B: int,
-                         mask: Tensor, context: Optional[Tensor], noise, fix_noise: bool = False):
+                         mask: Tensor, context: Optional[Tensor], noise, fix_noise: bool = False, xh_self_cond: Optional[Tensor] = None):
     """variational_diffusion.py:840-907 (+ unnormalize :735-757)."""
     dt = z0.dtype
     t0 = torch.zeros((B, 1), dtype=dt)
     g0 = gamma_at(gam, t0, cfg.num_timesteps).to(dt)
     sigma_x = torch.exp(-(-0.5 * g0))                            # SNR(-0.5*gamma_0) = exp(0.5*gamma_0)
-    eps = dynamics_forward(P, cfg, z0, t0[batch_index], batch_index, mask, context)
+    eps = dynamics_forward(P, cfg, z0, t0[batch_index], batch_index, mask, context, xh_self_cond=xh_self_cond)
     sig0, alp0 = torch.sqrt(torch.sigmoid(g0)), torch.sqrt(torch.sigmoid(-g0))
     mu = 1.0 / alp0[batch_index] * (z0 - sig0[batch_index] * eps)
     xh = mu + sigma_x[batch_index] * sample_combined_noise(noise, batch_index, B, mask, cfg.num_node_scalar_features, dt, fix_noise)
@@ -405,13 +418,16 @@ def mol_gen_sample(P: Params, cfg: OracleConfig, num_nodes: Tensor, noise, conte
     gam = gamma_table(cfg)
     z = sample_combined_noise(noise, bi, B, mask, cfg.num_node_scalar_features, dtype, fix_noise)
     frames = torch.zeros((return_frames,) + tuple(z.shape), dtype=dtype)
+    self_cond = None
     for s in reversed(range(T)):
-        z, _ = sample_p_zs_given_zt(P, cfg, gam, s / T, (s + 1) / T, z, bi, B, mask, ctx, noise, fix_noise=fix_noise)
+        z, _ = sample_p_zs_given_zt(P, cfg, gam, s / T, (s + 1) / T, z, bi, B, mask, ctx, noise, fix_noise=fix_noise, xh_self_cond=self_cond)
         if record is not None:
             record.append(z.clone())
         if (s * return_frames) % T == 0:                          # :1354-1361
             frames[(s * return_frames) // T] = unnormalize_z(cfg, z, mask)
-    x, one_hot, charges = sample_p_xh_given_z0(P, cfg, gam, z, bi, B, mask, ctx, noise, fix_noise)
+        if cfg.self_condition:                                    # :1363-1375: a jump from t = s/T to 0 (without self-conditioning input) is the next estimate
+            self_cond, _ = sample_p_zs_given_zt(P, cfg, gam, 0.0, s / T, z, bi, B, mask, ctx, noise)
+    x, one_hot, charges = sample_p_xh_given_z0(P, cfg, gam, z, bi, B, mask, ctx, noise, fix_noise, xh_self_cond=self_cond)
     if return_frames == 1:
         cog = torch.zeros(B, 3, dtype=dtype).index_add_(0, bi, x).abs().max().item()
         if cog > 5e-2:                                            # :1392-1402

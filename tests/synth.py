@@ -34,11 +34,14 @@ def gcp2_shapes(pre: str, s_in: int, v_in: int, s_out: int, v_out: int, bottlene
     return sh
 
 
-def dynamics_shapes(S=256, V=32, Se=64, Ve=16, L=9, h_in=7, bottleneck=4) -> Dict[str, Tuple[int, ...]]:
-    """All state-dict keys of GCPNetDynamics, in the reference's registration order."""
+def dynamics_shapes(S=256, V=32, Se=64, Ve=16, L=9, h_in=7, bottleneck=4, self_cond_feats: int = 0) -> Dict[str, Tuple[int, ...]]:
+    """All state-dict keys of GCPNetDynamics, in the reference's registration order.  ``self_cond_feats`` = F (number of
+    diffused node scalars) when diffusion_cfg.self_condition is on: the embeddings then take [h | h_sc | t | ctx], 4 node vectors,
+    2 edge scalars and 2 edge vectors (gcpnet.py:955-975); the projection keeps h_in outputs (:1027)."""
     sh: Dict[str, Tuple[int, ...]] = {}
-    sh.update(gcp2_shapes("gcp_embedding.edge_embedding.", 1, 1, Se, Ve, 1))
-    sh.update(gcp2_shapes("gcp_embedding.node_embedding.", h_in, 2, S, V, 1))
+    sc = self_cond_feats > 0
+    sh.update(gcp2_shapes("gcp_embedding.edge_embedding.", 2 if sc else 1, 2 if sc else 1, Se, Ve, 1))
+    sh.update(gcp2_shapes("gcp_embedding.node_embedding.", h_in + self_cond_feats, 4 if sc else 2, S, V, 1))
     for l in range(L):
         p = f"interaction_layers.{l}."
         sh.update(gcp2_shapes(p + "interaction.message_fusion.0.", 2 * S + Se, 2 * V + Ve, S, V, bottleneck))

@@ -135,6 +135,33 @@ def test_sampling_chain_frames_small(golden_dir):
     assert (rf[:, :3] - ref[0, :, :3]).abs().max().item() > 1e-3       # and it is a different sample than the per-molecule centring gives
 
 
+def test_self_conditioning_branch(golden_dir):
+    """diffusion_cfg.self_condition=True (gcpnet.py:1112-1139; sampler :1363-1386) vs the reference's own outputs: full-width forward with a
+    previous estimate, without one (zeros), and a free-running sample of the reduced-width model (two network evaluations per step)."""
+    g = load(golden_dir, "dyn_full_qm9sc")
+    d = synth.DATASET_DIMS["qm9"]
+    F_ = synth.dims_feat(d)
+    P = synth.make_weights(synth.dynamics_shapes(d["S"], d["V"], d["Se"], d["Ve"], d["L"], synth.dims_h_in(d), self_cond_feats=F_), seed=int(g["weight_seed"]))
+    cfg = cfg_for("qm9", d["L"])
+    cfg.self_condition = True
+    bi = O.num_nodes_to_batch_index(g["num_nodes"])
+    out = O.dynamics_forward(P, cfg, g["xh"], g["t"], bi, xh_self_cond=g["sc"])
+    assert (out - g["out32"]).abs().max().item() <= 1e-5 and (out - g["out64"]).abs().max().item() <= 1e-5
+    out0 = O.dynamics_forward(P, cfg, g["xh"], g["t"], bi)
+    assert (out0 - g["out32_nosc"]).abs().max().item() <= 1e-5
+    assert (g["out32"] - g["out32_nosc"]).abs().max().item() > 1e-3              # the self-conditioning input matters
+    gs = load(golden_dir, "sampler_small_qm9sc")
+    Ps = weights_of(gs)
+    cfgs_ = cfg_for("qm9", O.infer_num_layers(Ps))
+    cfgs_.self_condition = True
+    bis = O.num_nodes_to_batch_index(gs["num_nodes"])
+    outs = O.dynamics_forward(Ps, cfgs_, gs["xh"], gs["t"], bis, xh_self_cond=gs["sc"])
+    assert (outs - gs["out32"]).abs().max().item() <= 1e-5
+    free, _ = O.mol_gen_sample(Ps, cfgs_, gs["num_nodes"], O.TapeNoise(int(gs["free_seed"])), num_timesteps=int(gs["free_T"]))
+    ref = gs["free_out"]
+    assert (free[:, :3] - ref[:, :3]).abs().max().item() <= 1e-4 * max(1.0, ref[:, :3].abs().max().item()) and torch.equal(free[:, 3:], ref[:, 3:])
+
+
 def test_mol_gen_optimize_small(golden_dir):
     """Property-guided optimisation loop (variational_diffusion.py:1416-1546) vs the reference's own outputs, both time normalisations."""
     gw = load(golden_dir, "sampler_small_qm9cond")          # same reduced-width weights (weight seed 4)
