@@ -12,7 +12,7 @@ LIB_PATH = os.path.join(_HERE, "libgcdm_hip.so")
 SOURCES = [os.path.join(_HERE, "csrc", "gcdm_api.hip")]
 HEADERS = ([os.path.join(_HERE, "csrc", f) for f in sorted(os.listdir(os.path.join(_HERE, "csrc"))) if f.endswith(".h")]
            + [os.path.join(os.path.dirname(_HERE), "include", "gcdm_hip.h")])
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 FLAG_NAN_VEL, FLAG_MEAN_NOT_ZERO, FLAG_COG_DRIFT, FLAG_F16_RANGE = 1, 2, 4, 8
 
@@ -24,7 +24,7 @@ class GcdmConfig(C.Structure):
         ("h_hidden_dim", C.c_int32), ("chi_hidden_dim", C.c_int32), ("e_hidden_dim", C.c_int32),
         ("xi_hidden_dim", C.c_int32), ("bottleneck", C.c_int32), ("num_timesteps", C.c_int32),
         ("node_positions_weight", C.c_float), ("norm_values", C.c_float * 3), ("norm_biases", C.c_float * 3),
-        ("device", C.c_int32),
+        ("device", C.c_int32), ("self_condition", C.c_int32),
     ]
 
 
@@ -45,7 +45,7 @@ EXPORTS = [
     "gcdm_create", "gcdm_destroy", "gcdm_last_error", "gcdm_set_weight", "gcdm_finalize_weights", "gcdm_set_gamma",
     "gcdm_plan_batch", "gcdm_forward", "gcdm_sample_step", "gcdm_sample_final", "gcdm_sample_init", "gcdm_debug_read",
     "gcdm_debug_set_layer_limit", "gcdm_num_nodes", "gcdm_num_edges", "gcdm_forward_flops_executed",
-    "gcdm_profile_enable", "gcdm_profile_edge_kernel_ms", "gcdm_set_option", "gcdm_get_option", "gcdm_check_stability", "gcdm_encode_samples", "gcdm_unnormalize_z", "gcdm_sample_step_to",
+    "gcdm_profile_enable", "gcdm_profile_edge_kernel_ms", "gcdm_set_option", "gcdm_get_option", "gcdm_check_stability", "gcdm_encode_samples", "gcdm_unnormalize_z", "gcdm_sample_step_to", "gcdm_forward_sc",
 ]
 
 _lib: Optional[C.CDLL] = None
@@ -91,6 +91,7 @@ def load() -> C.CDLL:
     lib.gcdm_set_gamma.argtypes = [H, C.c_void_p, C.c_int64]
     lib.gcdm_plan_batch.argtypes = [H, C.c_int32, C.c_void_p]
     lib.gcdm_forward.argtypes = [H, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.gcdm_forward_sc.argtypes = [H, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.gcdm_sample_step.argtypes = [H, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]
     lib.gcdm_sample_step_to.argtypes = [H, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]
     lib.gcdm_sample_final.argtypes = [H, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p]

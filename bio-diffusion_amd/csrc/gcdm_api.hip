@@ -45,6 +45,9 @@ struct gcdm_handle {
     bool finalized = false;
     // derived dims
     int F = 0, C = 0, Fin = 0, FinG = 0, D = 0, Se = 0, Ve = 0, L = 0, H0 = 0;
+    int sc = 0, FinP = 0;            // self-conditioning: Fin = [h | h_sc | t | ctx] feeds the node embedding, FinP = F + 1 + C is what the projection returns
+    const float *ee_wd1 = nullptr, *ee_wdf1 = nullptr, *ee_kappa1 = nullptr;
+    float *X0SC = nullptr, *BL = nullptr, *USC = nullptr;
     // device weights
     float* wpool = nullptr;
     std::vector<LayerDev> layers;
@@ -345,8 +348,10 @@ int gcdm_create(const GcdmConfig* cfg, gcdm_handle** out) {
         return fail(h, "edge dims must be (64,16) [QM9] or (16,8) [GEOM]");
     h->F = cfg->num_atom_types + (cfg->include_charges ? 1 : 0);
     h->C = cfg->num_context;
-    h->Fin = h->F + 1 + h->C;
-    if (h->Fin > 32) return fail(h, "too many node input features (max 32)");
+    h->sc = cfg->self_condition ? 1 : 0;
+    h->FinP = h->F + 1 + h->C;
+    h->Fin = h->FinP + (h->sc ? h->F : 0);
+    if (h->Fin > 32) return fail(h, "too many node input features (max 32; self-conditioning doubles the diffused ones)");
     h->FinG = (h->Fin + 3) / 4;
     h->D = 3 + h->F;
     h->Se = cfg->e_hidden_dim;
@@ -394,28 +399,32 @@ int gcdm_finalize_weights(gcdm_handle* h) {
     const int S = GCDM_S, V = GCDM_V, Se = h->Se, Ve = h->Ve, H0 = h->H0, L = h->L;
     Pool pool;
     // ---- edge embedding (1,1) -> (Se,Ve), bottleneck 1: H = max(1, Ve) = Ve ------------------------
-    size_t o_ws, o_bs, o_wd, o_wdf, o_kap, o_wg, o_bg;
+    size_t o_ws, o_bs, o_wd, o_wdf, o_kap, o_wg, o_bg, o_wd1, o_wdf1, o_kap1;
     {
         const std::string p = "gcp_embedding.edge_embedding.";
         WView ws, bs, wd, wdf, wu, wg, bg;
-        if (!get_w(h, p + "scalar_out.weight", Se, 1 + Ve + 9, ws) || !get_w(h, p + "scalar_out.bias", 1, Se, bs) ||
-            !get_w(h, p + "vector_down.weight", Ve, 1, wd) || !get_w(h, p + "vector_down_frames.weight", 3, 1, wdf) ||
+        const int ne = h->sc ? 2 : 1;     // edge GCP2 is (1,1) -> (Se,Ve), with self-conditioning (2,2) -> (Se,Ve)
+        if (!get_w(h, p + "scalar_out.weight", Se, ne + Ve + 9, ws) || !get_w(h, p + "scalar_out.bias", 1, Se, bs) ||
+            !get_w(h, p + "vector_down.weight", Ve, ne, wd) || !get_w(h, p + "vector_down_frames.weight", 3, ne, wdf) ||
             !get_w(h, p + "vector_up.weight", Ve, Ve, wu) || !get_w(h, p + "vector_out_scale.weight", Ve, Se, wg) ||
             !get_w(h, p + "vector_out_scale.bias", 1, Ve, bg))
             return -1;
-        std::vector<float> kap(Ve, 0.f);
+        std::vector<float> kap(Ve, 0.f), kap1(Ve, 0.f), wd0(Ve), wd1(Ve, 0.f), wdf0(3), wdf1(3, 0.f);
         for (int c = 0; c < Ve; ++c) {
-            float s = 0.f;
-            for (int k = 0; k < Ve; ++k) s += wu.at(c, k) * wd.at(k, 0);
-            kap[c] = s;
+            float s = 0.f, s1 = 0.f;
+            for (int k = 0; k < Ve; ++k) { s += wu.at(c, k) * wd.at(k, 0); if (h->sc) s1 += wu.at(c, k) * wd.at(k, 1); }
+            kap[c] = s; kap1[c] = s1;
+            wd0[c] = wd.at(c, 0); if (h->sc) wd1[c] = wd.at(c, 1);
         }
-        o_ws = pool.add(*ws.v); o_bs = pool.add(*bs.v); o_wd = pool.add(*wd.v); o_wdf = pool.add(*wdf.v);
+        for (int k = 0; k < 3; ++k) { wdf0[k] = wdf.at(k, 0); if (h->sc) wdf1[k] = wdf.at(k, 1); }
+        o_ws = pool.add(*ws.v); o_bs = pool.add(*bs.v); o_wd = pool.add(wd0); o_wdf = pool.add(wdf0);
         o_kap = pool.add(kap); o_wg = pool.add(*wg.v); o_bg = pool.add(*bg.v);
+        o_wd1 = pool.add(wd1); o_wdf1 = pool.add(wdf1); o_kap1 = pool.add(kap1);
     }
     // ---- node embedding (Fin,2) -> (S,V), bottleneck 1 ------------------------------------------------
     GcpOff emb, proj;
-    if (!build_gcp(h, pool, "gcp_embedding.node_embedding.", h->Fin, 2, S, V, 1, false, emb)) return -1;
-    if (!build_gcp(h, pool, "scalar_node_projection_gcp.", S, V, h->Fin, 0, 1, false, proj)) return -1;
+    if (!build_gcp(h, pool, "gcp_embedding.node_embedding.", h->Fin, h->sc ? 4 : 2, S, V, 1, false, emb)) return -1;
+    if (!build_gcp(h, pool, "scalar_node_projection_gcp.", S, V, h->FinP, 0, 1, false, proj)) return -1;
     std::vector<LayerOff> lo(L);
     for (int l = 0; l < L; ++l) {
         const std::string lp = "interaction_layers." + std::to_string(l) + ".";
@@ -520,6 +529,7 @@ int gcdm_finalize_weights(gcdm_handle* h) {
     const float* base = h->wpool;
     h->ee_ws = base + o_ws; h->ee_bs = base + o_bs; h->ee_wd = base + o_wd; h->ee_wdf = base + o_wdf;
     h->ee_kappa = base + o_kap; h->ee_wg = base + o_wg; h->ee_bg = base + o_bg;
+    h->ee_wd1 = base + o_wd1; h->ee_wdf1 = base + o_wdf1; h->ee_kappa1 = base + o_kap1;
     h->emb = resolve(emb, base);
     h->proj = resolve(proj, base);
     h->embx = resolve_x3(emb, base);
@@ -549,7 +559,8 @@ int gcdm_finalize_weights(gcdm_handle* h) {
             set_lds_attr(h, k_edge_msg_x3<64, 16, 64>, EdgeGeo<64>::LDS_BYTES) || set_lds_attr(h, k_edge_msg_x3<16, 8, 64>, EdgeGeo<64>::LDS_BYTES) ||
             set_lds_attr(h, k_edge_msg_x3<64, 16, 32>, EdgeGeo<32>::LDS_BYTES) || set_lds_attr(h, k_edge_msg_x3<16, 8, 32>, EdgeGeo<32>::LDS_BYTES) ||
             set_lds_attr(h, k_node_x3<true>, NK_LDS_BYTES) || set_lds_attr(h, k_node_x3<false>, NK_LDS_BYTES) ||
-            set_lds_attr(h, k_node<true>, NK_LDS_BYTES) || set_lds_attr(h, k_node<false>, NK_LDS_BYTES))
+            set_lds_attr(h, k_node<true>, NK_LDS_BYTES) || set_lds_attr(h, k_node<false>, NK_LDS_BYTES) ||
+            set_lds_attr(h, k_node_x3<true, 4>, NK_LDS_BYTES) || set_lds_attr(h, k_node<true, 4>, NK_LDS_BYTES))
             return -1;
         h->attr_set = true;
     }
@@ -595,10 +606,11 @@ int gcdm_plan_batch(gcdm_handle* h, int32_t B, const int32_t* nn) {
     size_t off = 0;
     auto take = [&](size_t n) { size_t o = off; off += (n + 3) & ~size_t(3); return o; };
     const size_t n = (size_t)N, e = (size_t)E;
-    const size_t oX0 = take(3 * n), oXC = take(3 * n), oFB = take(9 * n), oC0 = take(6 * n), oHIN = take(4 * h->FinG * n), oH4 = take(GCDM_S * n),
+    const size_t oX0 = take(3 * n), oXC = take(3 * n), oFB = take(9 * n), oC0 = take(12 * n), oHIN = take(4 * h->FinG * n), oH4 = take(GCDM_S * n),
                  oCHI = take(96 * n), oPQ = take(512 * n), oVDI = take((size_t)(h->H0 + 3) * 3 * n), oVDJ = take((size_t)(h->H0 + 3) * 3 * n),
                  oAGG = take(GCDM_AGGW * n), oVEL = take(3 * n), oEPS = take((size_t)h->D * n), oT = take(n), oEP = take((size_t)h->Se * e),
-                 oAL = take((size_t)h->Ve * e), oU = take(3 * e), oFR = take(9 * e), oPROF = take(((e + 31) / 32) * 192);
+                 oAL = take((size_t)h->Ve * e), oU = take(3 * e), oFR = take(9 * e), oPROF = take(((e + 31) / 32) * 192),
+                 oX0SC = take(h->sc ? 3 * n : 0), oBL = take(h->sc ? (size_t)h->Ve * e : 0), oUSC = take(h->sc ? 3 * e : 0);
     h->ws_floats = off;
     HIP_OK(h, hipMalloc(&h->ws, off * sizeof(float)));
     HIP_OK(h, hipMemset(h->ws, 0, off * sizeof(float)));
@@ -606,6 +618,7 @@ int gcdm_plan_batch(gcdm_handle* h, int32_t B, const int32_t* nn) {
     h->X0 = w + oX0; h->XC = w + oXC; h->FBAR = w + oFB; h->CHI0 = w + oC0; h->HIN4 = w + oHIN; h->H4 = w + oH4; h->CHI = w + oCHI;
     h->PQ4 = w + oPQ; h->VDI = w + oVDI; h->VDJ = w + oVDJ; h->AGG = w + oAGG; h->VEL = w + oVEL; h->EPS = w + oEPS; h->TBUF = w + oT; h->EP4 = w + oEP;
     h->AL = w + oAL; h->U = w + oU; h->FR = w + oFR; h->PROF = w + oPROF;
+    h->X0SC = h->sc ? w + oX0SC : nullptr; h->BL = h->sc ? w + oBL : nullptr; h->USC = h->sc ? w + oUSC : nullptr;
     h->B = B; h->N = N; h->E = E; h->max_n = max_n;
     return 0;
 }
@@ -630,7 +643,13 @@ int gcdm_debug_set_layer_limit(gcdm_handle* h, int32_t n) {
 }
 
 int gcdm_forward(gcdm_handle* h, const float* xh, const float* t, const float* context, float* out, uint32_t* flags, void* stream_) {
+    return gcdm_forward_sc(h, xh, nullptr, t, context, out, flags, stream_);
+}
+
+int gcdm_forward_sc(gcdm_handle* h, const float* xh, const float* xh_sc, const float* t, const float* context, float* out, uint32_t* flags,
+                    void* stream_) {
     if (!h) return -1;
+    if (xh_sc && !h->sc) return fail(h, "gcdm_forward_sc: the handle was created without self_condition");
     if (!h->finalized) return fail(h, "gcdm_forward: weights not finalized");
     if (!h->N) return fail(h, "gcdm_forward: no batch plan");
     if (!xh || !t || !out) return fail(h, "gcdm_forward: null tensor");
@@ -639,10 +658,12 @@ int gcdm_forward(gcdm_handle* h, const float* xh, const float* t, const float* c
     const int N = h->N, B = h->B;
     const int E = (int)h->E;
     HIP_OK(h, hipMemsetAsync(h->d_flags, 0, sizeof(uint32_t), st));
-    PrepArgs pa{xh, t, context, h->d_noff, N, h->F, h->C, h->FinG, h->X0, h->XC, h->FBAR, h->CHI0, (v4f*)h->HIN4, h->flat_prev, h->flat_next};
+    PrepArgs pa{xh, t, context, h->d_noff, N, h->F, h->C, h->FinG, h->X0, h->XC, h->FBAR, h->CHI0, (v4f*)h->HIN4, h->flat_prev, h->flat_next,
+                h->sc, xh_sc, h->X0SC};
     hipLaunchKernelGGL(k_prep, dim3(B), dim3(64), 3 * h->max_n * sizeof(float), st, pa);
     EdgeEmbedArgs ea{h->X0, h->XC, N, h->d_erow, h->d_ecol, E, h->ee_ws, h->ee_bs, h->ee_wd, h->ee_wdf, h->ee_kappa, h->ee_wg, h->ee_bg,
-                     (v4f*)h->EP4, h->AL, h->U, h->FR};
+                     (v4f*)h->EP4, h->AL, h->U, h->FR,
+                     h->sc, (h->sc ? 2 : 1) + h->Ve + 9, h->X0SC, h->ee_wd1, h->ee_wdf1, h->ee_kappa1, h->BL, h->USC};
     const int egrid = (E + 255) / 256;
     if (h->Se == 64) hipLaunchKernelGGL((k_edge_embed<64, 16>), dim3(egrid), dim3(256), 0, st, ea);
     else hipLaunchKernelGGL((k_edge_embed<16, 8>), dim3(egrid), dim3(256), 0, st, ea);
@@ -677,10 +698,12 @@ int gcdm_forward(gcdm_handle* h, const float* xh, const float* t, const float* c
                 return;
             }
             if (next_layer < h->L) { nx.wpqH = h->layers[next_layer].wpqH; nx.wpqL = h->layers[next_layer].wpqL; }
-            if (embed) hipLaunchKernelGGL(k_node_x3<true>, dim3(ngrid), dim3(NX_THREADS), NK_LDS_BYTES, st, nx);
+            if (embed && h->sc) hipLaunchKernelGGL((k_node_x3<true, 4>), dim3(ngrid), dim3(NX_THREADS), NK_LDS_BYTES, st, nx);
+            else if (embed) hipLaunchKernelGGL(k_node_x3<true>, dim3(ngrid), dim3(NX_THREADS), NK_LDS_BYTES, st, nx);
             else hipLaunchKernelGGL(k_node_x3<false>, dim3(ngrid), dim3(NX_THREADS), NK_LDS_BYTES, st, nx);
         } else {
-            if (embed) hipLaunchKernelGGL(k_node<true>, dim3(ngrid), dim3(256), NK_LDS_BYTES, st, na);
+            if (embed && h->sc) hipLaunchKernelGGL((k_node<true, 4>), dim3(ngrid), dim3(256), NK_LDS_BYTES, st, na);
+            else if (embed) hipLaunchKernelGGL(k_node<true>, dim3(ngrid), dim3(256), NK_LDS_BYTES, st, na);
             else hipLaunchKernelGGL(k_node<false>, dim3(ngrid), dim3(256), NK_LDS_BYTES, st, na);
         }
     };
@@ -694,6 +717,7 @@ int gcdm_forward(gcdm_handle* h, const float* xh, const float* t, const float* c
         HIP_OK(h, hipMemsetAsync(h->AGG, 0, (size_t)N * GCDM_AGGW * sizeof(float), st));
         EdgeMsgArgs ma{};
         ma.EP4 = (const v4f*)h->EP4; ma.AL = h->AL; ma.U = h->U; ma.FR = h->FR; ma.EROW = h->d_erow; ma.ECOL = h->d_ecol; ma.NCNT = h->d_ncnt;
+        ma.BL = h->BL; ma.USC = h->USC;
         ma.E = E; ma.N = N; ma.PQ4 = (const v4f*)h->PQ4; ma.VDI = h->VDI; ma.VDJ = h->VDJ; ma.AGG = h->AGG;
         ma.w0 = d.w0; ma.G0 = d.G0; ma.wddE = d.wddE; ma.wg0 = d.wg0; ma.bg0 = d.bg0; ma.wup0 = d.wup0;
         for (int k = 0; k < 3; ++k) ma.mk[k] = d.mk[k];
@@ -929,7 +953,7 @@ int64_t gcdm_debug_read(gcdm_handle* h, const char* name, float* host_out, int64
     else if (k == "vdj") { p = h->VDJ; cnt = (int64_t)(h->H0 + 3) * 3 * n; }
     else if (k == "hin") { p = h->HIN4; cnt = 4 * (int64_t)h->FinG * n; }
     else if (k == "fbar") { p = h->FBAR; cnt = 9 * n; }
-    else if (k == "chi0") { p = h->CHI0; cnt = 6 * n; }
+    else if (k == "chi0") { p = h->CHI0; cnt = (h->sc ? 12 : 6) * n; }
     else if (k == "vel") { p = h->VEL; cnt = 3 * n; }
     else if (k == "phase") { p = h->PROF; cnt = ((e + h->tile() - 1) / h->tile()) * 192; }
     else return fail(h, "gcdm_debug_read: unknown buffer " + k);

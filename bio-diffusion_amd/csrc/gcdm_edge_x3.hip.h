@@ -362,7 +362,7 @@ __global__ __launch_bounds__(ET * 8) __attribute__((amdgpu_waves_per_eu(2, 2))) 
         for (int c = 0; c < VE; ++c) al[c] = a.AL[(size_t)c * E + eid];
         const float u0 = a.U[eid], u1 = a.U[(size_t)E + eid], u2 = a.U[2 * (size_t)E + eid];
         constexpr int ROWS0 = H0 + 3, NH0 = (ROWS0 + PARTS - 1) / PARTS;
-        float gi[NH0][3], gj[NH0][3], beta[NH0];
+        float gi[NH0][3], gj[NH0][3], beta[NH0], beta2[NH0];
 #pragma unroll
         for (int i = 0; i < NH0; ++i) {
             const int hh = min(part + PARTS * i, ROWS0 - 1);
@@ -377,13 +377,29 @@ __global__ __launch_bounds__(ET * 8) __attribute__((amdgpu_waves_per_eu(2, 2))) 
 #pragma unroll
             for (int c = 0; c < VE; ++c) bsum += w[c] * al[c];
             beta[i] = bsum;
+            beta2[i] = 0.f;
+        }
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+        if (a.BL) {                      // self-conditioning: rank-2 embedded edge vectors, xi'_c = AL_c u + BL_c u_sc (uniform branch)
+            s0 = a.USC[eid]; s1 = a.USC[(size_t)E + eid]; s2 = a.USC[2 * (size_t)E + eid];
+            float bl[VE];
+#pragma unroll
+            for (int c = 0; c < VE; ++c) bl[c] = a.BL[(size_t)c * E + eid];
+#pragma unroll
+            for (int i = 0; i < NH0; ++i) {
+                const float* w = a.wddE + min(part + PARTS * i, ROWS0 - 1) * VE;
+                float bsum = 0.f;
+#pragma unroll
+                for (int c = 0; c < VE; ++c) bsum += w[c] * bl[c];
+                beta2[i] = bsum;
+            }
         }
 #pragma unroll
         for (int i = 0; i < NH0; ++i) {
             const int hh = part + PARTS * i;
-            const float vx = gi[i][0] + beta[i] * u0 + gj[i][0];
-            const float vy = gi[i][1] + beta[i] * u1 + gj[i][1];
-            const float vz = gi[i][2] + beta[i] * u2 + gj[i][2];
+            const float vx = gi[i][0] + beta[i] * u0 + beta2[i] * s0 + gj[i][0];
+            const float vy = gi[i][1] + beta[i] * u1 + beta2[i] * s1 + gj[i][1];
+            const float vz = gi[i][2] + beta[i] * u2 + beta2[i] * s2 + gj[i][2];
             if (hh < H0) {
                 over |= put16(XH, XL, ETP, N8 + (hh >> 3), hh & 7, e, sqrtf(vx * vx + vy * vy + vz * vz + 1e-8f) + 1e-8f);
                 VH[(hh * 3 + 0) * ETP + e] = vx;

@@ -305,6 +305,9 @@ struct PrepArgs {
     float* CHI0;       // [6][N] orientations (flat-batch adjacency)
     v4f* HIN4;         // [FinG][N]
     int has_prev, has_next;   // this plan is a slice of a larger flat batch: rows -1 / N of xh exist and are its flat neighbours
+    // self-conditioning (gcpnet.py:1112-1139): h_in = [h0 | h_sc | t | context], CHI0 gets the orientations of x_sc as vectors 2, 3,
+    // X0SC the un-centralised x_sc for the second edge scalar / vector.  xh_sc may be null (= zeros)
+    int sc; const float* xh_sc; float* X0SC;
 };
 
 __global__ __launch_bounds__(64) void k_prep(PrepArgs a) {
@@ -338,8 +341,27 @@ __global__ __launch_bounds__(64) void k_prep(PrepArgs a) {
         }
 #pragma unroll
         for (int x = 0; x < 3; ++x) { a.CHI0[x * a.N + g] = fw[x]; a.CHI0[(3 + x) * a.N + g] = bw[x]; }
-        // h_in = [h0 | t | context], zero padded to a whole number of float4 groups
-        const int Fin = a.F + 1 + a.C;
+        const int Fsc = a.sc ? a.F : 0;
+        if (a.sc) {
+            const float* ps = a.xh_sc ? a.xh_sc + (size_t)g * D : nullptr;
+            const float s0 = ps ? ps[0] : 0.f, s1 = ps ? ps[1] : 0.f, s2 = ps ? ps[2] : 0.f;
+            a.X0SC[g] = s0; a.X0SC[a.N + g] = s1; a.X0SC[2 * a.N + g] = s2;
+            float fs[3] = {0.f, 0.f, 0.f}, bs_[3] = {0.f, 0.f, 0.f};
+            if (ps && (g + 1 < a.N || a.has_next)) {
+                const float* q = ps + D;
+                const float e0 = q[0] - s0, e1 = q[1] - s1, e2 = q[2] - s2, nr = sqrtf(e0 * e0 + e1 * e1 + e2 * e2);
+                if (nr > 0.f) { fs[0] = e0 / nr; fs[1] = e1 / nr; fs[2] = e2 / nr; }
+            }
+            if (ps && (g > 0 || a.has_prev)) {
+                const float* q = ps - D;
+                const float e0 = q[0] - s0, e1 = q[1] - s1, e2 = q[2] - s2, nr = sqrtf(e0 * e0 + e1 * e1 + e2 * e2);
+                if (nr > 0.f) { bs_[0] = e0 / nr; bs_[1] = e1 / nr; bs_[2] = e2 / nr; }
+            }
+#pragma unroll
+            for (int x = 0; x < 3; ++x) { a.CHI0[(6 + x) * a.N + g] = fs[x]; a.CHI0[(9 + x) * a.N + g] = bs_[x]; }
+        }
+        // h_in = [h0 | h_sc | t | context], zero padded to a whole number of float4 groups
+        const int Fin = a.F + Fsc + 1 + a.C;
         for (int gg = 0; gg < a.FinG; ++gg) {
             v4f v;
 #pragma unroll
@@ -347,8 +369,9 @@ __global__ __launch_bounds__(64) void k_prep(PrepArgs a) {
                 const int c = 4 * gg + k;
                 float val = 0.f;
                 if (c < a.F) val = p[3 + c];
-                else if (c == a.F) val = a.t[g];
-                else if (c < Fin) val = a.ctx[(size_t)g * a.C + (c - a.F - 1)];
+                else if (c < a.F + Fsc) val = a.xh_sc ? a.xh_sc[(size_t)g * D + 3 + (c - a.F)] : 0.f;
+                else if (c == a.F + Fsc) val = a.t[g];
+                else if (c < Fin) val = a.ctx[(size_t)g * a.C + (c - a.F - Fsc - 1)];
                 v[k] = val;
             }
             a.HIN4[(size_t)gg * a.N + g] = v;
@@ -386,6 +409,10 @@ struct EdgeEmbedArgs {
     float* AL;          // [Ve][E]     xi'_c = AL[c] * U
     float* U;           // [3][E]      unit vector (0 for self loops)
     float* FR;          // [9][E]      frames
+    // self-conditioning: the edge GCP2 is (2,2) -> (Se,Ve) (gcpnet.py:961-975): second scalar |x_sc_i - x_sc_j|^2, second vector u_sc;
+    // scalar_out.weight rows are [e | e_sc | norms | q] (row stride `kin`), vector_down / _frames have a second column (wd1, wdf1), the
+    // embedded vectors are rank 2: xi'_c = AL[c] * U + BL[c] * USC with kappa1 = vector_up @ vector_down[:, 1]
+    int sc, kin; const float* X0SC; const float* wd1; const float* wdf1; const float* kappa1; float* BL; float* USC;
 };
 
 template <int SE, int VE>
@@ -405,32 +432,45 @@ __global__ __launch_bounds__(256) void k_edge_embed(EdgeEmbedArgs a) {
     for (int r = 0; r < 9; ++r) a.FR[(size_t)r * E + eid] = f[r];
 #pragma unroll
     for (int x = 0; x < 3; ++x) a.U[(size_t)x * E + eid] = u[x];
-    constexpr int KIN = 1 + VE + 9;
+    float usc[3] = {0.f, 0.f, 0.f}, es_sc = 0.f;
+    if (a.sc) {
+        const float s0 = a.X0SC[i] - a.X0SC[j], s1 = a.X0SC[N + i] - a.X0SC[N + j], s2 = a.X0SC[2 * N + i] - a.X0SC[2 * N + j];
+        es_sc = s0 * s0 + s1 * s1 + s2 * s2;
+        const float ns = sqrtf(es_sc);
+        if (ns > 0.f) { usc[0] = s0 / ns; usc[1] = s1 / ns; usc[2] = s2 / ns; }
+#pragma unroll
+        for (int x = 0; x < 3; ++x) a.USC[(size_t)x * E + eid] = usc[x];
+    }
+    constexpr int KIN = 1 + VE + 9;      // [e | norms | q]; the second edge scalar of the self-conditioning mode is kept apart (es_sc)
     float in[KIN];
     in[0] = es;
 #pragma unroll
     for (int h = 0; h < VE; ++h) {
-        const float w = a.wd[h], v0 = u[0] * w, v1 = u[1] * w, v2 = u[2] * w;
+        const float w = a.wd[h], w1 = a.sc ? a.wd1[h] : 0.f;
+        const float v0 = u[0] * w + usc[0] * w1, v1 = u[1] * w + usc[1] * w1, v2 = u[2] * w + usc[2] * w1;
         in[1 + h] = sqrtf(v0 * v0 + v1 * v1 + v2 * v2 + 1e-8f) + 1e-8f;
     }
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
-        const float w = a.wdf[k], v0 = u[0] * w, v1 = u[1] * w, v2 = u[2] * w;
+        const float w = a.wdf[k], w1 = a.sc ? a.wdf1[k] : 0.f;
+        const float v0 = u[0] * w + usc[0] * w1, v1 = u[1] * w + usc[1] * w1, v2 = u[2] * w + usc[2] * w1;
 #pragma unroll
         for (int r = 0; r < 3; ++r) in[1 + VE + 3 * k + r] = f[3 * r] * v0 + f[3 * r + 1] * v1 + f[3 * r + 2] * v2;
     }
     float gate[VE];
 #pragma unroll
     for (int c = 0; c < VE; ++c) gate[c] = a.bg[c];
+    const int ne = a.sc ? 2 : 1;         // columns of the edge scalars in scalar_out.weight
     for (int g = 0; g < SE / 4; ++g) {
         v4f o;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const int ch = 4 * g + k;
-            float p = a.bs[ch];
-            const float* w = a.ws + ch * KIN;
+            const float* w = a.ws + ch * a.kin;
+            float p = a.bs[ch] + w[0] * es;
+            if (a.sc) p += w[1] * es_sc;
 #pragma unroll
-            for (int q = 0; q < KIN; ++q) p += w[q] * in[q];
+            for (int q = 1; q < KIN; ++q) p += w[ne - 1 + q] * in[q];
             p = fast_silu(p);
             o[k] = p;
 #pragma unroll
@@ -439,7 +479,11 @@ __global__ __launch_bounds__(256) void k_edge_embed(EdgeEmbedArgs a) {
         a.EP4[(size_t)g * E + eid] = o;
     }
 #pragma unroll
-    for (int c = 0; c < VE; ++c) a.AL[(size_t)c * E + eid] = a.kappa[c] * fast_sigmoid(gate[c]);
+    for (int c = 0; c < VE; ++c) {
+        const float sg = fast_sigmoid(gate[c]);
+        a.AL[(size_t)c * E + eid] = a.kappa[c] * sg;
+        if (a.sc) a.BL[(size_t)c * E + eid] = a.kappa1[c] * sg;
+    }
 }
 
 // ================================================================================================
@@ -449,6 +493,7 @@ __global__ __launch_bounds__(256) void k_edge_embed(EdgeEmbedArgs a) {
 struct EdgeMsgArgs {
     // per-edge (constant over layers)
     const v4f* EP4; const float* AL; const float* U; const float* FR; const int* EROW; const int* ECOL;
+    const float* BL; const float* USC;   // self-conditioning only (else null): second coefficient set / unit vector of the rank-2 embedded edge vectors
     const int* NCNT;  // [N] atoms in the node's molecule (row length)
     int E, N;
     // per-node, for this layer (written by the previous node kernel)
@@ -552,7 +597,7 @@ __global__ __launch_bounds__(EdgeGeo<ET>::THREADS) void k_edge_msg(EdgeMsgArgs a
         constexpr int gN = SEG, gQ = SEG + H0G;
         constexpr int ROWS0 = H0 + 3, NH0 = (ROWS0 + PARTS - 1) / PARTS;
         // all node-side gathers of this thread's rows are issued before the first use (static unroll)
-        float gi[NH0][3], gj[NH0][3], beta[NH0];
+        float gi[NH0][3], gj[NH0][3], beta[NH0], beta2[NH0];
 #pragma unroll
         for (int i = 0; i < NH0; ++i) {
             const int hh = min(part + PARTS * i, ROWS0 - 1);
@@ -567,13 +612,29 @@ __global__ __launch_bounds__(EdgeGeo<ET>::THREADS) void k_edge_msg(EdgeMsgArgs a
 #pragma unroll
             for (int c = 0; c < VE; ++c) bsum += w[c] * al[c];
             beta[i] = bsum;
+            beta2[i] = 0.f;
+        }
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+        if (a.BL) {                      // self-conditioning: rank-2 embedded edge vectors, xi'_c = AL_c u + BL_c u_sc (uniform branch)
+            s0 = a.USC[eid]; s1 = a.USC[(size_t)E + eid]; s2 = a.USC[2 * (size_t)E + eid];
+            float bl[VE];
+#pragma unroll
+            for (int c = 0; c < VE; ++c) bl[c] = a.BL[(size_t)c * E + eid];
+#pragma unroll
+            for (int i = 0; i < NH0; ++i) {
+                const float* w = a.wddE + min(part + PARTS * i, ROWS0 - 1) * VE;
+                float bsum = 0.f;
+#pragma unroll
+                for (int c = 0; c < VE; ++c) bsum += w[c] * bl[c];
+                beta2[i] = bsum;
+            }
         }
 #pragma unroll
         for (int i = 0; i < NH0; ++i) {
             const int hh = part + PARTS * i;
-            const float vx = gi[i][0] + beta[i] * u0 + gj[i][0];
-            const float vy = gi[i][1] + beta[i] * u1 + gj[i][1];
-            const float vz = gi[i][2] + beta[i] * u2 + gj[i][2];
+            const float vx = gi[i][0] + beta[i] * u0 + beta2[i] * s0 + gj[i][0];
+            const float vy = gi[i][1] + beta[i] * u1 + beta2[i] * s1 + gj[i][1];
+            const float vz = gi[i][2] + beta[i] * u2 + beta2[i] * s2 + gj[i][2];
             if (hh < H0) {
                 XSf[((gN + (hh >> 2)) * ETP + e) * 4 + (hh & 3)] = sqrtf(vx * vx + vy * vy + vz * vz + 1e-8f) + 1e-8f;
                 VH[(hh * 3 + 0) * ETP + e] = vx;
@@ -769,7 +830,8 @@ constexpr int NK_OFF_FR = NK_OFF_PG + 4 * 32 * NTP * 4;
 constexpr int NK_OFF_XP = NK_OFF_FR + 9 * NTP * 4;
 constexpr int NK_LDS_BYTES = NK_OFF_XP + 3 * NTP * 4;
 
-template <bool EMBED>
+// VIN0: input vectors of the node embedding (2 orientations; 4 with self-conditioning, gcpnet.py:966-970)
+template <bool EMBED, int VIN0 = 2>
 __global__ __launch_bounds__(256) void k_node(NodeArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     v4f* XS4 = (v4f*)(smem + NK_OFF_XS);
@@ -799,11 +861,11 @@ __global__ __launch_bounds__(256) void k_node(NodeArgs a) {
 
     if (EMBED) {
         for (int g = part; g < a.FinG; g += 8) XS4[g * NTP + e] = a.HIN4[(size_t)g * N + nid];
-        if (part < 6) VV[part * NTP + e] = a.CHI0[(size_t)part * N + nid];
+        for (int r = part; r < 3 * VIN0; r += 8) VV[r * NTP + e] = a.CHI0[(size_t)r * N + nid];
         __syncthreads();
         const GcpW& w = a.emb;
         const int gN = a.FinG, gQ = gN + (w.H + 3) / 4;
-        gcp2_pre<NT_, 32, 2>(w.wdd, VV, 0, FR, XSf, gN, gQ, 2 * w.G, VH, e, part);
+        gcp2_pre<NT_, 32, VIN0>(w.wdd, VV, 0, FR, XSf, gN, gQ, 2 * w.G, VH, e, part);
         __syncthreads();
         acc_init_bias<2, 1>(acc, w.b, mt0, lane);
         tile_gemm<2, 1>(acc, w.w + (size_t)mt0 * w.G * 64, w.G, XS4, NTP, lane);

@@ -87,7 +87,7 @@ constexpr int NX_GROUPS8 = 70;
 constexpr int NX_THREADS = 512;
 static_assert(2 * NX_GROUPS8 * NTP * 16 == NK_XS_GROUPS * NTP * 16, "XH8/XL8 must exactly fill the fp32 XS4 region of k_node");
 
-template <bool EMBED>
+template <bool EMBED, int VIN0 = 2>
 __global__ __launch_bounds__(NX_THREADS) void k_node_x3(NodeX3Args ax) {
     const NodeArgs& a = ax.base;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -167,10 +167,10 @@ __global__ __launch_bounds__(NX_THREADS) void k_node_x3(NodeX3Args ax) {
             *(h4*)(XH + off) = vh;
             *(h4*)(XL + off) = vl;
         }
-        if (part < 6) VV[part * NTP + e] = a.CHI0[(size_t)part * N + nid];
+        for (int r = part; r < 3 * VIN0; r += PARTS) VV[r * NTP + e] = a.CHI0[(size_t)r * N + nid];
         __syncthreads();
         const GcpW& w = a.emb;
-        over |= gcp2_pre_x3g<NT_, 32, 2, NX_THREADS>(w.wdd, VV, 0, FR, XH, XL, G8in, G8in + 4, 2 * ax.emb.KB, VH, e, part);
+        over |= gcp2_pre_x3g<NT_, 32, VIN0, NX_THREADS>(w.wdd, VV, 0, FR, XH, XL, G8in, G8in + 4, 2 * ax.emb.KB, VH, e, part);
         __syncthreads();
         acc_bias(w.b);
         gemm(integral_constant<int, 0>{}, ax.emb.wH, ax.emb.wL, ax.emb.KB, 0);

@@ -142,18 +142,21 @@ class GCPNetDynamics(nn.Module):
         super().__init__()
         if cfg_get(diffusion_cfg, "diffusion_target", "atom_types_and_coords") not in NODE_FEATURE_DIFFUSION_TARGETS:
             raise NotImplementedError("only diffusion_target=atom_types_and_coords is built")
-        if cfg_get(diffusion_cfg, "self_condition", False):
-            raise NotImplementedError("self_condition=True is not built yet (SURVEY 8f rank 2)")
         self.num_atom_types = int(cfg_get(dataloader_cfg, "num_atom_types"))
         self.include_charges = bool(cfg_get(dataloader_cfg, "include_charges"))
         self.num_x_dims = int(cfg_get(dataloader_cfg, "num_x_dims", 3))
         self.condition_on_time = bool(cfg_get(diffusion_cfg, "condition_on_time", True))
         self.num_context_node_features = len(cfg_get(module_cfg, "conditioning", []) or [])
         self.condition_on_context = self.num_context_node_features > 0
-        self.self_condition = False
-        h_in = self.num_atom_types + int(self.include_charges) + int(self.condition_on_time) + self.num_context_node_features
-        self.edge_input_dims = (int(cfg_get(model_cfg, "e_input_dim", 1)), int(cfg_get(model_cfg, "xi_input_dim", 1)))
-        self.node_input_dims = (h_in, int(cfg_get(model_cfg, "chi_input_dim", 2)))
+        # self-conditioning doubles the embedding inputs (gcpnet.py:955-975); the projection keeps h_in outputs (:1027)
+        self.self_condition = bool(cfg_get(diffusion_cfg, "self_condition", False))
+        h_diff = self.num_atom_types + int(self.include_charges)
+        h_in = h_diff + int(self.condition_on_time) + self.num_context_node_features
+        mult = 2 if self.self_condition else 1
+        self.edge_input_dims = (int(cfg_get(model_cfg, "e_input_dim", 1)) * mult, int(cfg_get(model_cfg, "xi_input_dim", 1)) * mult)
+        self.node_input_dims = (h_in + (h_diff if self.self_condition else 0), int(cfg_get(model_cfg, "chi_input_dim", 2)) * mult)
+        if self.edge_input_dims != (mult, mult) or self.node_input_dims[1] != 2 * mult:
+            raise NotImplementedError("only e_input_dim = xi_input_dim = 1, chi_input_dim = 2 are built")
         self.edge_dims = (int(cfg_get(model_cfg, "e_hidden_dim")), int(cfg_get(model_cfg, "xi_hidden_dim")))
         self.node_dims = (int(cfg_get(model_cfg, "h_hidden_dim")), int(cfg_get(model_cfg, "chi_hidden_dim")))
         self.num_layers = int(cfg_get(model_cfg, "num_encoder_layers"))
@@ -196,6 +199,7 @@ class GCPNetDynamics(nn.Module):
         cfg.norm_values = (C.c_float * 3)(*[float(v) for v in nv])
         cfg.norm_biases = (C.c_float * 3)(*nb)
         cfg.device = device_index
+        cfg.self_condition = int(self.self_condition)
         return cfg
 
     def _ensure_handle(self, device: torch.device):
@@ -257,20 +261,21 @@ class GCPNetDynamics(nn.Module):
 
     # ------------------------------------------------------------------------------------------
     def forward(self, batch: Any, xh: torch.Tensor, t: torch.Tensor, **kwargs: Any) -> Tuple[Any, torch.Tensor]:
-        if kwargs.get("xh_self_cond") is not None or kwargs.get("x_self_cond") is not None:
-            raise NotImplementedError("self-conditioning inputs are not built")
+        sc = kwargs.get("xh_self_cond")
+        if sc is not None and not self.self_condition:
+            sc = None                  # as the reference: the input is ignored unless diffusion_cfg.self_condition (gcpnet.py:1112)
         self._ensure_handle(xh.device)
         self.sync_weights()
         self._plan_from_batch_index(cfg_get(batch, "batch"), cfg_get(batch, "mask"))
         ctx = cfg_get(batch, "props_context") if self.condition_on_context else None
-        out = self.native_forward(xh, t, ctx)
+        out = self.native_forward(xh, t, ctx, xh_self_cond=sc)
         if self.mfma_mode == 1 and self.check_f16_range:
             # split-precision mode: one host sync to make the module-level call self-healing (the fused sampler loop reads
             # the flag once per run instead); an activation beyond the f16 range -> recompute this call with fp32 MFMA
             if self.read_flags() & _native.FLAG_F16_RANGE:
                 self.set_mfma_mode(0)
                 try:
-                    out = self.native_forward(xh, t, ctx)
+                    out = self.native_forward(xh, t, ctx, xh_self_cond=sc)
                 finally:
                     self.set_mfma_mode(1)
         return batch, out
@@ -284,7 +289,7 @@ class GCPNetDynamics(nn.Module):
         _native.check(self._lib, self._handle, self._lib.gcdm_set_option(self._handle, b"mfma_mode", int(mode)), "gcdm_set_option")
 
     def native_forward(self, xh: torch.Tensor, t: torch.Tensor, context: Optional[torch.Tensor] = None,
-                       out: Optional[torch.Tensor] = None) -> torch.Tensor:
+                       out: Optional[torch.Tensor] = None, xh_self_cond: Optional[torch.Tensor] = None) -> torch.Tensor:
         N = int(self._lib.gcdm_num_nodes(self._handle))
         D = 3 + self.num_atom_types + int(self.include_charges)
         if xh.shape != (N, D):
@@ -305,9 +310,15 @@ class GCPNetDynamics(nn.Module):
         if out is None:
             out = torch.empty_like(xh)
         stream = torch.cuda.current_stream(xh.device).cuda_stream
-        st = self._lib.gcdm_forward(self._handle, C.c_void_p(xh.data_ptr()), C.c_void_p(t.data_ptr()), cptr,
-                                    C.c_void_p(out.data_ptr()), C.c_void_p(self._flags.data_ptr()), C.c_void_p(stream))
-        _native.check(self._lib, self._handle, st, "gcdm_forward")
+        sptr = None
+        if xh_self_cond is not None:
+            if xh_self_cond.shape != (N, D):
+                raise ValueError(f"xh_self_cond has shape {tuple(xh_self_cond.shape)}, expected {(N, D)}")
+            xh_self_cond = xh_self_cond.detach().to(xh.device, torch.float32).contiguous()
+            sptr = C.c_void_p(xh_self_cond.data_ptr())
+        st = self._lib.gcdm_forward_sc(self._handle, C.c_void_p(xh.data_ptr()), sptr, C.c_void_p(t.data_ptr()), cptr,
+                                       C.c_void_p(out.data_ptr()), C.c_void_p(self._flags.data_ptr()), C.c_void_p(stream))
+        _native.check(self._lib, self._handle, st, "gcdm_forward_sc")
         return out
 
     # ------------------------------------------------------------------------------------------

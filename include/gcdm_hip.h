@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define GCDM_ABI_VERSION 1
+#define GCDM_ABI_VERSION 2
 
 /* Bits of the device-side `flags` word (reproduce the reference's host-side checks without a sync). */
 #define GCDM_FLAG_NAN_VEL        0x1u  /* gcpnet.py:1213-1216: NaN seen in vel -> whole-batch vel zeroed   */
@@ -53,6 +53,8 @@ typedef struct GcdmConfig {
     float   norm_values[3];    /* diffusion_cfg.norm_values */
     float   norm_biases[3];    /* diffusion_cfg.norm_biases (null -> 0) */
     int32_t device;            /* HIP device ordinal */
+    int32_t self_condition;    /* diffusion_cfg.self_condition (0 in both production configs): the embeddings additionally take the previous
+                                  estimate's features / orientations / edge features (gcpnet.py:955-975, 1112-1139) */
 } GcdmConfig;
 
 typedef struct gcdm_handle gcdm_handle;
@@ -93,6 +95,11 @@ int gcdm_sample_step(gcdm_handle* h, float* z, const float* context, int32_t s_i
  * Replaces sample_p_xh_given_z0 + the CoG re-projection (variational_diffusion.py:840-907, 1389-1412). */
 int gcdm_sample_final(gcdm_handle* h, const float* z0, const float* context, const float* noise, uint64_t seed,
                       float* out, uint32_t* flags, void* stream);
+
+/* gcdm_forward with the self-conditioning input (GCPNetDynamics.forward(..., xh_self_cond=), gcpnet.py:1084-1139): xh_self_cond [N,3+F]
+ * device, or NULL = zeros (what the reference substitutes, :1113-1122).  Requires cfg.self_condition; gcdm_forward is this call with NULL. */
+int gcdm_forward_sc(gcdm_handle* h, const float* xh, const float* xh_self_cond, const float* t, const float* context, float* out,
+                    uint32_t* flags, void* stream);
 
 /* Draws z_T (variational_diffusion.py:795-819) into z [N,3+F] from `noise` (device) or Philox(seed). */
 int gcdm_sample_init(gcdm_handle* h, float* z, const float* noise, uint64_t seed, void* stream);

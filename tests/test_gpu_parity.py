@@ -158,8 +158,49 @@ def test_forward_input_validation():
     bi2 = bi.clone().to(dev)
     with pytest.raises(NotImplementedError):
         net(dict(batch=bi2, mask=mask2), xh.to(dev), t.to(dev))
-    with pytest.raises(NotImplementedError):
-        net(dict(batch=bi.to(dev), mask=mask), xh.to(dev), t.to(dev), xh_self_cond=xh.to(dev))
+    # without diffusion_cfg.self_condition the reference ignores a self-conditioning input (gcpnet.py:1112); so does the mirror
+    _, o1 = net(dict(batch=bi.to(dev), mask=mask), xh.to(dev), t.to(dev), xh_self_cond=xh.to(dev))
+    _, o2 = net(dict(batch=bi.to(dev), mask=mask), xh.to(dev), t.to(dev))
+    assert torch.equal(o1, o2)
+
+
+@pytest.mark.parametrize("mode", MODES)
+def test_self_conditioning_forward_matches_reference_golden(mode, golden_dir):
+    """diffusion_cfg.self_condition=True (gcpnet.py:1112-1139): full-width forward with a previous estimate and with none (zeros) vs the
+    outputs of the REFERENCE itself (tests/golden/dyn_full_qm9sc.npz), both matrix modes; plus ragged tiles vs the oracle."""
+    g = np.load(os.path.join(golden_dir, "dyn_full_qm9sc.npz"))
+    d = _dims("qm9")
+    F_ = synth.dims_feat(d)
+    cfgs = pkg.default_cfgs("qm9")
+    cfgs["diffusion_cfg"]["self_condition"] = True
+    net = pkg.GCPNetDynamics(**cfgs)
+    W = synth.make_weights(synth.dynamics_shapes(d["S"], d["V"], d["Se"], d["Ve"], d["L"], synth.dims_h_in(d), self_cond_feats=F_), seed=int(g["weight_seed"]))
+    net.load_state_dict(W)
+    net = net.cuda()
+    net._ensure_handle(torch.device("cuda"))
+    net.set_mfma_mode(mode)
+    dev = torch.device("cuda")
+    bi = O.num_nodes_to_batch_index(torch.tensor(g["num_nodes"]))
+    batch = dict(batch=bi.to(dev), mask=torch.ones(len(bi), dtype=torch.bool, device=dev), props_context=None)
+    xh, t, sc = torch.tensor(g["xh"]).to(dev), torch.tensor(g["t"]).to(dev), torch.tensor(g["sc"]).to(dev)
+    _, out = net(batch, xh, t, xh_self_cond=sc, x_self_cond=sc)
+    assert (out.cpu() - torch.tensor(g["out32"])).abs().max().item() <= TOL
+    assert (out.cpu() - torch.tensor(g["out64"])).abs().max().item() <= TOL
+    _, out0 = net(batch, xh, t)
+    assert (out0.cpu() - torch.tensor(g["out32_nosc"])).abs().max().item() <= TOL
+    # ragged tiling against the oracle
+    ocfg = _ocfg("qm9")
+    ocfg.self_condition = True
+    Ws = synth.make_weights(synth.dynamics_shapes(d["S"], d["V"], d["Se"], d["Ve"], d["L"], synth.dims_h_in(d), self_cond_feats=F_), seed=23, scale_2d=0.5)
+    net.load_state_dict(Ws)
+    xh2, t2, bi2, _, _ = synth.make_inputs([29] * 3 + [1, 70, 2], F_, seed=31, t_value=0.63)
+    g2 = torch.Generator().manual_seed(8)
+    sc2 = torch.randn(xh2.shape, generator=g2)
+    ref = O.dynamics_forward(Ws, ocfg, xh2, t2, bi2, xh_self_cond=sc2)
+    b2 = dict(batch=bi2.to(dev), mask=torch.ones(len(bi2), dtype=torch.bool, device=dev), props_context=None)
+    _, o2 = net(b2, xh2.to(dev), t2.to(dev), xh_self_cond=sc2.to(dev))
+    assert (o2.cpu() - ref).abs().max().item() <= TOL * max(1.0, ref.abs().max().item())
+    assert net.read_flags() == 0
 
 
 def test_cabi_error_paths():
@@ -167,7 +208,7 @@ def test_cabi_error_paths():
     native = pkg._native
     lib = native.load()
     H = C.c_void_p
-    good = native.GcdmConfig(1, 5, 1, 0, 1, 9, 256, 32, 64, 16, 4, 1000, 1.0, (C.c_float * 3)(1, 4, 10), (C.c_float * 3)(0, 0, 0), 0)
+    good = native.GcdmConfig(native.ABI_VERSION, 5, 1, 0, 1, 9, 256, 32, 64, 16, 4, 1000, 1.0, (C.c_float * 3)(1, 4, 10), (C.c_float * 3)(0, 0, 0), 0, 0)
     for field, bad in (("abi_version", 99), ("h_hidden_dim", 128), ("chi_hidden_dim", 16), ("e_hidden_dim", 48), ("bottleneck", 2),
                        ("condition_on_time", 0), ("num_layers", 0)):
         cfg = native.GcdmConfig.from_buffer_copy(good)
