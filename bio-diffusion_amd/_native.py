@@ -45,7 +45,7 @@ EXPORTS = [
     "gcdm_create", "gcdm_destroy", "gcdm_last_error", "gcdm_set_weight", "gcdm_finalize_weights", "gcdm_set_gamma",
     "gcdm_plan_batch", "gcdm_forward", "gcdm_sample_step", "gcdm_sample_final", "gcdm_sample_init", "gcdm_debug_read",
     "gcdm_debug_set_layer_limit", "gcdm_num_nodes", "gcdm_num_edges", "gcdm_forward_flops_executed",
-    "gcdm_profile_enable", "gcdm_profile_edge_kernel_ms", "gcdm_set_option", "gcdm_get_option", "gcdm_check_stability", "gcdm_encode_samples", "gcdm_unnormalize_z", "gcdm_sample_step_to", "gcdm_forward_sc",
+    "gcdm_profile_enable", "gcdm_profile_edge_kernel_ms", "gcdm_set_option", "gcdm_get_option", "gcdm_check_stability", "gcdm_encode_samples", "gcdm_unnormalize_z", "gcdm_sample_step_to", "gcdm_forward_sc", "gcdm_sample_step_sc", "gcdm_sample_final_sc",
 ]
 
 _lib: Optional[C.CDLL] = None
@@ -94,6 +94,9 @@ def load() -> C.CDLL:
     lib.gcdm_forward_sc.argtypes = [H, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.gcdm_sample_step.argtypes = [H, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]
     lib.gcdm_sample_step_to.argtypes = [H, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]
+    lib.gcdm_sample_step_sc.argtypes = [H, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_uint64,
+                                        C.c_void_p, C.c_void_p]
+    lib.gcdm_sample_final_sc.argtypes = [H, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.gcdm_sample_final.argtypes = [H, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.gcdm_sample_init.argtypes = [H, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]
     lib.gcdm_encode_samples.argtypes = [H, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]

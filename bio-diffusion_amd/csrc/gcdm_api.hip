@@ -815,23 +815,20 @@ int gcdm_sample_step(gcdm_handle* h, float* z, const float* context, int32_t s_i
     return gcdm_sample_step_to(h, z, z, context, s_index, num_steps, noise, seed, flags, stream_);
 }
 
-int gcdm_sample_step_to(gcdm_handle* h, const float* z_in, float* z_out, const float* context, int32_t s_index, int32_t num_steps,
-                        const float* noise, uint64_t seed, uint32_t* flags, void* stream_) {
-    float* z = const_cast<float*>(z_in);
-    if (!h || !z || !z_out || num_steps <= 0 || s_index < 0 || s_index >= num_steps) return fail(h, "gcdm_sample_step: bad argument");
-    if ((int64_t)h->gamma.size() != (int64_t)h->cfg.num_timesteps + 1) return fail(h, "gcdm_sample_step: gamma table not set");
+// One ancestral transition z_t -> z_s (sample_p_zs_given_zt, variational_diffusion.py:1204-1278) for arbitrary normalised times s < t:
+// network evaluation at t (with the self-conditioning input `sc`, or none), then the fused update into z_out.
+static int transition(gcdm_handle* h, const float* z_in, float* z_out, const float* sc, const float* context, float s, float t,
+                      const float* noise, uint64_t seed, uint32_t draw, uint32_t* flags, void* stream_) {
     hipStream_t st = (hipStream_t)stream_;
-    // s = s_index / num_steps, t = (s_index + 1) / num_steps (variational_diffusion.py:1335-1341); t [N] = t[batch_index] (:1239)
-    const float s = (float)s_index / (float)num_steps, t = (float)(s_index + 1) / (float)num_steps;
     if (fill_t(h, t, st)) return -1;
-    if (gcdm_forward(h, z, h->TBUF, context, h->EPS, flags, stream_)) return -1;
+    if (gcdm_forward_sc(h, z_in, sc, h->TBUF, context, h->EPS, flags, stream_)) return -1;
     const float gs = gamma_lookup(h, s), gt = gamma_lookup(h, t);
     // sigma_and_alpha_t_given_s (:342-367), sigma (:318-325)
     const float s2ts = -expm1f(softplusf(gs) - softplusf(gt));
     const float alpha_ts = expf(0.5f * (logsigmoidf(-gt) - logsigmoidf(-gs)));
     const float sts = sqrtf(s2ts), sig_s = sqrtf(sigmoidf_(gs)), sig_t = sqrtf(sigmoidf_(gt));
     StepArgs sa{};
-    sa.z = z; sa.z_out = z_out; sa.eps = h->EPS; sa.noise = noise; sa.seed = seed; sa.draw = (uint32_t)s_index; sa.mode = 0;
+    sa.z = const_cast<float*>(z_in); sa.z_out = z_out; sa.eps = h->EPS; sa.noise = noise; sa.seed = seed; sa.draw = draw; sa.mode = 0;
     sa.alpha_coef = alpha_ts;
     sa.c_eps = s2ts / alpha_ts / sig_t;
     sa.sigma = sts * sig_s / sig_t;
@@ -839,13 +836,39 @@ int gcdm_sample_step_to(gcdm_handle* h, const float* z_in, float* z_out, const f
     return launch_sample(h, sa, st);
 }
 
+int gcdm_sample_step_to(gcdm_handle* h, const float* z_in, float* z_out, const float* context, int32_t s_index, int32_t num_steps,
+                        const float* noise, uint64_t seed, uint32_t* flags, void* stream_) {
+    if (!h || !z_in || !z_out || num_steps <= 0 || s_index < 0 || s_index >= num_steps) return fail(h, "gcdm_sample_step: bad argument");
+    if ((int64_t)h->gamma.size() != (int64_t)h->cfg.num_timesteps + 1) return fail(h, "gcdm_sample_step: gamma table not set");
+    // s = s_index / num_steps, t = (s_index + 1) / num_steps (variational_diffusion.py:1335-1341); t [N] = t[batch_index] (:1239)
+    return transition(h, z_in, z_out, nullptr, context, (float)s_index / (float)num_steps, (float)(s_index + 1) / (float)num_steps, noise, seed,
+                      (uint32_t)s_index, flags, stream_);
+}
+
+int gcdm_sample_step_sc(gcdm_handle* h, float* z, float* self_cond, int32_t have_self_cond, const float* context, int32_t s_index,
+                        int32_t num_steps, const float* noise, const float* noise_self_cond, uint64_t seed, uint32_t* flags, void* stream_) {
+    if (!h || !z || !self_cond || num_steps <= 0 || s_index < 0 || s_index >= num_steps) return fail(h, "gcdm_sample_step_sc: bad argument");
+    if (!h->sc) return fail(h, "gcdm_sample_step_sc: the handle was created without self_condition");
+    if ((int64_t)h->gamma.size() != (int64_t)h->cfg.num_timesteps + 1) return fail(h, "gcdm_sample_step_sc: gamma table not set");
+    const float s = (float)s_index / (float)num_steps, t = (float)(s_index + 1) / (float)num_steps;
+    // z_s ~ p(z_s | z_t, previous estimate) (:1343-1352)
+    if (transition(h, z, z, have_self_cond ? self_cond : nullptr, context, s, t, noise, seed, (uint32_t)s_index, flags, stream_)) return -1;
+    // the next estimate: a jump from s to 0 WITHOUT a self-conditioning input (:1363-1375); own Philox draw index
+    return transition(h, z, self_cond, nullptr, context, 0.0f, s, noise_self_cond, seed, 0x20000000u | (uint32_t)s_index, flags, stream_);
+}
+
 int gcdm_sample_final(gcdm_handle* h, const float* z0, const float* context, const float* noise, uint64_t seed, float* out, uint32_t* flags,
                       void* stream_) {
+    return gcdm_sample_final_sc(h, z0, nullptr, context, noise, seed, out, flags, stream_);
+}
+
+int gcdm_sample_final_sc(gcdm_handle* h, const float* z0, const float* self_cond, const float* context, const float* noise, uint64_t seed,
+                         float* out, uint32_t* flags, void* stream_) {
     if (!h || !z0 || !out) return fail(h, "gcdm_sample_final: bad argument");
     if ((int64_t)h->gamma.size() != (int64_t)h->cfg.num_timesteps + 1) return fail(h, "gcdm_sample_final: gamma table not set");
     hipStream_t st = (hipStream_t)stream_;
     if (fill_t(h, 0.0f, st)) return -1;
-    if (gcdm_forward(h, z0, h->TBUF, context, h->EPS, flags, stream_)) return -1;
+    if (gcdm_forward_sc(h, z0, self_cond, h->TBUF, context, h->EPS, flags, stream_)) return -1;
     const float g0 = gamma_lookup(h, 0.0f);
     const float sigma_x = expf(0.5f * g0);                       // SNR(-0.5 * gamma_0)   (:855-859)
     const float sig0 = sqrtf(sigmoidf_(g0)), alp0 = sqrtf(sigmoidf_(-g0));

@@ -204,7 +204,7 @@ class EquivariantVariationalDiffusion(nn.Module):
         sigma_t = self.sigma(gamma_t, target_tensor=z)
         if batch is None:
             batch = _Batch(batch=batch_index, mask=node_mask, props_context=context)
-        _, eps_t = self.dynamics_network(batch, z, t[batch_index])
+        _, eps_t = self.dynamics_network(batch, z, t[batch_index], x_self_cond=xh_self_cond, xh_self_cond=xh_self_cond)
         mu = z / alpha_t_given_s[batch_index] - (sigma2_t_given_s[batch_index] / alpha_t_given_s[batch_index] / sigma_t[batch_index]) * eps_t
         sigma = sigma_t_given_s * sigma_s / sigma_t
         if noise is not None:  # raw standard-normal draws [N,3+F] (x-part gets CoM-projected like the reference's sampler)
@@ -243,8 +243,13 @@ class EquivariantVariationalDiffusion(nn.Module):
         SURVEY A.5); without it noise comes from on-device Philox(seed)."""
         if generate_x_only:
             raise NotImplementedError("mol_gen_sample (HIP): generate_x_only is not built")
-        if fix_noise:
-            lanes = 1                  # the noise is centred over the whole flat batch: one handle sees all of it
+        self_cond_on = bool(getattr(self.dynamics_network, "self_condition", False))
+        if fix_noise or self_cond_on:
+            lanes = 1                  # fix_noise: the noise is centred over the whole flat batch; self-conditioning: not sliced (yet)
+        if self_cond_on and fix_self_conditioning_noise != fix_noise:
+            raise NotImplementedError("fix_self_conditioning_noise must equal fix_noise")
+        if self_cond_on and _init_xh is not None:
+            raise NotImplementedError("mol_gen_optimize with self-conditioning is not built")
         num_timesteps = self.T if num_timesteps is None else num_timesteps
         assert 0 < return_frames <= num_timesteps, "Number of frames cannot be greater than number of timesteps."
         assert num_timesteps % return_frames == 0, "Number of frames must be evenly divisible by number of timesteps."
@@ -299,9 +304,15 @@ class EquivariantVariationalDiffusion(nn.Module):
                 raise ValueError(f"samples have shape {tuple(xin.shape)}, expected {(N, D)}")
             _native.check(lib, h, lib.gcdm_encode_samples(h, C.c_void_p(xin.data_ptr()), C.c_void_p(z.data_ptr()), fptr, stream),
                           "gcdm_encode_samples")
+        self_cond = torch.zeros_like(z) if self_cond_on else None     # the estimate fed back into the next step (:1363-1375)
         for s in reversed(range(0, num_timesteps)):
             keep, p = nptr()
-            st = lib.gcdm_sample_step(h, C.c_void_p(z.data_ptr()), ctx_ptr, s, t_norm, p, C.c_uint64(seed), fptr, stream)
+            if self_cond_on:
+                keep2, p2 = nptr()
+                st = lib.gcdm_sample_step_sc(h, C.c_void_p(z.data_ptr()), C.c_void_p(self_cond.data_ptr()), int(s != num_timesteps - 1), ctx_ptr, s, t_norm,
+                                             p, p2, C.c_uint64(seed), fptr, stream)
+            else:
+                st = lib.gcdm_sample_step(h, C.c_void_p(z.data_ptr()), ctx_ptr, s, t_norm, p, C.c_uint64(seed), fptr, stream)
             _native.check(lib, h, st, "gcdm_sample_step")
             if return_frames > 1 and (s * return_frames) % num_timesteps == 0:             # save frame (:1354-1361)
                 fr = frames[(s * return_frames) // num_timesteps]
@@ -310,7 +321,11 @@ class EquivariantVariationalDiffusion(nn.Module):
                 step_callback(s, z)
         keep, p = nptr()
         _native.check(lib, h, lib.gcdm_set_option(h, b"cog_fix", 1 if return_frames == 1 else 0), "gcdm_set_option")   # :1389
-        st = lib.gcdm_sample_final(h, C.c_void_p(z.data_ptr()), ctx_ptr, p, C.c_uint64(seed), C.c_void_p(out.data_ptr()), fptr, stream)
+        if self_cond_on:
+            st = lib.gcdm_sample_final_sc(h, C.c_void_p(z.data_ptr()), C.c_void_p(self_cond.data_ptr()) if num_timesteps > 0 else None, ctx_ptr, p,
+                                          C.c_uint64(seed), C.c_void_p(out.data_ptr()), fptr, stream)
+        else:
+            st = lib.gcdm_sample_final(h, C.c_void_p(z.data_ptr()), ctx_ptr, p, C.c_uint64(seed), C.c_void_p(out.data_ptr()), fptr, stream)
         lib.gcdm_set_option(h, b"cog_fix", 1)
         lib.gcdm_set_option(h, b"fix_noise", 0)
         _native.check(lib, h, st, "gcdm_sample_final")

@@ -111,6 +111,16 @@ int gcdm_sample_init(gcdm_handle* h, float* z, const float* noise, uint64_t seed
 int gcdm_sample_step_to(gcdm_handle* h, const float* z_in, float* z_out, const float* context, int32_t s_index, int32_t num_steps,
                         const float* noise, uint64_t seed, uint32_t* flags, void* stream);
 
+/* One step of the self-conditioned sampler (mol_gen_sample with diffusion_cfg.self_condition, variational_diffusion.py:1343-1375):
+ *   z <- p(z_s | z_t; previous estimate)        network at t = (s+1)/T with xh_self_cond = self_cond (none when have_self_cond == 0)
+ *   self_cond <- p(z_0 | z_s)                    network at t = s/T without a self-conditioning input, its own noise draw
+ * z and self_cond [N,3+F] device, updated in place.  `noise` / `noise_self_cond`: device [N,3+F] raw draws or NULL = Philox(seed).
+ * The run ends with gcdm_sample_final_sc(..., self_cond, ...) (:1378-1386). */
+int gcdm_sample_step_sc(gcdm_handle* h, float* z, float* self_cond, int32_t have_self_cond, const float* context, int32_t s_index,
+                        int32_t num_steps, const float* noise, const float* noise_self_cond, uint64_t seed, uint32_t* flags, void* stream);
+int gcdm_sample_final_sc(gcdm_handle* h, const float* z0, const float* self_cond, const float* context, const float* noise, uint64_t seed,
+                         float* out, uint32_t* flags, void* stream);
+
 /* Start of the optimisation loop (mol_gen_optimize, variational_diffusion.py:1451-1464): z = normalize(xh) (:702-732) for caller-supplied
  * samples xh [N,3+F] = [x | one-hot | charge] (device), and the reference's assert_mean_zero_with_mask (:465-474) on the positions:
  * GCDM_FLAG_MEAN_NOT_ZERO is OR-ed into `flags` (device, may be NULL) when max_b|sum_i x| / (max|x| + 1e-10) >= 1e-2.

@@ -203,6 +203,39 @@ def test_self_conditioning_forward_matches_reference_golden(mode, golden_dir):
     assert net.read_flags() == 0
 
 
+def test_self_conditioned_sampling_matches_oracle():
+    """mol_gen_sample with diffusion_cfg.self_condition=True (two network evaluations per step, the estimate fed back; oracle pinned by
+    tests/golden/sampler_small_qm9sc.npz): free-running sample on the oracle's noise tape."""
+    d = _dims("qm9")
+    F_ = synth.dims_feat(d)
+    cfgs = pkg.default_cfgs("qm9")
+    cfgs["diffusion_cfg"]["self_condition"] = True
+    net = pkg.GCPNetDynamics(**cfgs)
+    W = synth.make_weights(synth.dynamics_shapes(d["S"], d["V"], d["Se"], d["Ve"], d["L"], synth.dims_h_in(d), self_cond_feats=F_), seed=43, scale_2d=0.25)
+    net.load_state_dict(W)
+    net = net.cuda()
+    ddpm = pkg.EquivariantVariationalDiffusion(net, cfgs["diffusion_cfg"], cfgs["dataloader_cfg"], pkg.dataset_info("qm9")).cuda()
+    ocfg = _ocfg("qm9")
+    ocfg.self_condition = True
+    nn_ = torch.tensor([7, 19, 4, 12])
+    N = int(nn_.sum())
+    Tp = 6
+    want, bi = O.mol_gen_sample(W, ocfg, nn_, O.TapeNoise(1234), num_timesteps=Tp)
+    tape = O.TapeNoise(1234)
+    draws = [torch.cat((tape(N, 3), tape(N, F_)), dim=-1) for _ in range(2 * Tp + 2)]
+    out, bi2, _ = ddpm.mol_gen_sample(num_samples=len(nn_), num_nodes=nn_, device="cuda", num_timesteps=Tp, noise_fn=lambda k: draws[k])
+    out = out.cpu()
+    assert torch.equal(bi2.cpu(), bi)
+    scale = max(1.0, want[:, :3].abs().max().item())
+    assert (out[:, :3] - want[:, :3]).abs().max().item() <= TOL * scale
+    assert torch.equal(out[:, 3:], want[:, 3:])
+    # Philox noise: runs, deterministic, finite
+    a, _, _ = ddpm.mol_gen_sample(num_samples=len(nn_), num_nodes=nn_, device="cuda", num_timesteps=Tp, norm_with_original_timesteps=True, seed=5)
+    a = a.clone()
+    b, _, _ = ddpm.mol_gen_sample(num_samples=len(nn_), num_nodes=nn_, device="cuda", num_timesteps=Tp, norm_with_original_timesteps=True, seed=5)
+    assert torch.equal(a, b) and torch.isfinite(a).all()
+
+
 def test_cabi_error_paths():
     """Every misuse of the C ABI returns a negative status with a message (no exception, no crash, no silent fallback)."""
     native = pkg._native
