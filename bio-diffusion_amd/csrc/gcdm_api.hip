@@ -351,7 +351,8 @@ int gcdm_create(const GcdmConfig* cfg, gcdm_handle** out) {
     h->sc = cfg->self_condition ? 1 : 0;
     h->FinP = h->F + 1 + h->C;
     h->Fin = h->FinP + (h->sc ? h->F : 0);
-    if (h->Fin > 32) return fail(h, "too many node input features (max 32; self-conditioning doubles the diffused ones)");
+    // the projection returns FinP scalars in one 32-row M-tile; the embedding only contracts over Fin (K dimension)
+    if (h->FinP > 32 || h->Fin > 64) return fail(h, "too many node input features (projection <= 32, embedding inputs <= 64)");
     h->FinG = (h->Fin + 3) / 4;
     h->D = 3 + h->F;
     h->Se = cfg->e_hidden_dim;

@@ -201,6 +201,25 @@ def test_self_conditioning_forward_matches_reference_golden(mode, golden_dir):
     _, o2 = net(b2, xh2.to(dev), t2.to(dev), xh_self_cond=sc2.to(dev))
     assert (o2.cpu() - ref).abs().max().item() <= TOL * max(1.0, ref.abs().max().item())
     assert net.read_flags() == 0
+    # GEOM widths (33 embedding inputs, Se = 16, Ve = 8): same code, checked against the oracle
+    dg = _dims("geom")
+    Fg = synth.dims_feat(dg)
+    cg = pkg.default_cfgs("geom")
+    cg["diffusion_cfg"]["self_condition"] = True
+    ng = pkg.GCPNetDynamics(**cg)
+    Wg = synth.make_weights(synth.dynamics_shapes(dg["S"], dg["V"], dg["Se"], dg["Ve"], dg["L"], synth.dims_h_in(dg), self_cond_feats=Fg), seed=29, scale_2d=0.5)
+    ng.load_state_dict(Wg)
+    ng = ng.cuda()
+    ng._ensure_handle(dev)
+    ng.set_mfma_mode(mode)
+    og = _ocfg("geom")
+    og.self_condition = True
+    xh3, t3, bi3, _, _ = synth.make_inputs([44, 5, 91, 17], Fg, seed=33, t_value=0.21)
+    sc3 = torch.randn(xh3.shape, generator=g2)
+    ref3 = O.dynamics_forward(Wg, og, xh3, t3, bi3, xh_self_cond=sc3)
+    b3 = dict(batch=bi3.to(dev), mask=torch.ones(len(bi3), dtype=torch.bool, device=dev), props_context=None)
+    _, o3 = ng(b3, xh3.to(dev), t3.to(dev), xh_self_cond=sc3.to(dev))
+    assert (o3.cpu() - ref3).abs().max().item() <= TOL * max(1.0, ref3.abs().max().item())
 
 
 def test_self_conditioned_sampling_matches_oracle():
