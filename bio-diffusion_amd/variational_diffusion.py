@@ -248,8 +248,6 @@ class EquivariantVariationalDiffusion(nn.Module):
             lanes = 1                  # fix_noise: the noise is centred over the whole flat batch; self-conditioning: not sliced (yet)
         if self_cond_on and fix_self_conditioning_noise != fix_noise:
             raise NotImplementedError("fix_self_conditioning_noise must equal fix_noise")
-        if self_cond_on and _init_xh is not None:
-            raise NotImplementedError("mol_gen_optimize with self-conditioning is not built")
         num_timesteps = self.T if num_timesteps is None else num_timesteps
         assert 0 < return_frames <= num_timesteps, "Number of frames cannot be greater than number of timesteps."
         assert num_timesteps % return_frames == 0, "Number of frames must be evenly divisible by number of timesteps."

@@ -469,9 +469,12 @@ def mol_gen_optimize(P: Params, cfg: OracleConfig, x: Tensor, h_cat: Tensor, num
     xn, hn = normalize(cfg, x.to(dtype), h_cat, mask)
     z = torch.cat((xn, hn), dim=-1)
     assert assert_mean_zero_with_mask(z[:, :3], bi, B) < 1e-2                       # :1464
+    self_cond = None
     for s in reversed(range(T)):
-        z, _ = sample_p_zs_given_zt(P, cfg, gam, s / Tn, (s + 1) / Tn, z, bi, B, mask, ctx, noise)
-    xo, one_hot, charges = sample_p_xh_given_z0(P, cfg, gam, z, bi, B, mask, ctx, noise)
+        z, _ = sample_p_zs_given_zt(P, cfg, gam, s / Tn, (s + 1) / Tn, z, bi, B, mask, ctx, noise, xh_self_cond=self_cond)
+        if cfg.self_condition:                                                      # :1500-1512
+            self_cond, _ = sample_p_zs_given_zt(P, cfg, gam, 0.0, s / Tn, z, bi, B, mask, ctx, noise)
+    xo, one_hot, charges = sample_p_xh_given_z0(P, cfg, gam, z, bi, B, mask, ctx, noise, xh_self_cond=self_cond)
     cog = torch.zeros(B, 3, dtype=dtype).index_add_(0, bi, xo).abs().max().item()
     if cog > 5e-2:                                                                  # :1527-1537
         xo = centralize(xo, bi, B, mask)

@@ -253,6 +253,31 @@ def test_self_conditioned_sampling_matches_oracle():
     a = a.clone()
     b, _, _ = ddpm.mol_gen_sample(num_samples=len(nn_), num_nodes=nn_, device="cuda", num_timesteps=Tp, norm_with_original_timesteps=True, seed=5)
     assert torch.equal(a, b) and torch.isfinite(a).all()
+    # the optimisation loop with self-conditioning (variational_diffusion.py:1500-1512) on the alpha-conditional model
+    dc = _dims("qm9cond")
+    Fc = synth.dims_feat(dc)
+    cc = pkg.default_cfgs("qm9", ("alpha",))
+    cc["diffusion_cfg"]["self_condition"] = True
+    nc = pkg.GCPNetDynamics(**cc)
+    Wc = synth.make_weights(synth.dynamics_shapes(dc["S"], dc["V"], dc["Se"], dc["Ve"], dc["L"], synth.dims_h_in(dc), self_cond_feats=Fc), seed=47, scale_2d=0.25)
+    nc.load_state_dict(Wc)
+    nc = nc.cuda()
+    dd = pkg.EquivariantVariationalDiffusion(nc, cc["diffusion_cfg"], cc["dataloader_cfg"], pkg.dataset_info("qm9")).cuda()
+    oc = _ocfg("qm9cond")
+    oc.self_condition = True
+    gq = torch.Generator().manual_seed(9)
+    ctx_b = torch.randn((len(nn_), 1), generator=gq)
+    samples = []
+    for n in nn_.tolist():
+        x = torch.randn((n, 3), generator=gq) * 1.2
+        samples.append((x - x.mean(0, keepdim=True), torch.nn.functional.one_hot(torch.randint(0, Fc, (n,), generator=gq), Fc).float()))
+    wo, _ = O.mol_gen_optimize(Wc, oc, torch.cat([s_[0] for s_ in samples]), torch.cat([s_[1] for s_ in samples]), nn_, O.TapeNoise(77), context=ctx_b, num_timesteps=5)
+    tp = O.TapeNoise(77)
+    dr = [torch.cat((tp(N, 3), tp(N, Fc)), dim=-1) for _ in range(2 * 5 + 1)]
+    oo, _, _ = dd.mol_gen_optimize(samples=[(x.cuda(), h_.cuda()) for x, h_ in samples], num_nodes=nn_, device="cuda", num_timesteps=5, context=ctx_b.cuda(),
+                                   noise_fn=lambda k: dr[k])
+    oo = oo.cpu()
+    assert (oo[:, :3] - wo[:, :3]).abs().max().item() <= TOL * max(1.0, wo[:, :3].abs().max().item()) and torch.equal(oo[:, 3:], wo[:, 3:])
 
 
 def test_cabi_error_paths():
