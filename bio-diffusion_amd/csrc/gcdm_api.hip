@@ -62,7 +62,7 @@ struct gcdm_handle {
     float* ws = nullptr;  // workspace pool
     size_t ws_floats = 0;
     float *X0 = nullptr, *XC = nullptr, *FBAR = nullptr, *CHI0 = nullptr, *HIN4 = nullptr, *H4 = nullptr, *CHI = nullptr, *PQ4 = nullptr,
-          *VDI = nullptr, *VDJ = nullptr, *AGG = nullptr, *VEL = nullptr, *EPS = nullptr, *TBUF = nullptr, *EP4 = nullptr, *AL = nullptr, *U = nullptr, *FR = nullptr, *PROF = nullptr;
+          *VDI = nullptr, *VDJ = nullptr, *AGG = nullptr, *VEL = nullptr, *EPS = nullptr, *TBUF = nullptr, *EP4 = nullptr, *AL = nullptr, *U = nullptr, *FR = nullptr, *PROF = nullptr, *ZK = nullptr, *ZU = nullptr;
     uint32_t* d_flags = nullptr;
     float* d_gmean = nullptr;
     int flat_prev = 0, flat_next = 0;   // the plan is a slice of a larger flat batch (options "flat_prev" / "flat_next"; include/gcdm_hip.h)
@@ -611,7 +611,8 @@ int gcdm_plan_batch(gcdm_handle* h, int32_t B, const int32_t* nn) {
                  oCHI = take(96 * n), oPQ = take(512 * n), oVDI = take((size_t)(h->H0 + 3) * 3 * n), oVDJ = take((size_t)(h->H0 + 3) * 3 * n),
                  oAGG = take(GCDM_AGGW * n), oVEL = take(3 * n), oEPS = take((size_t)h->D * n), oT = take(n), oEP = take((size_t)h->Se * e),
                  oAL = take((size_t)h->Ve * e), oU = take(3 * e), oFR = take(9 * e), oPROF = take(((e + 31) / 32) * 192),
-                 oX0SC = take(h->sc ? 3 * n : 0), oBL = take(h->sc ? (size_t)h->Ve * e : 0), oUSC = take(h->sc ? 3 * e : 0);
+                 oX0SC = take(h->sc ? 3 * n : 0), oBL = take(h->sc ? (size_t)h->Ve * e : 0), oUSC = take(h->sc ? 3 * e : 0),
+                 oZK = take((size_t)h->D * n), oZU = take((size_t)h->D * n);
     h->ws_floats = off;
     HIP_OK(h, hipMalloc(&h->ws, off * sizeof(float)));
     HIP_OK(h, hipMemset(h->ws, 0, off * sizeof(float)));
@@ -619,6 +620,7 @@ int gcdm_plan_batch(gcdm_handle* h, int32_t B, const int32_t* nn) {
     h->X0 = w + oX0; h->XC = w + oXC; h->FBAR = w + oFB; h->CHI0 = w + oC0; h->HIN4 = w + oHIN; h->H4 = w + oH4; h->CHI = w + oCHI;
     h->PQ4 = w + oPQ; h->VDI = w + oVDI; h->VDJ = w + oVDJ; h->AGG = w + oAGG; h->VEL = w + oVEL; h->EPS = w + oEPS; h->TBUF = w + oT; h->EP4 = w + oEP;
     h->AL = w + oAL; h->U = w + oU; h->FR = w + oFR; h->PROF = w + oPROF;
+    h->ZK = w + oZK; h->ZU = w + oZU;
     h->X0SC = h->sc ? w + oX0SC : nullptr; h->BL = h->sc ? w + oBL : nullptr; h->USC = h->sc ? w + oUSC : nullptr;
     h->B = B; h->N = N; h->E = E; h->max_n = max_n;
     return 0;
@@ -885,6 +887,51 @@ int gcdm_sample_final_sc(gcdm_handle* h, const float* z0, const float* self_cond
     if (h->cog_fix) hipLaunchKernelGGL(k_cog_fix, dim3(h->B), dim3(64), 0, st, out, h->d_noff, h->D, h->d_flags, flags);
     HIP_OK(h, hipGetLastError());
     return 0;
+}
+
+// ---- RePaint inpainting (variational_diffusion.py:1582-1789) ----
+int gcdm_inpaint_center(gcdm_handle* h, const float* xh, const uint8_t* fixed, float* xh0, void* stream_) {
+    if (!h || !xh || !fixed || !xh0 || !h->N) return fail(h, "gcdm_inpaint_center: bad argument / no plan");
+    hipLaunchKernelGGL(k_inpaint_center, dim3(h->B), dim3(64), 0, (hipStream_t)stream_, xh, fixed, h->d_noff, h->D, xh0);
+    HIP_OK(h, hipGetLastError());
+    return 0;
+}
+
+int gcdm_inpaint_step(gcdm_handle* h, float* z, const float* xh0, const uint8_t* fixed, float* self_cond, int32_t have_self_cond,
+                      const float* context, int32_t s_index, int32_t num_steps, const float* noise_known, const float* noise_unknown,
+                      const float* noise_self_cond, uint64_t seed, uint32_t draw_base, uint32_t* flags, void* stream_) {
+    if (!h || !z || !xh0 || !fixed || num_steps <= 0 || s_index < 0 || s_index >= num_steps || !h->N) return fail(h, "gcdm_inpaint_step: bad argument / no plan");
+    if ((h->sc != 0) != (self_cond != nullptr)) return fail(h, "gcdm_inpaint_step: self_cond must be given exactly when the handle has self_condition");
+    if ((int64_t)h->gamma.size() != (int64_t)h->cfg.num_timesteps + 1) return fail(h, "gcdm_inpaint_step: gamma table not set");
+    hipStream_t st = (hipStream_t)stream_;
+    const float s = (float)s_index / (float)num_steps, t = (float)(s_index + 1) / (float)num_steps;
+    // known nodes: q(z_s | x, h) of the given molecule (compute_noised_representation, :910-931)
+    const float gs = gamma_lookup(h, s);
+    StepArgs sa{};
+    sa.z = const_cast<float*>(xh0); sa.z_out = h->ZK; sa.noise = noise_known; sa.seed = seed; sa.draw = draw_base; sa.mode = 3;
+    sa.alpha_coef = sqrtf(sigmoidf_(-gs)); sa.sigma = sqrtf(sigmoidf_(gs));
+    sa.user_flags = flags; sa.flags_dev = h->d_flags;
+    if (launch_sample(h, sa, st)) return -1;
+    // everything: one ancestral step of the model (:1652-1662), then the next self-conditioning estimate from it (:1664-1676)
+    if (transition(h, z, h->ZU, (self_cond && have_self_cond) ? self_cond : nullptr, context, s, t, noise_unknown, seed, draw_base + 1, flags, stream_)) return -1;
+    if (self_cond && transition(h, h->ZU, self_cond, nullptr, context, 0.0f, s, noise_self_cond, seed, draw_base + 2, flags, stream_)) return -1;
+    hipLaunchKernelGGL(k_inpaint_combine, dim3(h->B), dim3(64), 0, st, h->ZK, h->ZU, fixed, h->d_noff, h->D, z);
+    HIP_OK(h, hipGetLastError());
+    return 0;
+}
+
+int gcdm_inpaint_jump(gcdm_handle* h, float* z, int32_t s_index, int32_t t_index, int32_t num_steps, const float* noise, uint64_t seed,
+                      uint32_t draw, void* stream_) {
+    if (!h || !z || num_steps <= 0 || s_index < 0 || t_index <= s_index || t_index > num_steps || !h->N) return fail(h, "gcdm_inpaint_jump: bad argument / no plan");
+    if ((int64_t)h->gamma.size() != (int64_t)h->cfg.num_timesteps + 1) return fail(h, "gcdm_inpaint_jump: gamma table not set");
+    // q(z_t | z_s) (sample_p_zt_given_zs, :1163-1201; sigma_and_alpha_t_given_s :342-367)
+    const float gs = gamma_lookup(h, (float)s_index / (float)num_steps), gt = gamma_lookup(h, (float)t_index / (float)num_steps);
+    StepArgs sa{};
+    sa.z = z; sa.z_out = z; sa.noise = noise; sa.seed = seed; sa.draw = draw; sa.mode = 4;
+    sa.alpha_coef = expf(0.5f * (logsigmoidf(-gt) - logsigmoidf(-gs)));
+    sa.sigma = sqrtf(-expm1f(softplusf(gs) - softplusf(gt)));
+    sa.flags_dev = h->d_flags;
+    return launch_sample(h, sa, (hipStream_t)stream_);
 }
 
 int gcdm_unnormalize_z(gcdm_handle* h, const float* z, float* out, void* stream_) {

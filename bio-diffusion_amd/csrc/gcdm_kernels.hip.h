@@ -1069,7 +1069,7 @@ struct StepArgs {
     const int* noff; int N, D;
     float alpha_coef, c_eps, sigma;     // step: z/alpha_coef - c_eps*eps + sigma*noise ; final: alpha_coef*(z - c_eps*eps) + sigma*noise
     uint64_t seed; uint32_t draw;
-    int mode;            // 0 = step, 1 = init (z = noise), 2 = final decode
+    int mode;            // 0 = step, 1 = init (z = noise), 2 = final decode, 3 = forward noising alpha_coef*z + sigma*noise, 4 = the same + zero-CoM projection
     // final decode
     float* out; int num_atom_types, include_charges; float nv0, nv1, nv2, nb1, nb2;
     uint32_t* user_flags; uint32_t* flags_dev;
@@ -1162,6 +1162,50 @@ __global__ __launch_bounds__(1024) void k_noise_mean(const float* __restrict__ n
     if (threadIdx.x < 3) gmean[threadIdx.x] = red[threadIdx.x][0] / (float)N;
 }
 
+// RePaint inpainting (variational_diffusion.py:1582-1789).  One wave per molecule; `fixed` marks the nodes taken from the known molecule.
+// mean over the fixed nodes of a molecule of the x-part of p (0 if it has none); every lane returns the same value
+__device__ inline void fixed_mean(const float* __restrict__ p, const uint8_t* __restrict__ fixed, int o, int n, int D, float m[3]) {
+    float s[3] = {0.f, 0.f, 0.f}, cnt = 0.f;
+    for (int i = threadIdx.x; i < n; i += 64)
+        if (fixed[o + i]) {
+            const float* r = p + (size_t)(o + i) * D;
+            s[0] += r[0]; s[1] += r[1]; s[2] += r[2]; cnt += 1.f;
+        }
+#pragma unroll
+    for (int sh = 32; sh > 0; sh >>= 1) {
+        s[0] += __shfl_xor(s[0], sh); s[1] += __shfl_xor(s[1], sh); s[2] += __shfl_xor(s[2], sh); cnt += __shfl_xor(cnt, sh);
+    }
+    const float inv = 1.f / fmaxf(cnt, 1.f);
+    m[0] = s[0] * inv; m[1] = s[1] * inv; m[2] = s[2] * inv;
+}
+
+// the known molecule, shifted so that its fixed nodes have zero CoM (:1625-1633)
+__global__ __launch_bounds__(64) void k_inpaint_center(const float* __restrict__ xh, const uint8_t* __restrict__ fixed, const int* __restrict__ noff,
+                                                       int D, float* __restrict__ out) {
+    const int b = blockIdx.x, o = noff[b], n = noff[b + 1] - o;
+    float m[3];
+    fixed_mean(xh, fixed, o, n, D, m);
+    for (int idx = threadIdx.x; idx < n * D; idx += 64) {
+        const int c = idx % D;
+        const size_t gi = (size_t)o * D + idx;
+        out[gi] = xh[gi] - (c < 3 ? m[c] : 0.f);
+    }
+}
+
+// z = fixed ? z_known + (CoM_fixed(z_unknown) - CoM_fixed(z_known)) : z_unknown   (:1678-1702)
+__global__ __launch_bounds__(64) void k_inpaint_combine(const float* __restrict__ zk, const float* __restrict__ zu, const uint8_t* __restrict__ fixed,
+                                                        const int* __restrict__ noff, int D, float* __restrict__ z) {
+    const int b = blockIdx.x, o = noff[b], n = noff[b + 1] - o;
+    float mk[3], mu[3];
+    fixed_mean(zk, fixed, o, n, D, mk);
+    fixed_mean(zu, fixed, o, n, D, mu);
+    for (int idx = threadIdx.x; idx < n * D; idx += 64) {
+        const int i = idx / D, c = idx - i * D;
+        const size_t gi = (size_t)o * D + idx;
+        z[gi] = fixed[o + i] ? zk[gi] + (c < 3 ? mu[c] - mk[c] : 0.f) : zu[gi];
+    }
+}
+
 __global__ __launch_bounds__(64) void k_sample(StepArgs a) {
     extern __shared__ __attribute__((aligned(16))) float ns[];  // [n][D] noise, then results
     const int b = blockIdx.x, o = a.noff[b], n = a.noff[b + 1] - o, D = a.D;
@@ -1187,13 +1231,16 @@ __global__ __launch_bounds__(64) void k_sample(StepArgs a) {
             const size_t gi = (size_t)(o + i) * D + c;
             // mu = z / alpha_ts - (sigma2_ts / alpha_ts / sigma_t) * eps ; zs = mu + sigma * noise   (:1247-1263)
             // final: mu = 1/alpha_0 * (z0 - sigma_0 * eps) ; xh = mu + sigma_x * noise          (:571, :878-886)
+            // forward noising: q(z_t | x, h) = alpha_t * xh + sigma_t * noise (:922-929) and q(z_t | z_s) (:1174-1185)
+            if (a.mode >= 3) v = a.alpha_coef * a.z[gi] + a.sigma * e;
+            else
             v = (a.mode == 0) ? (a.z[gi] / a.alpha_coef - a.c_eps * a.eps[gi]) + a.sigma * e
                               : a.alpha_coef * (a.z[gi] - a.c_eps * a.eps[gi]) + a.sigma * e;
         }
         ns[idx] = v;
     }
     __syncthreads();
-    if (a.mode == 0) {  // project x back to zero CoM (:1266-1277)
+    if (a.mode == 0 || a.mode == 4) {  // project x back to zero CoM (:1266-1277, :1187-1194)
         float s[3] = {0.f, 0.f, 0.f};
         for (int i = 0; i < n; ++i) { s[0] += ns[i * D]; s[1] += ns[i * D + 1]; s[2] += ns[i * D + 2]; }
         s[0] /= (float)n; s[1] /= (float)n; s[2] /= (float)n;
@@ -1202,7 +1249,7 @@ __global__ __launch_bounds__(64) void k_sample(StepArgs a) {
             const int i = idx / D, c = idx - i * D;
             zo[(size_t)(o + i) * D + c] = ns[idx] - (c < 3 ? s[c] : 0.f);
         }
-    } else if (a.mode == 1) {
+    } else if (a.mode == 1 || a.mode == 3) {
         float* zo = a.z_out ? a.z_out : a.z;
         for (int idx = threadIdx.x; idx < n * D; idx += 64) {
             const int i = idx / D, c = idx - i * D;

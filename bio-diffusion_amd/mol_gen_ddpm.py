@@ -153,11 +153,43 @@ class _MoleculeGenerationDDPM(nn.Module):
                            num_resamplings: int = 1, jump_length: int = 1,
                            molecule_builder: Optional[Callable[[torch.Tensor, torch.Tensor, Dict[str, Any]], Any]] = None,
                            **kw) -> List[Any]:
-        """qm9_mol_gen_ddpm.py:1063-1243 up to (not including) the RDKit post-processing."""
-        if ddpm_mode != "unconditional" or sample_chain:
-            raise NotImplementedError("only ddpm_mode='unconditional' without chains is built")
-        x, one_hot, charges, batch_index = self.sample(num_samples, num_nodes=num_nodes, node_mask=node_mask, context=context,
-                                                       num_timesteps=num_timesteps, **kw)
+        """qm9_mol_gen_ddpm.py:1063-1243 up to (not including) the RDKit post-processing.  ``ddpm_mode="inpainting"`` (:1130-1181): RePaint on an
+        all-zero molecule with the nodes of ``node_mask`` fixed (default: the first node of the batch), then every generated molecule is
+        moved back to the given one's centre of mass."""
+        if sample_chain:
+            raise NotImplementedError("chains (sample_chain=True) are not built")
+        if ddpm_mode == "unconditional":
+            x, one_hot, charges, batch_index = self.sample(num_samples, num_nodes=num_nodes, node_mask=node_mask, context=context,
+                                                           num_timesteps=num_timesteps, **kw)
+        elif ddpm_mode == "inpainting":
+            if num_nodes is None:
+                num_nodes = self.ddpm.num_nodes_distribution.sample(num_samples)
+                assert int(num_nodes.max()) <= self.dataset_info.get("max_n_nodes", int(num_nodes.max()))
+            if self.condition_on_context:
+                if context is None:
+                    if self.props_distr is None:
+                        raise ValueError("context required (no props_distr attached)")
+                    context = self.props_distr.sample_batch(num_nodes)
+            else:
+                context = None
+            dev = self.device
+            n_total = int(torch.as_tensor(num_nodes).sum())
+            batch_index = torch.repeat_interleave(torch.arange(len(num_nodes), device=dev), torch.as_tensor(num_nodes).to(dev))
+            molecule = {"x": torch.zeros((n_total, self.num_x_dims), device=dev), "one_hot": torch.zeros((n_total, self.num_atom_types), device=dev),
+                        "charges": torch.zeros((n_total, 1), device=dev), "num_nodes": num_nodes, "batch_index": batch_index}
+            if node_mask is None:                     # "largely disable inpainting": only the first node is a fixed point (:1159-1162)
+                node_mask = torch.zeros(n_total, dtype=torch.bool, device=dev)
+                node_mask[0] = True
+            xh = self.ddpm.inpaint(molecule=molecule, node_mask_fixed=node_mask, num_resamplings=num_resamplings, jump_length=jump_length,
+                                   num_timesteps=num_timesteps, context=context, **kw)
+            cnt = torch.as_tensor(num_nodes).to(dev, torch.float32)[:, None]
+            com_before = torch.zeros((len(cnt), self.num_x_dims), device=dev).index_add_(0, batch_index, molecule["x"]) / cnt
+            com_after = torch.zeros((len(cnt), self.num_x_dims), device=dev).index_add_(0, batch_index, xh[:, : self.num_x_dims]) / cnt
+            x = xh[:, : self.num_x_dims] + (com_before - com_after)[batch_index]
+            one_hot = xh[:, self.num_x_dims:-1] if self.include_charges else xh[:, self.num_x_dims:]
+            charges = xh[:, -1:] if self.include_charges else torch.zeros(0, device=dev)
+        else:
+            raise NotImplementedError(f"ddpm_mode {ddpm_mode!r} is not implemented (reference: 'unconditional' | 'inpainting')")
         atom_types = one_hot.argmax(dim=-1)
         counts = torch.unique_consecutive(batch_index, return_counts=True)[1].tolist()
         mols, o = [], 0

@@ -78,6 +78,27 @@ def slice_cuts(num_nodes: torch.Tensor, K: int) -> List[int]:
     return cuts
 
 
+def repaint_schedule(resamplings: int, jump_length: int, num_timesteps: int) -> List[int]:
+    """RePaint schedule (variational_diffusion.py:1548-1578, `get_repaint_schedule`): the number of denoising steps to apply before each
+    jump back, from t = T downwards.  T is cut into ``(T-1) // jump_length`` stretches of ``jump_length`` steps plus a remainder; every
+    stretch is visited ``resamplings`` times, the last visit running on through the following stretch, and the remainder joins the last
+    entry.  (With one resampling there is never a jump: the schedule is [T].)"""
+    if num_timesteps <= 0:
+        return []
+    if jump_length <= 0:
+        raise ValueError("jump_length must be positive")
+    stretches = (num_timesteps - 1) // jump_length
+    rest = num_timesteps - stretches * jump_length
+    if stretches == 0 or resamplings <= 0:
+        return [rest]
+    if resamplings == 1:
+        return [num_timesteps]
+    low_to_high = [jump_length] * (resamplings - 1)
+    low_to_high += ([2 * jump_length] + [jump_length] * (resamplings - 2)) * (stretches - 1)
+    low_to_high.append(jump_length + rest)
+    return low_to_high[::-1]
+
+
 class PredefinedNoiseSchedule(nn.Module):
     def __init__(self, noise_schedule: str, num_timesteps: int, noise_precision: float, verbose: bool = False, **kwargs):
         super().__init__()
@@ -349,6 +370,112 @@ class EquivariantVariationalDiffusion(nn.Module):
         self.last_flags = fl
         return (out if return_frames == 1 else frames), batch_index, node_mask
 
+    @torch.inference_mode()
+    def inpaint(self, molecule: Dict[str, Any], node_mask_fixed: torch.Tensor, num_resamplings: int = 1, jump_length: int = 1,
+                return_frames: int = 1, num_timesteps: Optional[int] = None, context: Optional[torch.Tensor] = None,
+                generate_x_only: bool = False, noise_fn: Optional[Callable[[int], torch.Tensor]] = None, seed: int = 1234,
+                _retry_fp32: bool = False) -> torch.Tensor:
+        """Draw samples while keeping parts of the given molecules fixed (RePaint; variational_diffusion.py:1582-1789).
+        ``molecule``: dict with "x" [N,3], "one_hot" [N,F], "charges" [N,1] (if the model has charges), "num_nodes" [B] (and optionally
+        "batch_index", which must be the contiguous one); ``node_mask_fixed`` [N] bool.  Returns [N,3+F], or [return_frames,N,3+F].
+        The reference method raises on every call (:1650, :1177); this is that method with the two tokens repaired (include/gcdm_hip.h,
+        DESIGN.md 7), pinned by tests/golden/inpaint_small_qm9.npz.  ``noise_fn(k)``: the k-th raw draw in the reference's order -- z_T, then
+        per step [known part, model step, self-conditioning estimate if any], one per jump back, and the final decode."""
+        if generate_x_only:
+            raise NotImplementedError("inpaint (HIP): generate_x_only is not built")
+        num_timesteps = self.T if num_timesteps is None else num_timesteps
+        assert 0 < return_frames <= num_timesteps, "Number of frames cannot be greater than number of timesteps."
+        assert num_timesteps % return_frames == 0, "Number of frames must be evenly divisible by number of timesteps."
+        assert jump_length == 1 or return_frames == 1, "Chain visualization is only implemented for `jump_length=1`"
+        num_nodes = torch.as_tensor(molecule["num_nodes"])
+        device = torch.device(molecule["x"].device)
+        dyn, lib, h = self._native(device)
+        self_cond_on = bool(getattr(dyn, "self_condition", False))
+        batch_index = num_nodes_to_batch_index(len(num_nodes), num_nodes.to(device), device=device)
+        if "batch_index" in molecule and not torch.equal(molecule["batch_index"].to(device), batch_index):
+            raise ValueError("molecule['batch_index'] must be the contiguous index implied by molecule['num_nodes']")
+        dyn.plan(num_nodes.cpu())
+        N, D = int(batch_index.shape[0]), self.num_x_dims + self.num_node_scalar_features
+        parts = [molecule["x"], molecule["one_hot"]] + ([molecule["charges"]] if self.include_charges else [])
+        xh0 = torch.cat([p.to(device, torch.float32) for p in parts], dim=-1).contiguous()
+        fixed = node_mask_fixed.to(device).bool().contiguous()
+        if xh0.shape != (N, D) or fixed.shape != (N,):
+            raise ValueError(f"molecule has shape {tuple(xh0.shape)} / mask {tuple(fixed.shape)}, expected {(N, D)} / {(N,)}")
+        ctx_ptr, context_in = None, context
+        if context is not None:
+            context = context.to(device, torch.float32)[batch_index].contiguous()
+            ctx_ptr = C.c_void_p(context.data_ptr())
+        elif dyn.condition_on_context:
+            raise ValueError("context required by a context-conditioned model")
+        stream = C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+        flags = torch.zeros(1, dtype=torch.int32, device=device)
+        fptr, sd = C.c_void_p(flags.data_ptr()), C.c_uint64(seed)
+        ptr = lambda t_: None if t_ is None else C.c_void_p(t_.data_ptr())       # noqa: E731
+        z = torch.empty((N, D), dtype=torch.float32, device=device)
+        frames = torch.zeros((return_frames, N, D), dtype=torch.float32, device=device)
+        self_cond = torch.zeros_like(z) if self_cond_on else None
+        k = 0
+        held: List[Optional[torch.Tensor]] = []
+
+        def draw():
+            """Tape tensor (kept alive until the stream has consumed it) or None = Philox draw number k."""
+            nonlocal k
+            nz = None if noise_fn is None else noise_fn(k).to(device, torch.float32).contiguous()
+            k += 1
+            held.append(nz)
+            return ptr(nz)
+
+        _native.check(lib, h, lib.gcdm_inpaint_center(h, ptr(xh0), ptr(fixed), ptr(xh0), stream), "gcdm_inpaint_center")
+        _native.check(lib, h, lib.gcdm_sample_init(h, ptr(z), draw(), sd, stream), "gcdm_sample_init")
+        schedule = repaint_schedule(num_resamplings, jump_length, num_timesteps)
+        s = num_timesteps - 1
+        first = True
+        for i, num_denoise_steps in enumerate(schedule):
+            for j in range(num_denoise_steps):
+                base = k
+                p_known, p_unknown = draw(), draw()
+                p_sc = draw() if self_cond_on else None
+                st = lib.gcdm_inpaint_step(h, ptr(z), ptr(xh0), ptr(fixed), ptr(self_cond), int(not first), ctx_ptr, s, num_timesteps, p_known, p_unknown,
+                                           p_sc, sd, base, fptr, stream)
+                _native.check(lib, h, st, "gcdm_inpaint_step")
+                first = False
+                # frame at the end of a resample cycle (:1707-1715)
+                if return_frames > 1 and (num_denoise_steps > jump_length or i == len(schedule) - 1) and (s * return_frames) % num_timesteps == 0:
+                    fr = frames[(s * return_frames) // num_timesteps]
+                    _native.check(lib, h, lib.gcdm_unnormalize_z(h, ptr(z), ptr(fr), stream), "gcdm_unnormalize_z")
+                if j == num_denoise_steps - 1 and i < len(schedule) - 1:       # go back `jump_length` steps (:1717-1737)
+                    t = s + jump_length
+                    dk = k
+                    _native.check(lib, h, lib.gcdm_inpaint_jump(h, ptr(z), s, t, num_timesteps, draw(), sd, dk, stream), "gcdm_inpaint_jump")
+                    s = t
+                s -= 1
+        out = frames[0]
+        _native.check(lib, h, lib.gcdm_set_option(h, b"cog_fix", 1 if return_frames == 1 else 0), "gcdm_set_option")   # :1767
+        if self_cond_on:
+            st = lib.gcdm_sample_final_sc(h, ptr(z), ptr(self_cond) if not first else None, ctx_ptr, draw(), sd, ptr(out), fptr, stream)
+        else:
+            st = lib.gcdm_sample_final(h, ptr(z), ctx_ptr, draw(), sd, ptr(out), fptr, stream)
+        lib.gcdm_set_option(h, b"cog_fix", 1)
+        _native.check(lib, h, st, "gcdm_sample_final")
+        fl = int(flags.item())                                                  # the one host sync of the run
+        held.clear()
+        if fl & _native.FLAG_F16_RANGE:
+            if _retry_fp32:
+                raise RuntimeError("f16 range flag raised in fp32 mode (internal error)")
+            log.warning("An activation left the f16 range of the split-precision kernels; re-running the inpainting with fp32 MFMA.")
+            dyn.set_mfma_mode(0)
+            try:
+                return self.inpaint(molecule, node_mask_fixed, num_resamplings, jump_length, return_frames, num_timesteps, context_in,
+                                    generate_x_only, noise_fn=noise_fn, seed=seed, _retry_fp32=True)
+            finally:
+                dyn.set_mfma_mode(1)
+        if fl & _native.FLAG_NAN_VEL:
+            log.warning("Detected NaN in `vel` -> GCPNet `vel` output was reset to zero for at least one time step.")
+        if fl & _native.FLAG_COG_DRIFT:
+            log.warning("CoG drift above 5e-2. Projected the positions down.")
+        self.last_flags = fl
+        return out if return_frames == 1 else frames
+
     # ---- several independent batches in flight (evaluation driver) -------------------------------------------------------------
     class _Lane:
         """One extra library handle + stream: its own packed weights (26 MB) and workspace, so that the launches of different
@@ -584,6 +711,10 @@ class EquivariantVariationalDiffusion(nn.Module):
             log.warning("CoG drift above 5e-2. Projected the positions down.")
         self.last_flags = fl
         return sb.out, sb.batch_index, torch.ones_like(sb.batch_index).bool()
+
+    def get_repaint_schedule(self, resamplings: int, jump_length: int, num_timesteps: int) -> List[int]:
+        """variational_diffusion.py:1548-1578."""
+        return repaint_schedule(resamplings, jump_length, num_timesteps)
 
     @torch.inference_mode()
     def mol_gen_optimize(self, samples: List[Tuple[torch.Tensor, torch.Tensor]], num_nodes: torch.Tensor, device: Union[torch.device, str],

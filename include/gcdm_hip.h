@@ -128,6 +128,29 @@ int gcdm_sample_final_sc(gcdm_handle* h, const float* z0, const float* self_cond
  * num_timesteps) followed by gcdm_sample_final. */
 int gcdm_encode_samples(gcdm_handle* h, const float* xh, float* z, uint32_t* flags, void* stream);
 
+/* RePaint inpainting (EquivariantVariationalDiffusion.inpaint, variational_diffusion.py:1582-1789): parts of a given molecule stay fixed
+ * while the model generates the rest.  `fixed` [N] bytes (device; non-zero = node taken from the given molecule).  The reference method
+ * raises on every call (:1650 reads a variable before it is assigned; :1177 indexes a [B,1] tensor with the [N] node mask); these entry
+ * points implement it with those two tokens repaired -- see oracle/gcdm_oracle.py `inpaint`, DESIGN.md 7 -- and, unlike :1626/:1688/:1694,
+ * a molecule without fixed nodes is simply generated freely (shift 0) instead of raising.
+ *   gcdm_inpaint_center   xh0 [N,3+F] = xh shifted so that each molecule's FIXED nodes have zero CoM (:1625-1633); features untouched,
+ *                         the molecule is NOT normalised (as in the reference).  xh0 may alias xh.
+ *   gcdm_inpaint_step     one step t = (s+1)/num_steps -> s = s/num_steps (:1640-1705):
+ *                           z_known   = alpha_s xh0 + sigma_s eps_1                    (compute_noised_representation, :910-931)
+ *                           z_unknown ~ p(z_s | z_t = z [, self_cond])                 (as gcdm_sample_step)
+ *                           self_cond <- p(z_0 | z_unknown), no self-conditioning input (only with config.self_condition; else pass NULL)
+ *                           z = fixed ? z_known + CoM_fixed(z_unknown) - CoM_fixed(z_known) : z_unknown
+ *                         noise_*: device [N,3+F] raw draws or NULL = Philox(seed) with draw indices draw_base, draw_base+1, draw_base+2.
+ *   gcdm_inpaint_jump     z <- q(z_t | z_s), t_index > s_index, positions re-projected to zero CoM (sample_p_zt_given_zs, :1163-1201).
+ * A run: z = gcdm_sample_init; for each entry of the schedule (get_repaint_schedule, :1548-1578) that many gcdm_inpaint_step, then --
+ * except after the last entry -- gcdm_inpaint_jump by jump_length; finally gcdm_sample_final[_sc]. */
+int gcdm_inpaint_center(gcdm_handle* h, const float* xh, const uint8_t* fixed, float* xh0, void* stream);
+int gcdm_inpaint_step(gcdm_handle* h, float* z, const float* xh0, const uint8_t* fixed, float* self_cond, int32_t have_self_cond,
+                      const float* context, int32_t s_index, int32_t num_steps, const float* noise_known, const float* noise_unknown,
+                      const float* noise_self_cond, uint64_t seed, uint32_t draw_base, uint32_t* flags, void* stream);
+int gcdm_inpaint_jump(gcdm_handle* h, float* z, int32_t s_index, int32_t t_index, int32_t num_steps, const float* noise, uint64_t seed,
+                      uint32_t draw, void* stream);
+
 /* unnormalize_z (variational_diffusion.py:759-792): out [N,3+F] = continuous, un-normalised copy of the latent z -- one frame of the
  * chain visualisation (`mol_gen_sample(return_frames > 1)`, :1354-1361).  With frames the reference skips the final CoG re-projection
  * (:1389): set option "cog_fix" to 0 before gcdm_sample_final (default 1). */

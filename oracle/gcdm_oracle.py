@@ -450,6 +450,27 @@ def assert_mean_zero_with_mask(x: Tensor, batch_index: Tensor, B: int, eps: floa
     return err / (largest + eps)
 
 
+
+def get_repaint_schedule(resamplings: int, jump_length: int, num_timesteps: int) -> List[int]:
+    """EquivariantVariationalDiffusion.get_repaint_schedule, variational_diffusion.py:1548-1578: how many denoising steps to apply before
+    each jump back (RePaint), listed from t = T downwards.  Pinned to the reference's outputs in tests/golden/repaint_schedule.json."""
+    t, out = 0, []
+    while t < num_timesteps:
+        step = jump_length if t + jump_length < num_timesteps else num_timesteps - t
+        if step == jump_length and t + jump_length < num_timesteps:
+            if out:
+                out[-1] += step
+                out.extend([step] * (resamplings - 1))
+            else:
+                out.extend([step] * resamplings)
+        elif out:
+            out[-1] += step
+        else:
+            out.append(step)
+        t += step
+    return out[::-1]
+
+
 def mol_gen_optimize(P: Params, cfg: OracleConfig, x: Tensor, h_cat: Tensor, num_nodes: Tensor, noise,
                      context: Optional[Tensor] = None, num_timesteps: Optional[int] = None,
                      norm_with_original_timesteps: bool = False, dtype=torch.float32) -> Tuple[Tensor, Tensor]:
@@ -480,6 +501,89 @@ def mol_gen_optimize(P: Params, cfg: OracleConfig, x: Tensor, h_cat: Tensor, num
         xo = centralize(xo, bi, B, mask)
     return torch.cat((xo, one_hot.to(dtype)), dim=-1), bi
 
+
+
+def sample_p_zt_given_zs(cfg: OracleConfig, gam: Tensor, zs: Tensor, s: float, t: float, batch_index: Tensor, B: int, mask: Tensor,
+                         noise) -> Tensor:
+    """variational_diffusion.py:1163-1201: the forward (noising) jump z_s -> z_t, s < t, x re-projected to zero CoM.
+    REPAIR: the reference line :1177 reads `alpha_t_given_s[node_mask] * zs`, a boolean-mask index of a [B,1] tensor with an [N] mask, which
+    raises IndexError unless N == B; every other per-molecule factor in the file is gathered with `[batch_index]` (e.g. :929, :1252), and
+    that is what is restated here."""
+    dt = zs.dtype
+    gs = gamma_at(gam, torch.full((B, 1), s, dtype=dt), cfg.num_timesteps).to(dt)
+    gt = gamma_at(gam, torch.full((B, 1), t, dtype=dt), cfg.num_timesteps).to(dt)
+    _, sts, ats = sigma_and_alpha_t_given_s(gt, gs)
+    zt = ats[batch_index] * zs + sts[batch_index] * sample_combined_noise(noise, batch_index, B, mask, cfg.num_node_scalar_features, dt)
+    return torch.cat((centralize(zt[:, :3], batch_index, B, mask), zt[:, 3:]), dim=-1)
+
+
+def _fixed_mean(x: Tensor, fixed: Tensor, batch_index: Tensor, B: int) -> Tensor:
+    """scatter(x[fixed], batch_index[fixed], reduce="mean") with one row per molecule (a molecule without fixed nodes gets 0).  The reference
+    omits dim_size (:1626, :1688, :1694), so its result is shorter than B -- and the following `[batch_index]` gather raises -- whenever the
+    last molecules have no fixed node; for inputs the reference can process the two agree."""
+    sums = torch.zeros((B, x.shape[1]), dtype=x.dtype).index_add_(0, batch_index[fixed], x[fixed])
+    cnt = torch.zeros(B, dtype=x.dtype).index_add_(0, batch_index[fixed], torch.ones(int(fixed.sum()), dtype=x.dtype))
+    return sums / cnt.clamp(min=1)[:, None]
+
+
+def inpaint(P: Params, cfg: OracleConfig, x: Tensor, h_cat: Tensor, h_int: Optional[Tensor], num_nodes: Tensor, fixed: Tensor, noise,
+            num_resamplings: int = 1, jump_length: int = 1, return_frames: int = 1, num_timesteps: Optional[int] = None,
+            context: Optional[Tensor] = None, dtype=torch.float32) -> Tensor:
+    """EquivariantVariationalDiffusion.inpaint (RePaint), variational_diffusion.py:1582-1789.  The reference method cannot run as written:
+      * :1650 divides by `num_denoise_steps` before the loop that defines it (UnboundLocalError on every call); the value is 0 / anything,
+        i.e. the self-conditioning jump targets t = 0 as in mol_gen_sample (:1364) -- restated as 0;
+      * :1177 (see sample_p_zt_given_zs above) raises IndexError on the first jump back.
+    tests/golden/make_inpaint_golden.py runs the reference with exactly these two tokens repaired at run time; this restatement is pinned
+    to that output and is "reference + two repairs", not the reference.  As in the reference the known molecule is used as given (it is not
+    passed through `normalize`), only shifted so that its fixed nodes have zero CoM (:1625-1633)."""
+    T = cfg.num_timesteps if num_timesteps is None else num_timesteps
+    assert 0 < return_frames <= T and T % return_frames == 0
+    assert jump_length == 1 or return_frames == 1
+    B = len(num_nodes)
+    bi = num_nodes_to_batch_index(num_nodes)
+    mask = torch.ones_like(bi).bool()
+    fixed = fixed.bool()
+    ctx = None if context is None else context.to(dtype)[bi]
+    parts = [x.to(dtype), h_cat.to(dtype)] + ([h_int.to(dtype)] if cfg.include_charges else [])
+    xh0 = torch.cat(parts, dim=-1)
+    xh0[:, :3] = xh0[:, :3] - _fixed_mean(x.to(dtype), fixed, bi, B)[bi]
+    gam = gamma_table(cfg)
+    Fd = cfg.num_node_scalar_features
+    z = sample_combined_noise(noise, bi, B, mask, Fd, dtype)
+    out = torch.zeros((return_frames,) + tuple(z.shape), dtype=dtype)
+    schedule = get_repaint_schedule(num_resamplings, jump_length, T)
+    s = T - 1
+    self_cond = None
+    fm = fixed.to(dtype)[:, None]
+    for i, steps in enumerate(schedule):
+        for j in range(steps):
+            sn, tn = s / T, (s + 1) / T
+            g_s = gamma_at(gam, torch.full((B, 1), sn, dtype=dtype), cfg.num_timesteps).to(dtype)
+            # compute_noised_representation (:910-931)
+            eps_known = sample_combined_noise(noise, bi, B, mask, Fd, dtype)
+            z_known = torch.sqrt(torch.sigmoid(-g_s))[bi] * xh0 + torch.sqrt(torch.sigmoid(g_s))[bi] * eps_known
+            z_unknown, _ = sample_p_zs_given_zt(P, cfg, gam, sn, tn, z, bi, B, mask, ctx, noise, xh_self_cond=self_cond)
+            if cfg.self_condition:                                    # :1664-1676
+                self_cond, _ = sample_p_zs_given_zt(P, cfg, gam, 0.0, sn, z_unknown, bi, B, mask, ctx, noise)
+            shift = _fixed_mean(z_unknown[:, :3], fixed, bi, B) - _fixed_mean(z_known[:, :3], fixed, bi, B)   # :1680-1697
+            z_known = torch.cat((z_known[:, :3] + shift[bi], z_known[:, 3:]), dim=-1)
+            z = z_known * fm + z_unknown * (1 - fm)
+            assert assert_mean_zero_with_mask(z[:, :3], bi, B) < 1e-2
+            if (steps > jump_length or i == len(schedule) - 1) and (s * return_frames) % T == 0:     # :1707-1715
+                out[(s * return_frames) // T] = unnormalize_z(cfg, z, mask)
+            if j == steps - 1 and i < len(schedule) - 1:              # :1717-1737: jump back
+                t_back = s + jump_length
+                z = sample_p_zt_given_zs(cfg, gam, z, sn, t_back / T, bi, B, mask, noise)
+                s = t_back
+            s -= 1
+    xo, one_hot, charges = sample_p_xh_given_z0(P, cfg, gam, z, bi, B, mask, ctx, noise, xh_self_cond=self_cond)
+    if return_frames == 1:
+        cog = torch.zeros(B, 3, dtype=dtype).index_add_(0, bi, xo).abs().max().item()
+        if cog > 5e-2:
+            xo = centralize(xo, bi, B, mask)
+    parts = [xo, one_hot.to(dtype)] + ([charges.to(dtype)] if cfg.include_charges else [])
+    out[0] = torch.cat(parts, dim=-1)
+    return out[0] if return_frames == 1 else out
 
 # ------------------------------------------------------------------------------------------------
 # algorithmic FLOP count (SURVEY A.4) -- used by bench.py for the roofline line

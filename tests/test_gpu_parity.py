@@ -280,6 +280,83 @@ def test_self_conditioned_sampling_matches_oracle():
     assert (oo[:, :3] - wo[:, :3]).abs().max().item() <= TOL * max(1.0, wo[:, :3].abs().max().item()) and torch.equal(oo[:, 3:], wo[:, 3:])
 
 
+def _inpaint_inputs(nn_, F_, charges, seed=21):
+    N = int(nn_.sum())
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn((N, 3), generator=g) * 1.5 + torch.tensor([0.3, -2.0, 1.0])            # not centred
+    oh = torch.nn.functional.one_hot(torch.randint(0, F_, (N,), generator=g), F_).float()
+    ch = torch.randint(0, 9, (N, 1), generator=g).float() if charges else None
+    fixed = torch.rand(N, generator=g) < 0.4
+    off = [0] + nn_.cumsum(0).tolist()
+    fixed[off[1]:off[2]] = False                                                           # a molecule generated freely
+    fixed[off[2]:off[3]] = True                                                            # a molecule kept whole
+    fixed[0] = True
+    return x, oh, ch, fixed
+
+
+@pytest.mark.parametrize("selfcond", [False, True])
+def test_inpaint_matches_oracle(selfcond):
+    """RePaint inpainting (variational_diffusion.py:1582-1789 with its two crashing tokens repaired; oracle pinned by
+    tests/golden/inpaint_small_qm9.npz): known part re-noised each step, model step, CoM matching, jumps back -- on the oracle's noise tape."""
+    d = _dims("qm9")
+    F_ = synth.dims_feat(d)
+    cfgs = pkg.default_cfgs("qm9")
+    cfgs["diffusion_cfg"]["self_condition"] = selfcond
+    net = pkg.GCPNetDynamics(**cfgs)
+    W = synth.make_weights(synth.dynamics_shapes(d["S"], d["V"], d["Se"], d["Ve"], d["L"], synth.dims_h_in(d), self_cond_feats=F_ if selfcond else 0),
+                           seed=43, scale_2d=0.25)
+    net.load_state_dict(W)
+    net = net.cuda()
+    ddpm = pkg.EquivariantVariationalDiffusion(net, cfgs["diffusion_cfg"], cfgs["dataloader_cfg"], pkg.dataset_info("qm9")).cuda()
+    ocfg = _ocfg("qm9")
+    ocfg.self_condition = selfcond
+    nn_ = torch.tensor([7, 19, 4, 12])
+    N = int(nn_.sum())
+    x, oh, ch, fixed = _inpaint_inputs(nn_, d["num_atom_types"], True)
+    mol = dict(x=x.cuda(), one_hot=oh.cuda(), charges=ch.cuda(), num_nodes=nn_)
+    runs = [dict(num_resamplings=2, jump_length=2, num_timesteps=6, return_frames=1)]
+    if not selfcond:
+        runs.append(dict(num_resamplings=3, jump_length=1, num_timesteps=6, return_frames=3))
+    for kw in runs:
+        want = O.inpaint(W, ocfg, x, oh, ch, nn_, fixed, O.TapeNoise(1234), **kw)
+        tape = O.TapeNoise(1234)
+        cache = {}
+        def noise_fn(k, _t=tape, _c=cache):
+            assert k == len(_c)                                    # the draws are requested in order, each once
+            _c[k] = torch.cat((_t(N, 3), _t(N, F_)), dim=-1)
+            return _c[k]
+        out = ddpm.inpaint(mol, fixed.cuda(), noise_fn=noise_fn, **kw).cpu()
+        assert out.shape == want.shape
+        last, lw = (out, want) if kw["return_frames"] == 1 else (out[0], want[0])
+        scale = max(1.0, want.abs().max().item())
+        assert (last[:, :3] - lw[:, :3]).abs().max().item() <= TOL * scale and torch.equal(last[:, 3:], lw[:, 3:])
+        if kw["return_frames"] > 1:
+            assert (out[1:] - want[1:]).abs().max().item() <= TOL * scale and want[1:].abs().max().item() > 0
+    assert torch.equal(mol["x"].cpu(), x)                          # the caller's molecule is not modified
+    # Philox noise: deterministic, finite, seed-dependent; the schedule method is the reference's
+    a = ddpm.inpaint(mol, fixed.cuda(), num_resamplings=2, jump_length=2, num_timesteps=6, seed=5).clone()
+    b = ddpm.inpaint(mol, fixed.cuda(), num_resamplings=2, jump_length=2, num_timesteps=6, seed=5)
+    c = ddpm.inpaint(mol, fixed.cuda(), num_resamplings=2, jump_length=2, num_timesteps=6, seed=6)
+    assert torch.equal(a, b) and torch.isfinite(a).all() and not torch.equal(a[:, :3], c[:, :3])
+    assert ddpm.get_repaint_schedule(2, 2, 6) == [4, 4, 2]
+    with pytest.raises(AssertionError):
+        ddpm.inpaint(mol, fixed.cuda(), jump_length=2, num_timesteps=6, return_frames=2)
+    if not selfcond:
+        # the whole-model entry (generate_molecules(ddpm_mode="inpainting"), qm9_mol_gen_ddpm.py:1130-1181): zero molecule, first node fixed,
+        # every molecule moved back to the given centre of mass (the origin)
+        model = pkg.QM9MoleculeGenerationDDPM(**cfgs)
+        model.ddpm.dynamics_network.load_state_dict(W)
+        model = model.cuda()
+        mols = model.generate_molecules(ddpm_mode="inpainting", num_samples=3, num_nodes=torch.tensor([5, 9, 3]), num_timesteps=4, num_resamplings=2,
+                                        jump_length=2)
+        assert [len(m[0]) for m in mols] == [5, 9, 3]
+        for pos, at, chg in mols:
+            assert torch.isfinite(pos).all() and pos.mean(0).abs().max().item() <= 1e-3 * max(1.0, pos.abs().max().item())
+            assert at.min() >= 0 and at.max() < d["num_atom_types"]
+        with pytest.raises(NotImplementedError):
+            model.generate_molecules(ddpm_mode="conditional", num_samples=1)
+
+
 def test_cabi_error_paths():
     """Every misuse of the C ABI returns a negative status with a message (no exception, no crash, no silent fallback)."""
     native = pkg._native

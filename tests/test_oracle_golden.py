@@ -179,6 +179,42 @@ def test_mol_gen_optimize_small(golden_dir):
     assert (g["a_out"][:, :3] - g["b_out"][:, :3]).abs().max().item() > 1e-3
 
 
+def test_repaint_schedule_matches_reference(golden_dir):
+    """get_repaint_schedule (variational_diffusion.py:1548-1578) on a grid of 192 (resamplings, jump_length, T) triples."""
+    import json
+    cases = json.load(open(os.path.join(golden_dir, "repaint_schedule.json")))
+    assert len(cases) == 192
+    for c in cases:
+        assert O.get_repaint_schedule(c["resamplings"], c["jump_length"], c["num_timesteps"]) == c["schedule"], c
+
+
+def test_inpaint_small(golden_dir):
+    """RePaint inpainting loop (variational_diffusion.py:1582-1789) vs the reference run with its two crashing tokens repaired in memory
+    (tests/golden/make_inpaint_golden.py): jump_length 2, chain frames with jump_length 1, and the self-conditioning variant."""
+    g = load(golden_dir, "inpaint_small_qm9")
+    for tag, wfile, runs in (("plain", "sampler_small_qm9", ("jump", "frames")), ("sc", "sampler_small_qm9sc", ("jump",))):
+        P = weights_of(load(golden_dir, wfile))
+        assert torch.equal(P["gcp_embedding.edge_embedding.vector_down.weight"], g[f"{tag}_weight_check"])
+        cfg = cfg_for("qm9", O.infer_num_layers(P))
+        cfg.self_condition = tag == "sc"
+        for run in runs:
+            r, j, T, frames = (int(v) for v in g[f"{tag}_{run}_kw"])
+            tape = O.TapeNoise(int(g["seed"]))
+            draws = [0]
+            def noise(n, k, dtype=torch.float32, _t=tape, _d=draws):
+                _d[0] += 1
+                return _t(n, k, dtype)
+            out = O.inpaint(P, cfg, g["x"], g["one_hot"], g["charges"], g["num_nodes"], g["fixed"], noise, num_resamplings=r, jump_length=j,
+                            return_frames=frames, num_timesteps=T)
+            ref = g[f"{tag}_{run}_out"]
+            assert out.shape == ref.shape and draws[0] // 2 == int(g[f"{tag}_{run}_draws"])
+            last, lref = (out, ref) if frames == 1 else (out[0], ref[0])
+            scale = max(1.0, ref.abs().max().item())
+            assert (last[:, :3] - lref[:, :3]).abs().max().item() <= 1e-4 * scale and torch.equal(last[:, 3:], lref[:, 3:])
+            if frames > 1:
+                assert (out[1:] - ref[1:]).abs().max().item() <= 1e-4 * scale and ref[1:].abs().max().item() > 0
+
+
 @pytest.mark.parametrize("case", CASES)
 def test_dynamics_full_width(golden_dir, case):
     """Full-width production architecture; weights re-created from the seed recipe (tests/synth.py)."""
