@@ -75,6 +75,7 @@ struct gcdm_handle {
     // 100-molecule evaluation batches; QM9 molecules have <= 29 atoms, so a row is cut into at most 2 pieces and the result stays
     // bit-reproducible), everything else 64 (GEOM: +-1 %, and rows of 44+ edges would be cut into >= 3 atomically added pieces)
     int tile() const { return edge_tile ? edge_tile : ((mfma_x3 && Se == 64) ? 32 : 64); }
+    bool x3_weights_ok = true;       // every GEMM weight fits the split-precision images (|W| < 255); else mfma_mode 1 is refused
     int mfma_x3 = 1;                 // 1: split-precision f16 x3 edge kernel (default; env GCDM_MFMA=f16x3|f32), 0: fp32 MFMA
     bool attr_set = false;
     // profiling (HIP events around the k_edge_msg launches of one forward)
@@ -131,7 +132,9 @@ std::vector<float> pack_mfma(Dense& W) {
 // Packed split-precision weights carry a factor 2^8 (exact): the kernels keep every activation image pre-multiplied by 2^-8 (X3_PRE,
 // gcdm_edge_x3.hip.h), which moves the f16 overflow bound of the activations from 6.5e4 to 1.7e7 at no cost in accuracy (f16
 // denormals are honoured by the MFMA, tools/mfma_denorm.hip); weights stay representable while |W| < 255.
+thread_local float g_split_absmax = 0.f;      // largest |W| seen by split_f16 since gcdm_finalize_weights reset it (NaN counts as too large)
 void split_f16(float x, uint16_t& hi, uint16_t& lo) {
+    g_split_absmax = (fabsf(x) <= g_split_absmax) ? g_split_absmax : (x == x ? fabsf(x) : INFINITY);
     x *= 256.0f;
     const _Float16 h = (_Float16)x;
     const _Float16 l = (_Float16)((x - (float)h) * 2048.0f);
@@ -399,6 +402,7 @@ int gcdm_finalize_weights(gcdm_handle* h) {
     HIP_OK(h, hipSetDevice(h->cfg.device));
     const int S = GCDM_S, V = GCDM_V, Se = h->Se, Ve = h->Ve, H0 = h->H0, L = h->L;
     Pool pool;
+    g_split_absmax = 0.f;
     // ---- edge embedding (1,1) -> (Se,Ve), bottleneck 1: H = max(1, Ve) = Ve ------------------------
     size_t o_ws, o_bs, o_wd, o_wdf, o_kap, o_wg, o_bg, o_wd1, o_wdf1, o_kap1;
     {
@@ -565,6 +569,9 @@ int gcdm_finalize_weights(gcdm_handle* h) {
             return -1;
         h->attr_set = true;
     }
+    // split-precision images hold 2^8 W in f16: a checkpoint with a matrix weight of 255 or more (or NaN) cannot use them -> fp32 MFMA only
+    h->x3_weights_ok = g_split_absmax < 255.0f;
+    if (!h->x3_weights_ok) h->mfma_x3 = 0;
     h->finalized = true;
     h->host_w.clear();
     return 0;
@@ -584,7 +591,8 @@ int gcdm_plan_batch(gcdm_handle* h, int32_t B, const int32_t* nn) {
         max_n = std::max(max_n, (int)nn[b]);
     }
     if (E >= (int64_t)1 << 31) return fail(h, "gcdm_plan_batch: too many edges");
-    if (max_n > 4096) return fail(h, "gcdm_plan_batch: molecule too large");
+    // k_sample / k_prep stage one molecule in LDS (max_n * (3 + F) floats, 64 KB without an opt-in attribute)
+    if (max_n > 4096 || (size_t)max_n * h->D * sizeof(float) > 65536) return fail(h, "gcdm_plan_batch: molecule too large (max_n * (3 + F) floats must fit 64 KB of LDS)");
     const int N = noff[B];
     std::vector<int> erow(E), ecol(E), ncnt(N);
     int64_t p = 0;
@@ -948,6 +956,7 @@ int gcdm_set_option(gcdm_handle* h, const char* name, int32_t value) {
     const std::string k(name);
     if (k == "mfma_mode") {                 // 0: fp32 MFMA, 1: split-precision f16 x3 (fp32-equivalent, 5.3x the matrix rate)
         if (value != 0 && value != 1) return fail(h, "gcdm_set_option(mfma_mode): 0 or 1");
+        if (value == 1 && !h->x3_weights_ok) return fail(h, "gcdm_set_option(mfma_mode): a weight of this model is >= 255 in magnitude, outside the split-precision images; only mode 0 (fp32 MFMA) is available");
         h->mfma_x3 = value;
         return 0;
     }

@@ -16,7 +16,10 @@
  *   - the caller owns every buffer it passes; the library owns only its handle, packed weights and workspace;
  *   - pointers documented "device" are HIP device pointers valid on the handle's device; "host" are host pointers;
  *   - all device work is enqueued on the `stream` argument (a hipStream_t passed as void*) and is asynchronous;
- *   - one handle per device; a handle is not thread-safe;
+ *   - a handle belongs to one device (GcdmConfig.device) and is not thread-safe; any number of handles may share a device (each owns
+ *     its packed weights and workspace -- that is how several batches or slices run concurrently on separate streams);
+ *   - calls that take a `stream` do not switch devices: the handle's device must be the calling thread's current HIP device
+ *     (gcdm_create / gcdm_finalize_weights / gcdm_plan_batch / gcdm_profile_enable do call hipSetDevice);
  *   - all tensors are fp32, row-major, node-major ([N, C]) unless stated otherwise.
  */
 #ifndef GCDM_HIP_H
@@ -166,6 +169,8 @@ int gcdm_debug_set_layer_limit(gcdm_handle* h, int32_t num_layers_to_run);
 /* Options.  "mfma_mode": 1 (default; env GCDM_MFMA=f16x3) evaluates the per-edge contractions with three f16 MFMAs per product
  * block on operands split as x = hi + 2^-11 lo' (fp32-equivalent accuracy; raises GCDM_FLAG_F16_RANGE if an
  * activation exceeds 1.5e7, in which case the caller must re-run with mode 0); 0 (env GCDM_MFMA=f32) uses fp32 MFMA throughout.
+ * A model with a matrix weight of magnitude >= 255 (the split images hold 2^8 W in f16) is switched to mode 0 by gcdm_finalize_weights and
+ * setting mode 1 on it fails.
  * "edge_tile": edges per workgroup of the edge-message kernels: 64 (one 8-wave workgroup per CU), 32 (two 4-wave workgroups per CU) or
  * 0 = automatic (default; env GCDM_EDGE_TILE): 32 for the split-precision kernel at the QM9 edge width (rows of <= 32 edges), else 64
  * -- DESIGN.md 3.4.

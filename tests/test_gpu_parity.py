@@ -146,6 +146,26 @@ def test_f16_range_flag_and_fp32_fallback():
     del raw
 
 
+def test_weights_outside_split_range_use_fp32_mfma():
+    """A checkpoint with a matrix weight >= 255 does not fit the split-precision images (2^8 W in f16): gcdm_finalize_weights switches the
+    handle to fp32 MFMA, refuses mode 1, and the forward still matches the oracle."""
+    d = _dims("qm9")
+    cfgs = pkg.default_cfgs("qm9", ())
+    net = pkg.GCPNetDynamics(**cfgs)
+    W = synth.make_weights(synth.dynamics_shapes(d["S"], d["V"], d["Se"], d["Ve"], d["L"], synth.dims_h_in(d)), seed=23, scale_2d=0.5)
+    W["interaction_layers.0.interaction.message_fusion.1.scalar_out.weight"][3, 5] = 300.0
+    net.load_state_dict(W)
+    net = net.cuda()
+    net._ensure_handle(torch.device("cuda"))
+    assert net.mfma_mode == 0
+    with pytest.raises(pkg._native.NativeError, match="255"):
+        net.set_mfma_mode(1)
+    xh, t, bi, nn_, _ = synth.make_inputs([19, 7, 30], synth.dims_feat(d), seed=5)
+    ref = O.dynamics_forward(W, _ocfg("qm9"), xh, t, bi, None, None)
+    out = _fwd(net, xh, t, bi)
+    assert torch.isfinite(out).all() and (out - ref).abs().max().item() <= TOL * max(1.0, ref.abs().max().item())
+
+
 def test_forward_input_validation():
     net, _, _ = _net("qm9")
     d = _dims("qm9")
