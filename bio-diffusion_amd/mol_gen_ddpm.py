@@ -157,7 +157,25 @@ class _MoleculeGenerationDDPM(nn.Module):
         all-zero molecule with the nodes of ``node_mask`` fixed (default: the first node of the batch), then every generated molecule is
         moved back to the given one's centre of mass."""
         if sample_chain:
-            raise NotImplementedError("chains (sample_chain=True) are not built")
+            assert num_samples == 1, "Chain sampling is only supported for single-molecule batches."
+            if ddpm_mode != "unconditional":
+                raise NotImplementedError("chains are built for ddpm_mode='unconditional' only")
+            # every step is a frame (return_frames = num_timesteps, :1122), frames put in generation order (reverse_tensor, :1186)
+            T = self.ddpm.T if num_timesteps is None else num_timesteps
+            if num_nodes is None:
+                num_nodes = self.ddpm.num_nodes_distribution.sample(num_samples)
+            if self.condition_on_context and context is None:
+                if self.props_distr is None:
+                    raise ValueError("context required (no props_distr attached)")
+                context = self.props_distr.sample_batch(num_nodes)
+            frames, _, _ = self.ddpm.mol_gen_sample(num_samples=1, num_nodes=num_nodes, device=self.device, return_frames=T, num_timesteps=T,
+                                                    node_mask=node_mask, context=context if self.condition_on_context else None, **kw)
+            frames = frames.reshape(T, -1, frames.shape[-1]).flip(0)
+            oh = frames[:, :, self.num_x_dims:-1] if self.include_charges else frames[:, :, self.num_x_dims:]
+            mols = []
+            for pos, at in zip(frames[:, :, : self.num_x_dims].cpu(), oh.argmax(-1).cpu()):
+                mols.append(molecule_builder(pos, at, self.dataset_info) if molecule_builder is not None else (pos, at, None))
+            return mols
         if ddpm_mode == "unconditional":
             x, one_hot, charges, batch_index = self.sample(num_samples, num_nodes=num_nodes, node_mask=node_mask, context=context,
                                                            num_timesteps=num_timesteps, **kw)
@@ -212,6 +230,49 @@ class _MoleculeGenerationDDPM(nn.Module):
         out_dir = str(sampling_output_dir) if sampling_output_dir is not None else os.path.join("sampling_output", "epoch_0")
         save_xyz_file(path=out_dir + "/", positions=x, one_hot=one_hot, charges=charges, dataset_info=self.dataset_info,
                       id_from=id_from, name=name, batch_index=batch_index)
+
+    @torch.inference_mode()
+    def sample_chain_and_save(self, keep_frames: int, node_mask: Optional[torch.Tensor] = None, context: Optional[torch.Tensor] = None,
+                              id_from: int = 0, num_tries: int = 1, name: str = os.sep + "chain", verbose: bool = True,
+                              sampling_output_dir: Optional[str] = None, num_timesteps: Optional[int] = None, **kw) -> bool:
+        """qm9_mol_gen_ddpm.py:957-1060 without the matplotlib / wandb visualisation: one molecule sampled with `keep_frames` intermediate
+        frames (up to `num_tries` times, until the final molecule is stable -- checked on the device), frames put in generation order, the
+        last one repeated 10 times, one XYZ file per frame.  Returns whether the molecule shown is stable."""
+        if "QM9" in str(self.dataset_info.get("name", "")).upper():
+            num_nodes = torch.tensor([19], dtype=torch.long)
+        else:
+            num_nodes = self.ddpm.num_nodes_distribution.sample(1)
+            assert int(num_nodes.max()) <= self.dataset_info.get("max_n_nodes", int(num_nodes.max()))
+        if self.condition_on_context:
+            if context is None:
+                if self.props_distr is None:
+                    raise ValueError("context required (no props_distr attached)")
+                context = self.props_distr.sample_batch(num_nodes)
+        else:
+            context = None
+        x = one_hot = charges = None
+        mol_stable = False
+        for i in range(num_tries):
+            chain, _, _ = self.ddpm.mol_gen_sample(num_samples=1, num_nodes=num_nodes, node_mask=node_mask, context=context,
+                                                   return_frames=keep_frames, device=self.device, num_timesteps=num_timesteps,
+                                                   seed=kw.get("seed", 1234) + i, **{k: v for k, v in kw.items() if k != "seed"})
+            chain = chain.reshape(keep_frames, -1, chain.shape[-1]).flip(0)
+            chain = torch.cat([chain, chain[-1:].repeat(10, 1, 1)], dim=0)           # repeat the last frame to see the final sample better
+            oh_last = chain[-1, :, self.num_x_dims:-1] if self.include_charges else chain[-1, :, self.num_x_dims:]
+            res = check_molecular_stability_batch(chain[-1].contiguous(), oh_last.argmax(-1), num_nodes, self.dataset_info)
+            mol_stable = bool(int(res[0, 0]))
+            x = chain[:, :, : self.num_x_dims]
+            oh = chain[:, :, self.num_x_dims:-1] if self.include_charges else chain[:, :, self.num_x_dims:]
+            one_hot = torch.nn.functional.one_hot(oh.argmax(-1), num_classes=self.num_atom_types)
+            charges = torch.round(chain[:, :, -1:]).long() if self.include_charges else torch.zeros(0, dtype=torch.long, device=self.device)
+            if mol_stable:
+                break
+        F_, n = x.shape[0], x.shape[1]
+        out_dir = os.path.join(str(sampling_output_dir) if sampling_output_dir is not None else os.path.join("sampling_output", "epoch_0"), "chain")
+        save_xyz_file(path=out_dir, positions=x.reshape(-1, x.shape[-1]), one_hot=one_hot.reshape(-1, one_hot.shape[-1]),
+                      charges=charges.reshape(-1, 1) if charges.numel() > 0 else charges, dataset_info=self.dataset_info, id_from=id_from, name=name,
+                      batch_index=torch.arange(F_).repeat_interleave(n))
+        return mol_stable
 
     @torch.inference_mode()
     def optimize(self, samples: List[Tuple[torch.Tensor, torch.Tensor]], num_timesteps: int, num_nodes: torch.Tensor,

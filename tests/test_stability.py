@@ -206,3 +206,38 @@ def test_sample_sharded_single_rank_equals_direct_call():
     b, _, _ = model.ddpm.mol_gen_sample(num_samples=len(nn_), num_nodes=nn_, device="cuda", num_timesteps=6, seed=5, lanes=2)
     assert torch.equal(a, b) and torch.equal(nn_out.cpu(), nn_.long())
     model.ddpm.release_lanes()
+
+
+@pytest.mark.gpu
+def test_chain_sampling_entry_points(tmp_path):
+    """sample_chain_and_save (qm9_mol_gen_ddpm.py:957-1060) and generate_molecules(sample_chain=True) (:1119-1128, 1183-1207): frames in generation
+    order, the last one repeated 10 times, one XYZ file per frame; the frames are those of mol_gen_sample(return_frames=...) (parity:
+    tests/test_gpu_parity.py::test_sampling_with_chain_frames)."""
+    cfgs = pkg.default_cfgs("qm9")
+    cfgs["diffusion_cfg"]["num_timesteps"] = 8
+    torch.manual_seed(0)
+    model = pkg.QM9MoleculeGenerationDDPM(**cfgs)
+    with torch.no_grad():
+        for p in model.ddpm.dynamics_network.parameters():
+            if p.dim() == 2:
+                p.mul_(0.25)
+    model = model.cuda()
+    stable = model.sample_chain_and_save(keep_frames=4, num_tries=1, sampling_output_dir=str(tmp_path), seed=3)
+    files = sorted(os.listdir(tmp_path / "chain"))
+    assert files == ["chain_%03d.xyz" % i for i in range(14)] and isinstance(stable, bool)
+    texts = [open(tmp_path / "chain" / f).read() for f in files]
+    assert all(t.startswith("19\n\n") and len(t.splitlines()) == 21 for t in texts)
+    assert len(set(texts[:4])) == 4 and len(set(texts[3:])) == 1               # 4 distinct frames, then the final one 11 times
+    want, _, _ = model.ddpm.mol_gen_sample(num_samples=1, num_nodes=torch.tensor([19]), device="cuda", return_frames=4, seed=3)
+    last = want[0].cpu()
+    lines = texts[-1].splitlines()[2:]
+    dec = pkg.dataset_info("qm9")["atom_decoder"]
+    for i, ln in enumerate(lines):
+        sym, xs, ys, zs = ln.split()
+        assert sym == dec[int(last[i, 3:8].argmax())] and abs(float(xs) - last[i, 0].item()) <= 1e-6 * max(1.0, abs(last[i, 0].item()))
+    mols = model.generate_molecules(ddpm_mode="unconditional", num_samples=1, num_nodes=torch.tensor([7]), sample_chain=True, seed=3)
+    assert len(mols) == 8 and all(m[0].shape == (7, 3) and m[1].shape == (7,) for m in mols)
+    fr, _, _ = model.ddpm.mol_gen_sample(num_samples=1, num_nodes=torch.tensor([7]), device="cuda", return_frames=8, seed=3)
+    assert torch.equal(mols[-1][0], fr[0, :, :3].cpu()) and torch.equal(mols[0][0], fr[7, :, :3].cpu())
+    with pytest.raises(AssertionError):
+        model.generate_molecules(ddpm_mode="unconditional", num_samples=2, sample_chain=True)
