@@ -13,7 +13,7 @@ through the alias module ``bio_diffusion_amd`` at the repository root.
 from .config import AttrDict, default_cfgs, load_cfg_tree, dataset_info          # noqa: F401
 from .gcpnet import GCP2, GCPNetDynamics                                        # noqa: F401
 from .variational_diffusion import EquivariantVariationalDiffusion, PredefinedNoiseSchedule, NumNodesDistribution  # noqa: F401
-from .mol_gen_ddpm import QM9MoleculeGenerationDDPM, GEOMMoleculeGenerationDDPM  # noqa: F401
+from .mol_gen_ddpm import QM9MoleculeGenerationDDPM, GEOMMoleculeGenerationDDPM, sample_sweep_conditionally  # noqa: F401
 from . import _native, stability, xyz                                           # noqa: F401
 from .xyz import save_xyz_file, write_xyz_file                                  # noqa: F401
 from .stability import check_molecular_stability, check_molecular_stability_batch, get_bond_length_arrays, CategoricalDistribution  # noqa: F401

@@ -367,3 +367,18 @@ class QM9MoleculeGenerationDDPM(_MoleculeGenerationDDPM):
 class GEOMMoleculeGenerationDDPM(_MoleculeGenerationDDPM):
     """``_target_`` stand-in for src.models.geom_mol_gen_ddpm.GEOMMoleculeGenerationDDPM."""
     _DATASETS = {"GEOM": "geom"}
+
+
+def sample_sweep_conditionally(model: Any, props_distr: Any, num_nodes: int = 19, num_frames: int = 100
+                               ) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor]:
+    """src/models/__init__.py:200-226: `num_frames` molecules of `num_nodes` atoms whose (normalised) property context sweeps linearly from the
+    smallest to the largest value seen for that size, all drawn with the same noise (`fix_noise=True`: option "fix_noise" of the library)."""
+    num_nodes_ = torch.tensor([num_nodes] * num_frames, device=model.device)
+    cols = []
+    for key in props_distr.distributions:
+        lo, hi = props_distr.distributions[key][num_nodes]["params"]
+        mean, mad = props_distr.normalizer[key]["mean"], props_distr.normalizer[key]["mad"]
+        lo_n, hi_n = float((torch.as_tensor(lo) - mean) / mad), float((torch.as_tensor(hi) - mean) / mad)
+        cols.append(torch.tensor(np.linspace(lo_n, hi_n, num_frames)).unsqueeze(1))
+    context = torch.cat(cols, dim=-1).float().to(model.device)
+    return model.sample(num_samples=num_frames, num_nodes=num_nodes_, context=context, fix_noise=True)
