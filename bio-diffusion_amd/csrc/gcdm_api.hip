@@ -74,9 +74,10 @@ struct gcdm_handle {
     // automatic choice, measured on MI355X: split-precision kernel at the QM9 edge width -> 32 (+3..5 %; +12 % on
     // 100-molecule evaluation batches; QM9 molecules have <= 29 atoms, so a row is cut into at most 2 pieces and the result stays
     // bit-reproducible), everything else 64 (GEOM: +-1 %, and rows of 44+ edges would be cut into >= 3 atomically added pieces)
-    int tile() const { return edge_tile ? edge_tile : ((mfma_x3 && Se == 64) ? 32 : 64); }
+    int tile() const { return edge_tile ? edge_tile : ((use_x3() && Se == 64) ? 32 : 64); }
     bool x3_weights_ok = true;       // every GEMM weight fits the split-precision images (|W| < 255); else mfma_mode 1 is refused
-    int mfma_x3 = 1;                 // 1: split-precision f16 x3 edge kernel (default; env GCDM_MFMA=f16x3|f32), 0: fp32 MFMA
+    int mfma_x3 = 1;                 // requested mode -- 1: split-precision f16 x3 kernels (default; env GCDM_MFMA=f16x3|f32), 0: fp32 MFMA
+    bool use_x3() const { return mfma_x3 && x3_weights_ok; }   // effective mode: models whose weights do not fit the split images run fp32 MFMA
     bool attr_set = false;
     // profiling (HIP events around the k_edge_msg launches of one forward)
     bool profile = false;
@@ -571,7 +572,6 @@ int gcdm_finalize_weights(gcdm_handle* h) {
     }
     // split-precision images hold 2^8 W in f16: a checkpoint with a matrix weight of 255 or more (or NaN) cannot use them -> fp32 MFMA only
     h->x3_weights_ok = g_split_absmax < 255.0f;
-    if (!h->x3_weights_ok) h->mfma_x3 = 0;
     h->finalized = true;
     h->host_w.clear();
     return 0;
@@ -699,7 +699,7 @@ int gcdm_forward_sc(gcdm_handle* h, const float* xh, const float* xh_sc, const f
     NodeX3Args nx{};
     bool node_kb_ok = true;
     auto launch_node = [&](bool embed, int next_layer, const LayerDev* cur) {
-        if (h->mfma_x3) {
+        if (h->use_x3()) {
             nx.base = na;
             nx.emb = h->embx; nx.proj = h->projx;
             if (cur) { nx.ff = cur->ffx; nx.pos = cur->posx; }
@@ -735,7 +735,7 @@ int gcdm_forward_sc(gcdm_handle* h, const float* xh, const float* xh_sc, const f
         ma.wa = d.wa; ma.ba = d.ba;
         ma.prof = h->profile_phases ? h->PROF : nullptr;
         if (h->profile) HIP_OK(h, hipEventRecord(h->ev[2 * l], st));
-        if (h->mfma_x3) {
+        if (h->use_x3()) {
             EdgeMsgX3Args xa{};
             xa.base = ma;
             xa.w0H = d.w0H; xa.w0L = d.w0L; xa.KB0 = d.KB0; xa.wg0H = d.wg0H; xa.wg0L = d.wg0L; xa.KB = d.KB;
@@ -976,7 +976,7 @@ int gcdm_set_option(gcdm_handle* h, const char* name, int32_t value) {
 int gcdm_get_option(const gcdm_handle* h, const char* name) {
     if (!h || !name) return -1;
     const std::string k(name);
-    if (k == "mfma_mode") return h->mfma_x3;
+    if (k == "mfma_mode") return h->use_x3() ? 1 : 0;
     if (k == "edge_tile") return h->tile();
     if (k == "cog_fix") return h->cog_fix;
     if (k == "fix_noise") return h->fix_noise;

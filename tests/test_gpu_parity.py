@@ -157,6 +157,7 @@ def test_weights_outside_split_range_use_fp32_mfma():
     net.load_state_dict(W)
     net = net.cuda()
     net._ensure_handle(torch.device("cuda"))
+    net.sync_weights()
     assert net.mfma_mode == 0
     with pytest.raises(pkg._native.NativeError, match="255"):
         net.set_mfma_mode(1)
@@ -164,6 +165,11 @@ def test_weights_outside_split_range_use_fp32_mfma():
     ref = O.dynamics_forward(W, _ocfg("qm9"), xh, t, bi, None, None)
     out = _fwd(net, xh, t, bi)
     assert torch.isfinite(out).all() and (out - ref).abs().max().item() <= TOL * max(1.0, ref.abs().max().item())
+    # back to ordinary weights: the default mode returns
+    W["interaction_layers.0.interaction.message_fusion.1.scalar_out.weight"][3, 5] = 0.01
+    net.load_state_dict(W)
+    net.sync_weights(force=True)
+    assert net.mfma_mode == 1
 
 
 def test_forward_input_validation():
