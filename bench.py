@@ -155,9 +155,10 @@ def main():
         # "nccl" is RCCL on ROCm.  GCDM_BENCH_SINGLE_GPU_TEST=1 (test hook): all ranks share GPU 0 over gloo, to exercise the multi-rank
         # control flow on a one-GPU box; never used for reported numbers.
         single_gpu_test = os.environ.get("GCDM_BENCH_SINGLE_GPU_TEST") == "1"
-        dist.init_process_group("gloo" if single_gpu_test else "nccl", rank=rank, world_size=world)
         if single_gpu_test:
             local_rank = 0
+        torch.cuda.set_device(local_rank)          # before the process group: RCCL binds its communicator to the current device
+        dist.init_process_group("gloo" if single_gpu_test else "nccl", rank=rank, world_size=world)
         assert world == args.gpus, f"launch with --nproc-per-node {args.gpus}"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
