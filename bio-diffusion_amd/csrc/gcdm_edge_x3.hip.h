@@ -122,76 +122,6 @@ __device__ __forceinline__ void tile_gemm_x3(f32x16 (&am)[MT][NT], f32x16 (&al)[
 }
 
 // gate partial from registers: contraction over the channels this wave holds (two 16-deep blocks per M-tile)
-// Two M-tiles of one wave run ONE AFTER THE OTHER (compile-time k-block count, fully unrolled), so that VALU work on the first tile's
-// finished accumulators -- `fin(r)`, one small independent piece per k-block -- issues in the MFMA shadow of the second tile's loop
-// (on gfx950 about half of a 32x32x16 MFMA's 32 clocks can host VALU issue of the SAME wave, none of another wave's: DESIGN.md 3.4).
-// Per accumulator the operations and their order are those of tile_gemm_x3, so results are bit-identical; the price is one more pair
-// of ds_read_b128 per k-block (the B operand is read once per tile instead of once for both).
-template <int NT, int PD, int KBC, typename Fin>
-__device__ __forceinline__ void tile_gemm_x3_seq2(f32x16 (&am)[2][NT], f32x16 (&al)[2][NT], X3Ring<2, PD>& ring, const h8* __restrict__ wH,
-                                                  const h8* __restrict__ wL, const h8* xh8, const h8* xl8, int TP, int lane, Fin&& fin) {
-    constexpr int R = PD + 1;
-    constexpr int wstride = KBC * 64;
-    const int boff = (lane >> 5) * TP + (lane & 31);
-#pragma unroll
-    for (int m = 0; m < 2; ++m) {
-        const h8* wh = wH + m * wstride + lane + PD * 64;
-        const h8* wl = wL + m * wstride + lane + PD * 64;
-        const h8* sh = xh8 + boff;
-        const h8* sl = xl8 + boff;
-        h8 bh[2][NT], bl[2][NT];
-#pragma unroll
-        for (int n = 0; n < NT; ++n) { bh[0][n] = sh[n * 32]; bl[0][n] = sl[n * 32]; }
-#ifdef GCDM_X3_PIPE_AB
-        f32x16 alb[NT];
-#pragma unroll
-        for (int n = 0; n < NT; ++n)
-#pragma unroll
-            for (int q = 0; q < 16; ++q) alb[n][q] = 0.f;
-#endif
-#pragma unroll
-        for (int r = 0; r < KBC; ++r) {
-            ring.ah[(r + PD) % R][m] = wh[0];
-            ring.alo[(r + PD) % R][m] = wl[0];
-            wh += 64;
-            wl += 64;
-            sh += 2 * TP;
-            sl += 2 * TP;
-#pragma unroll
-            for (int n = 0; n < NT; ++n) { bh[(r + 1) & 1][n] = sh[n * 32]; bl[(r + 1) & 1][n] = sl[n * 32]; }
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int n = 0; n < NT; ++n) am[m][n] = MFMA16(ring.ah[r % R][m], bh[r & 1][n], am[m][n]);
-#pragma unroll
-            for (int n = 0; n < NT; ++n) al[m][n] = MFMA16(ring.ah[r % R][m], bl[r & 1][n], al[m][n]);
-#ifdef GCDM_X3_PIPE_AB
-#pragma unroll
-            for (int n = 0; n < NT; ++n) alb[n] = MFMA16(ring.alo[r % R][m], bh[r & 1][n], alb[n]);
-#else
-#pragma unroll
-            for (int n = 0; n < NT; ++n) al[m][n] = MFMA16(ring.alo[r % R][m], bh[r & 1][n], al[m][n]);
-#endif
-            if (m == 1) {
-                fin(r);
-                // one MFMA, then two VALU / transcendental instructions of fin(r), three times
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x402, 2, 0);
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x402, 2, 0);
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x402, 2, 0);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-        }
-#ifdef GCDM_X3_PIPE_AB
-#pragma unroll
-        for (int n = 0; n < NT; ++n)
-#pragma unroll
-            for (int q = 0; q < 16; ++q) al[m][n][q] += alb[n][q];
-#endif
-    }
-}
-
 template <int MT, int NT>
 __device__ __forceinline__ void gate_partial_x3(f32x16 (&gm)[NT], f32x16 (&gl)[NT], const f32x16 (&act)[MT][NT], const h8* __restrict__ wgH,
                                                 const h8* __restrict__ wgL, int mt0, int lane) {
@@ -375,7 +305,11 @@ __global__ __launch_bounds__(ET * 8) __attribute__((amdgpu_waves_per_eu(2, 2))) 
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int e = (ET == 64) ? lane : (tid & (ET - 1)), part = (ET == 64) ? wave : (tid / ET);
     const int E = a.E, N = a.N;
-    const int e0 = blockIdx.x * ET;
+    // XCD-aware tile order: workgroup b runs on XCD b % 8 (round-robin dispatch), so XCD x takes the x-th contiguous eighth of the tiles and
+    // the node rows its tiles gather (PQ4 / VDI / VDJ of consecutive molecules) stay in that XCD's own L2.  Same tiles, same results;
+    // measured -0.5 % (QM9) / -0.2 % (GEOM) step time (tools/ab_variant.py, same box, alternating runs).
+    const int G_ = gridDim.x, xcd_ = blockIdx.x & 7, base_ = G_ >> 3, rem_ = G_ & 7;
+    const int e0 = (xcd_ * base_ + min(xcd_, rem_) + (int)(blockIdx.x >> 3)) * ET;
     const int nvalid = min(ET, E - e0);
     const int eid = min(e0 + e, E - 1);
     const int ni = a.EROW[eid], nj = a.ECOL[eid];
@@ -573,39 +507,6 @@ __global__ __launch_bounds__(ET * 8) __attribute__((amdgpu_waves_per_eu(2, 2))) 
 #pragma unroll
                 for (int r = 0; r < 16; ++r) al2[m][n][r] = 0.f;
         if (k == 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); STAMP(21); }
-#ifdef GCDM_X3_PIPE_SILU
-        if constexpr (MT == 2) {          // 32-edge tiles: SiLU of the first M-tile rides in the MFMA shadow of the second tile's K loop
-            tile_gemm_x3_seq2<NT, PD, 18>(am, al2, ring, ax.wH[k] + (size_t)mt0 * 18 * 64, ax.wL[k] + (size_t)mt0 * 18 * 64, xh8, xl8, ETP, lane, [&](int r) {
-#ifndef GCDM_X3_SEQ_ONLY
-                if (r < 16)
-#else
-                if (false)
-#endif
-                {
-#pragma unroll
-                    for (int n = 0; n < NT; ++n) {
-                        float v = fast_silu(am[0][n][r] + al2[0][n][r] * X3_INV_SCALE);
-                        asm volatile("" : "+v"(v));      // pins the value inside this k-block (IR-level sinking would move it behind the loop)
-                        am[0][n][r] = v;
-                    }
-                }
-            });
-            if (k == 0) STAMP(22);
-            if (k < 2) x3_prefetch<MT, PD>(ring, ax.wH[k + 1] + (size_t)mt0 * 18 * 64, ax.wL[k + 1] + (size_t)mt0 * 18 * 64, 18, lane);
-            if (k == 0) STAMP(12);
-#ifdef GCDM_X3_SEQ_ONLY
-#pragma unroll
-            for (int n = 0; n < NT; ++n)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) am[0][n][r] = fast_silu(am[0][n][r] + al2[0][n][r] * X3_INV_SCALE);
-#endif
-#pragma unroll
-            for (int n = 0; n < NT; ++n)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) am[MT - 1][n][r] = fast_silu(am[MT - 1][n][r] + al2[MT - 1][n][r] * X3_INV_SCALE);
-        } else
-#endif
-        {
         tile_gemm_x3<MT, NT, PD, 18>(am, al2, ring, ax.wH[k] + (size_t)mt0 * 18 * 64, ax.wL[k] + (size_t)mt0 * 18 * 64, 18, xh8, xl8, ETP, lane);
         if (k == 0) STAMP(22);
         if (k < 2) x3_prefetch<MT, PD>(ring, ax.wH[k + 1] + (size_t)mt0 * 18 * 64, ax.wL[k + 1] + (size_t)mt0 * 18 * 64, 18, lane);
@@ -616,7 +517,6 @@ __global__ __launch_bounds__(ET * 8) __attribute__((amdgpu_waves_per_eu(2, 2))) 
             for (int n = 0; n < NT; ++n)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) am[m][n][r] = fast_silu(am[m][n][r] + al2[m][n][r] * X3_INV_SCALE);
-        }
         if (k == 0) STAMP(13);
 #pragma unroll
         for (int n = 0; n < NT; ++n)
