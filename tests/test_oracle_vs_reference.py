@@ -1,0 +1,77 @@
+"""Live pin of the CPU oracle: when the reference checkout is present (build container only; it never travels to the GPU box) the oracle is
+compared with the imported, unmodified reference on FRESH random weights and inputs -- i.e. on cases that are not among the committed golden
+vectors.  Skipped elsewhere.  CPU only."""
+import os
+import sys
+
+import pytest
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path[:0] = [os.path.join(HERE, "golden"), HERE, os.path.dirname(HERE)]
+import ref_harness as rh  # noqa: E402
+import synth  # noqa: E402
+from oracle import gcdm_oracle as O  # noqa: E402
+
+pytestmark = pytest.mark.skipif(not rh.reference_available(), reason="reference checkout not present")
+
+CASES = {"qm9": ("qm9", ()), "qm9cond": ("qm9", ("alpha",)), "geom": ("geom", ())}
+
+
+def _ocfg(case, layers):
+    d = synth.DATASET_DIMS[case]
+    return O.OracleConfig(num_atom_types=d["num_atom_types"], include_charges=d["include_charges"], num_context=d["n_ctx"], num_layers=layers,
+                          norm_values=d["norm_values"])
+
+
+def _reference(case, seed, self_condition=False):
+    ds, cond = CASES[case]
+    cfgs = rh.shrink_cfgs(rh.load_reference_cfgs(ds, cond))
+    cfgs["diffusion_cfg"]["self_condition"] = self_condition
+    net = rh.build_reference_dynamics(cfgs, seed=seed, weight_scale=0.5)
+    return cfgs, net, rh.build_reference_ddpm(cfgs, net, ds)
+
+
+@pytest.mark.parametrize("case", list(CASES))
+def test_forward_and_sampler_on_fresh_weights(case):
+    d = synth.DATASET_DIMS[case]
+    cfgs, net, ddpm = _reference(case, seed=101)
+    P = {k: v.clone().float() for k, v in net.state_dict().items()}
+    ocfg = _ocfg(case, O.infer_num_layers(P))
+    sizes = [6, 1, 9, 4]
+    xh, t, bi, nn_, ctx = synth.make_inputs(sizes, synth.dims_feat(d), seed=303, t_value=0.37, n_ctx=d["n_ctx"])
+    mask = torch.ones(len(bi), dtype=torch.bool)
+    with torch.no_grad():
+        _, want = net(rh.make_batch(bi, mask, ctx), xh, t)
+    got = O.dynamics_forward(P, ocfg, xh, t, bi, None, ctx)
+    assert (got - want).abs().max().item() <= 1e-5 * max(1.0, want.abs().max().item())
+    # free-running sample, 5 coarse steps, same noise tape
+    ctx_b = None
+    if d["n_ctx"]:
+        ctx_b = torch.randn((len(sizes), d["n_ctx"]), generator=torch.Generator().manual_seed(5))
+    with rh.NoiseTape(77), torch.no_grad():
+        ref, _, _ = ddpm.mol_gen_sample(num_samples=len(sizes), num_nodes=nn_, device="cpu", num_timesteps=5, context=ctx_b)
+    out, _ = O.mol_gen_sample(P, ocfg, nn_, O.TapeNoise(77), context=ctx_b, num_timesteps=5)
+    assert (out[:, :3] - ref[:, :3]).abs().max().item() <= 1e-4 * max(1.0, ref[:, :3].abs().max().item())
+    assert torch.equal(out[:, 3:], ref[:, 3:])
+
+
+def test_self_conditioned_sampler_on_fresh_weights():
+    cfgs, net, ddpm = _reference("qm9", seed=202, self_condition=True)
+    P = {k: v.clone().float() for k, v in net.state_dict().items()}
+    ocfg = _ocfg("qm9", O.infer_num_layers(P))
+    ocfg.self_condition = True
+    nn_ = torch.tensor([4, 8, 3])
+    with rh.NoiseTape(9), torch.no_grad():
+        ref, _, _ = ddpm.mol_gen_sample(num_samples=3, num_nodes=nn_, device="cpu", num_timesteps=4)
+    out, _ = O.mol_gen_sample(P, ocfg, nn_, O.TapeNoise(9), num_timesteps=4)
+    assert (out[:, :3] - ref[:, :3]).abs().max().item() <= 1e-4 * max(1.0, ref[:, :3].abs().max().item())
+    assert torch.equal(out[:, 3:], ref[:, 3:])
+
+
+def test_repaint_schedule_live():
+    _, vd, _ = rh.import_reference()
+    fn = vd.EquivariantVariationalDiffusion.get_repaint_schedule
+    fn = getattr(fn, "__wrapped__", fn)
+    for r, j, t in ((2, 3, 17), (5, 2, 9), (1, 4, 4), (4, 10, 1000), (3, 1, 2)):
+        assert O.get_repaint_schedule(r, j, t) == fn(None, r, j, t)
