@@ -75,3 +75,31 @@ def test_repaint_schedule_live():
     fn = getattr(fn, "__wrapped__", fn)
     for r, j, t in ((2, 3, 17), (5, 2, 9), (1, 4, 4), (4, 10, 1000), (3, 1, 2)):
         assert O.get_repaint_schedule(r, j, t) == fn(None, r, j, t)
+
+
+@pytest.mark.parametrize("ds", ["qm9", "geom"])
+def test_stability_oracle_live(ds):
+    """oracle/stability_oracle.py vs the reference's check_molecular_stability (src/datamodules/components/edm/__init__.py:91-122) on fresh
+    random molecules (seeds other than the golden set's)."""
+    import importlib
+    import json
+
+    import numpy as np
+    from oracle import stability_oracle as so
+
+    sys.path.insert(0, os.path.join(HERE, "golden"))
+    gen = importlib.import_module("make_stability_golden")
+    rh.install_stubs()
+    edm = importlib.import_module("src.datamodules.components.edm")
+    info = rh.dataset_info(ds)
+    info["bonds1"], info["bonds2"], info["bonds3"] = edm.get_bond_length_arrays(info["atom_encoder"])
+    tables = json.load(open(os.path.join(os.path.dirname(HERE), "bio-diffusion_amd", "data", "bond_tables.json")))
+    bonds = so.bond_length_arrays(tables, info["atom_encoder"])
+    rng = np.random.default_rng(991 if ds == "qm9" else 992)
+    sizes = [int(s) for s in rng.integers(2, 30 if ds == "qm9" else 90, size=25)]
+    xs, ts = gen.synth_molecules(info["atom_decoder"], sizes, seed=4242 if ds == "qm9" else 4343)
+    for x, t in zip(xs, ts):
+        want = edm.check_molecular_stability(torch.from_numpy(x), torch.from_numpy(t), info)
+        got = so.check_molecular_stability(x, t.astype(np.int32), info["atom_decoder"], tables, bonds)
+        if so.threshold_gap(x, t.astype(np.int32), bonds, tables["margins"]) > 1e-3:
+            assert (int(got[0]), int(got[1]), int(got[2])) == (int(want[0]), int(want[1]), int(want[2]))
