@@ -103,3 +103,33 @@ def test_stability_oracle_live(ds):
         got = so.check_molecular_stability(x, t.astype(np.int32), info["atom_decoder"], tables, bonds)
         if so.threshold_gap(x, t.astype(np.int32), bonds, tables["margins"]) > 1e-3:
             assert (int(got[0]), int(got[1]), int(got[2])) == (int(want[0]), int(want[1]), int(want[2]))
+
+
+def test_inpaint_live_against_repaired_reference():
+    """oracle `inpaint` vs the reference's method with its two crashing tokens repaired in memory (tests/golden/make_inpaint_golden.py
+    `repaired_method`), fresh weights / molecule / mask / schedule."""
+    import importlib
+    import types
+
+    gen = importlib.import_module("make_inpaint_golden")
+    _, vd, _ = rh.import_reference()
+    cfgs, net, ddpm = _reference("qm9", seed=303)
+    ddpm.inpaint = types.MethodType(gen.repaired_method(vd, "inpaint", r"(s_array_self_cond = [^\n]*?) / num_denoise_steps", r"\1"), ddpm)
+    ddpm.sample_p_zt_given_zs = types.MethodType(gen.repaired_method(vd, "sample_p_zt_given_zs", r"alpha_t_given_s\[node_mask\]", "alpha_t_given_s[batch_index]"), ddpm)
+    P = {k: v.clone().float() for k, v in net.state_dict().items()}
+    ocfg = _ocfg("qm9", O.infer_num_layers(P))
+    nn_ = torch.tensor([6, 4, 9])
+    N = int(nn_.sum())
+    bi = torch.repeat_interleave(torch.arange(3), nn_)
+    g = torch.Generator().manual_seed(8)
+    x = torch.randn((N, 3), generator=g) * 1.3 - 0.7
+    oh = torch.nn.functional.one_hot(torch.randint(0, 5, (N,), generator=g), 5).float()
+    ch = torch.randint(0, 5, (N, 1), generator=g).float()
+    fixed = torch.rand(N, generator=g) < 0.5
+    fixed[[0, 6, 10]] = True                                    # the reference needs a fixed node in every molecule
+    with rh.NoiseTape(31), torch.no_grad():
+        ref = ddpm.inpaint(molecule=dict(x=x.clone(), one_hot=oh.clone(), charges=ch.clone(), num_nodes=nn_, batch_index=bi), node_mask_fixed=fixed,
+                           num_resamplings=3, jump_length=2, num_timesteps=7)
+    out = O.inpaint(P, ocfg, x, oh, ch, nn_, fixed, O.TapeNoise(31), num_resamplings=3, jump_length=2, num_timesteps=7)
+    assert (out[:, :3] - ref[:, :3]).abs().max().item() <= 1e-4 * max(1.0, ref[:, :3].abs().max().item())
+    assert torch.equal(out[:, 3:], ref[:, 3:])
