@@ -133,3 +133,26 @@ def test_inpaint_live_against_repaired_reference():
     out = O.inpaint(P, ocfg, x, oh, ch, nn_, fixed, O.TapeNoise(31), num_resamplings=3, jump_length=2, num_timesteps=7)
     assert (out[:, :3] - ref[:, :3]).abs().max().item() <= 1e-4 * max(1.0, ref[:, :3].abs().max().item())
     assert torch.equal(out[:, 3:], ref[:, 3:])
+
+
+@pytest.mark.parametrize("orig", [False, True])
+def test_mol_gen_optimize_live(orig):
+    """oracle `mol_gen_optimize` vs the reference's (variational_diffusion.py:1416-1546) on fresh weights and samples, both time normalisations."""
+    cfgs, net, ddpm = _reference("qm9cond", seed=404)
+    P = {k: v.clone().float() for k, v in net.state_dict().items()}
+    ocfg = _ocfg("qm9cond", O.infer_num_layers(P))
+    F_ = ocfg.num_atom_types
+    nn_ = torch.tensor([4, 9, 5])
+    g = torch.Generator().manual_seed(12)
+    ctx_b = torch.randn((3, 1), generator=g)
+    samples = []
+    for n in nn_.tolist():
+        x = torch.randn((n, 3), generator=g)
+        samples.append((x - x.mean(0, keepdim=True), torch.nn.functional.one_hot(torch.randint(0, F_, (n,), generator=g), F_).float()))
+    with rh.NoiseTape(55), torch.no_grad():
+        ref, _, _ = ddpm.mol_gen_optimize(samples=[(x.clone(), h.clone()) for x, h in samples], num_nodes=nn_, device="cpu", num_timesteps=6,
+                                          context=ctx_b, norm_with_original_timesteps=orig)
+    out, _ = O.mol_gen_optimize(P, ocfg, torch.cat([s[0] for s in samples]), torch.cat([s[1] for s in samples]), nn_, O.TapeNoise(55), context=ctx_b,
+                                num_timesteps=6, norm_with_original_timesteps=orig)
+    assert (out[:, :3] - ref[:, :3]).abs().max().item() <= 1e-4 * max(1.0, ref[:, :3].abs().max().item())
+    assert torch.equal(out[:, 3:], ref[:, 3:])
