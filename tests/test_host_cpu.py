@@ -238,3 +238,65 @@ def test_sample_sweep_conditionally_builds_the_reference_context():
     ctx = m.kw["context"]
     assert ctx.dtype == torch.float32 and ctx.shape == (5, 2)
     assert torch.allclose(ctx[:, 0], torch.linspace(-3.0, 3.0, 5)) and torch.allclose(ctx[:, 1], torch.linspace(-2.0, 2.0, 5), atol=1e-6)
+
+
+def test_header_is_plain_c_and_matches_the_ctypes_binding(tmp_path):
+    """include/gcdm_hip.h must be usable from C (the drop-in boundary is a C ABI): compile it with gcc -std=c99 -pedantic and compare the struct
+    layouts the C compiler sees with those of the ctypes binding (bio-diffusion_amd/_native.py)."""
+    import subprocess
+    native = importlib.import_module("bio-diffusion_amd._native")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = tmp_path / "layout.c"
+    fields_cfg = [f[0] for f in native.GcdmConfig._fields_]
+    fields_tab = [f[0] for f in native.GcdmBondTables._fields_]
+    lines = ['#include "gcdm_hip.h"', "#include <stddef.h>", "#include <stdio.h>", "int main(void) {",
+             '  printf("%zu %zu %d\\n", sizeof(GcdmConfig), sizeof(GcdmBondTables), GCDM_ABI_VERSION);']
+    lines += [f'  printf("%zu\\n", offsetof(GcdmConfig, {f}));' for f in fields_cfg]
+    lines += [f'  printf("%zu\\n", offsetof(GcdmBondTables, {f}));' for f in fields_tab]
+    lines += ["  return 0;", "}"]
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "layout"
+    r = subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", os.path.join(root, "include"), str(src), "-o", str(exe)],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    out = subprocess.run([str(exe)], capture_output=True, text=True).stdout.split("\n")
+    size_cfg, size_tab, abi = (int(v) for v in out[0].split())
+    assert (size_cfg, size_tab, abi) == (ctypes.sizeof(native.GcdmConfig), ctypes.sizeof(native.GcdmBondTables), native.ABI_VERSION)
+    offs = [int(v) for v in out[1:1 + len(fields_cfg) + len(fields_tab)]]
+    want = [getattr(native.GcdmConfig, f).offset for f in fields_cfg] + [getattr(native.GcdmBondTables, f).offset for f in fields_tab]
+    assert offs == want
+
+
+def test_library_links_from_c_without_torch(tmp_path):
+    """A C program (no Python, no torch) links libgcdm_hip.so through the header and calls entry points that need no GPU: the null-handle
+    error paths.  This is what a cgo / JNI / plain-C host would do."""
+    import subprocess
+    native = importlib.import_module("bio-diffusion_amd._native")
+    if not os.path.exists(native.LIB_PATH):
+        pytest.skip("library not built")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = tmp_path / "link.c"
+    src.write_text("""
+#include "gcdm_hip.h"
+#include <stdio.h>
+#include <string.h>
+int main(void) {
+    GcdmConfig cfg; gcdm_handle* h = NULL;
+    memset(&cfg, 0, sizeof cfg);
+    if (strcmp(gcdm_last_error(NULL), "null handle") != 0) return 1;
+    if (gcdm_num_nodes(NULL) != -1 || gcdm_num_edges(NULL) != -1) return 2;
+    if (gcdm_create(NULL, &h) >= 0) return 3;
+    if (gcdm_create(&cfg, NULL) >= 0) return 4;
+    if (gcdm_destroy(NULL) != 0) return 5;
+    if (gcdm_get_option(NULL, "mfma_mode") != -1) return 6;
+    puts("ok");
+    return 0;
+}
+""")
+    exe = tmp_path / "link"
+    libdir = os.path.dirname(native.LIB_PATH)
+    r = subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(root, "include"), str(src), "-o", str(exe),
+                        "-L" + libdir, "-lgcdm_hip", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    run = subprocess.run([str(exe)], capture_output=True, text=True)
+    assert run.returncode == 0 and run.stdout.strip() == "ok", (run.returncode, run.stdout, run.stderr)
