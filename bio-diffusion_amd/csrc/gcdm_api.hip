@@ -31,6 +31,9 @@ struct LayerDev {
     const v4f* wpq; const float* bpq; const float* wddI; const float* wddJ;
     // split-precision (f16 x3) images of the edge-kernel GEMM weights
     const h8 *w0H, *w0L, *wg0H, *wg0L, *wH[3], *wL[3], *wgH[3], *wgL[3];
+#ifdef GCDM_X3_PRE_MFMA
+    const h8 *wddH[3], *wddL[3];
+#endif
     int KB0, KB;
     GcpX3 ffx, posx;
     const h8 *wpqH, *wpqL;
@@ -310,6 +313,9 @@ struct LayerOff {
     float ba;
     GcpOff mk[3], ff, pos;
     size_t w0H, w0L, wg0H, wg0L, wH[3], wL[3], wgH[3], wgL[3];
+#ifdef GCDM_X3_PRE_MFMA
+    size_t wddH[3], wddL[3];
+#endif
     size_t wpqH, wpqL;
     int KB0, KB;
 };
@@ -515,6 +521,23 @@ int gcdm_finalize_weights(gcdm_handle* h) {
             for (int m = 0; m < V; ++m) for (int kk = 0; kk < S; ++kk) Wgd.at(m, kk) = wg.at(m, kk);
             pack_gate_x3(Wgd, xh, xl);
             o.wgH[k - 1] = pool.add(xh); o.wgL[k - 1] = pool.add(xl);
+#ifdef GCDM_X3_PRE_MFMA
+            {   // [W_down (8); W_frames (3)] x 32 channels as the A operand of v_mfma_f32_16x16x32_f16: lane l = row l & 15, k = 8 (l >> 4) + j
+                WView wd, wdf;
+                if (!get_w(h, p + "vector_down.weight", 8, V, wd) || !get_w(h, p + "vector_down_frames.weight", 3, V, wdf)) return -1;
+                std::vector<uint16_t> H16(64 * 8), L16(64 * 8);
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int j = 0; j < 8; ++j) {
+                        const int r = lane & 15, c = 8 * (lane >> 4) + j;
+                        const float wv = r < 8 ? wd.at(r, c) : (r < 11 ? wdf.at(r - 8, c) : 0.f);
+                        split_f16(wv, H16[lane * 8 + j], L16[lane * 8 + j]);
+                    }
+                std::vector<float> ph(H16.size() / 2), pl(L16.size() / 2);
+                std::memcpy(ph.data(), H16.data(), H16.size() * 2);
+                std::memcpy(pl.data(), L16.data(), L16.size() * 2);
+                o.wddH[k - 1] = pool.add(ph); o.wddL[k - 1] = pool.add(pl);
+            }
+#endif
         }
         {
             WView wa, ba;
@@ -557,6 +580,9 @@ int gcdm_finalize_weights(gcdm_handle* h) {
         for (int k = 0; k < 3; ++k) {
             d.wH[k] = (const h8*)(base + o.wH[k]); d.wL[k] = (const h8*)(base + o.wL[k]);
             d.wgH[k] = (const h8*)(base + o.wgH[k]); d.wgL[k] = (const h8*)(base + o.wgL[k]);
+#ifdef GCDM_X3_PRE_MFMA
+            d.wddH[k] = (const h8*)(base + o.wddH[k]); d.wddL[k] = (const h8*)(base + o.wddL[k]);
+#endif
         }
     }
     if (!h->attr_set) {
@@ -740,6 +766,9 @@ int gcdm_forward_sc(gcdm_handle* h, const float* xh, const float* xh_sc, const f
             xa.base = ma;
             xa.w0H = d.w0H; xa.w0L = d.w0L; xa.KB0 = d.KB0; xa.wg0H = d.wg0H; xa.wg0L = d.wg0L; xa.KB = d.KB;
             for (int k = 0; k < 3; ++k) { xa.wH[k] = d.wH[k]; xa.wL[k] = d.wL[k]; xa.wgH[k] = d.wgH[k]; xa.wgL[k] = d.wgL[k]; }
+#ifdef GCDM_X3_PRE_MFMA
+            for (int k = 0; k < 3; ++k) { xa.wddH[k] = d.wddH[k]; xa.wddL[k] = d.wddL[k]; }
+#endif
             xa.flags_dev = h->d_flags;
             if (d.KB != 18 || d.KB0 != (h->Se == 64 ? 7 : 4)) return fail(h, "internal: k-block counts differ from the kernel's compile-time constants");
             if (ET == 64) {

@@ -259,6 +259,76 @@ __device__ __forceinline__ bool gcp2_pre_x3(const float* __restrict__ wdd, const
     return over;
 }
 
+#ifdef GCDM_X3_PRE_MFMA
+// EXPERIMENTAL (off by default, not yet run on a GPU; data movement validated by tools/emu/pre_mfma_plan.py): the pre-phase of a residual
+// message GCP2 on the matrix pipe.  [W_down; W_frames] (11 x 32, padded to 16 rows) x v (32 channels x {x,y,z} x edges) is one
+// v_mfma_f32_16x16x32_f16 per component and 16 edges (x3 for the split precision): wave w < T/16 takes edges 16w..16w+15.
+//   A: lane l = row l&15, k = 8(l>>4)+j (host-packed)      B: lane l = edge l&15, channel 8(l>>4)+j      D: lane l = edge l&15, rows 4(l>>4)+i
+// so lanes 0-31 end up with the 8 hidden vectors (norms -> extended-K rows, vectors -> VH), lanes 32-47 with the three W_frames
+// vectors (-> 9 frame scalars) and lanes 48-63 write the zero padding.  Replaces 192 FMAs + 96 LDS reads + 64 per-lane weight loads
+// per thread on all waves (8.3 % of the QM9 step) by 24 LDS reads, 12 pair splits and 9 small MFMAs on T/16 waves.
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+template <int T>
+__device__ __forceinline__ bool gcp2_pre_mfma(const h8* __restrict__ wddH, const h8* __restrict__ wddL, const float* VV, const float* FR, char* XH,
+                                              char* XL, int gN8, int gQ8, int gEnd8, float* VH, int wave, int lane) {
+    constexpr int TP = T + 1;
+    bool over = false;
+    if (wave < T / 16) {
+        const int e = 16 * wave + (lane & 15), q = lane >> 4;
+        const h8 aH = wddH[lane], aL = wddL[lane];
+        float o[3][4];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            h8 bh, bl;
+#pragma unroll
+            for (int j = 0; j < 8; j += 2) {
+                const float x0 = VV[((q * 8 + j) * 3 + k) * TP + e], x1 = VV[((q * 8 + j + 1) * 3 + k) * TP + e];
+                over |= fmaxf(fabsf(x0), fabsf(x1)) > X3_RANGE;
+                h2 hi, lo;
+                split16x2(x0, x1, hi, lo);
+                bh[j] = hi[0]; bh[j + 1] = hi[1];
+                bl[j] = lo[0]; bl[j + 1] = lo[1];
+            }
+            f32x4 am = {0.f, 0.f, 0.f, 0.f}, al = {0.f, 0.f, 0.f, 0.f};
+            am = __builtin_amdgcn_mfma_f32_16x16x32_f16(aH, bh, am, 0, 0, 0);
+            al = __builtin_amdgcn_mfma_f32_16x16x32_f16(aH, bl, al, 0, 0, 0);
+            al = __builtin_amdgcn_mfma_f32_16x16x32_f16(aL, bh, al, 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) o[k][i] = am[i] + al[i] * X3_INV_SCALE;
+        }
+        if (q < 2) {                    // rows 4q..4q+3 of W_down: hidden vectors -> VH, their norms -> extended-K rows (gcpnet.py:442-452)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int r = 4 * q + i;
+                const float vx = o[0][i], vy = o[1][i], vz = o[2][i];
+                over |= put16(XH, XL, TP, gN8 + (r >> 3), r & 7, e, sqrtf(vx * vx + vy * vy + vz * vz + 1e-8f) + 1e-8f);
+                VH[(r * 3 + 0) * TP + e] = vx;
+                VH[(r * 3 + 1) * TP + e] = vy;
+                VH[(r * 3 + 2) * TP + e] = vz;
+            }
+        } else if (q == 2) {            // rows 8..10 = W_frames: q[3j + r] = F[r,:] . u_j (scalarize, components/__init__.py:174-219)
+            float f[9];
+#pragma unroll
+            for (int r = 0; r < 9; ++r) f[r] = FR[r * TP + e];
+#pragma unroll
+            for (int j = 0; j < 3; ++j)
+#pragma unroll
+                for (int r = 0; r < 3; ++r) {
+                    const int idx = 3 * j + r;
+                    over |= put16(XH, XL, TP, gQ8 + (idx >> 3), idx & 7, e, f[3 * r] * o[0][j] + f[3 * r + 1] * o[1][j] + f[3 * r + 2] * o[2][j]);
+                }
+        } else {                        // zero the padding slots (weights there are zero, LDS is not)
+            for (int idx = 9; idx < 16; ++idx) put16(XH, XL, TP, gQ8 + (idx >> 3), idx & 7, e, 0.f);
+            for (int g = gQ8 + 2; g < gEnd8; ++g) {
+                *(v4f*)(XH + (g * TP + e) * 16) = (v4f){0.f, 0.f, 0.f, 0.f};
+                *(v4f*)(XL + (g * TP + e) * 16) = (v4f){0.f, 0.f, 0.f, 0.f};
+            }
+        }
+    }
+    return over;
+}
+#endif
+
 struct EdgeMsgX3Args {
     EdgeMsgArgs base;                 // everything the fp32 kernel takes (tables, biases, vector weights, attention)
     const h8* w0H; const h8* w0L; int KB0;          // msg0 per-edge part, packed [8][KB0][64] x 8 f16
@@ -266,6 +336,9 @@ struct EdgeMsgX3Args {
     const h8* wH[3]; const h8* wL[3]; int KB;       // msg1..3 scalar_out, packed [8][KB][64]
     const h8* wgH[3]; const h8* wgL[3];
     uint32_t* flags_dev;                            // bit GCDM_FLAG_F16_RANGE
+#ifdef GCDM_X3_PRE_MFMA
+    const h8* wddH[3]; const h8* wddL[3];           // msg1..3 [W_down; W_frames] (11 x 32 -> 16 x 32) as the A operand of one 16x16x32 MFMA, [64 lanes] x 8 f16
+#endif
 };
 
 #define GCDM_FLAG_F16_RANGE_BIT 8u
@@ -495,7 +568,11 @@ __global__ __launch_bounds__(ET * 8) __attribute__((amdgpu_waves_per_eu(2, 2))) 
     // ---- residual message GCP2s k = 1..3 ---------------------------------------------------------------------------------
     for (int k = 0; k < 3; ++k) {
         const GcpW& w = a.mk[k];
+#ifdef GCDM_X3_PRE_MFMA
+        over |= gcp2_pre_mfma<ET>(ax.wddH[k], ax.wddL[k], VV, FR, XH, XL, 32, 33, 36, VH, wave, lane);
+#else
         over |= gcp2_pre_x3<ET, EK_THREADS>(w.wdd, VV, FR, XH, XL, 32, 33, 36, VH, e, part);
+#endif
         if (k == 0) STAMP(10);
         __syncthreads();
         if (k == 0) STAMP(11);
