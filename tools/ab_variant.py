@@ -1,9 +1,14 @@
 """A/B helper for kernel variants (run via gpurun; the library under test is whatever bio-diffusion_amd/libgcdm_hip.so is at the moment):
 
-    python tools/ab_variant.py <tag> [qm9|geom]
+    python tools/ab_variant.py <tag> [qm9|geom] [compare-to-tag]
 
 Prints one line: sha256 of a full-size forward output and of the latent after 3 Philox sampler steps (bit-identity check between
-variants), and the per-step time of 40 sampler steps on one handle (HIP events on the launch stream).
+variants), and the per-step time of 40 sampler steps on one handle (HIP events on the launch stream).  The forward output is also
+kept in /tmp/ab_<tag>_<case>.pt; with a third argument the line additionally carries max |out - out_of_that_tag| / max |out| (for
+variants that change the summation order, e.g. -DGCDM_X3_PRE_MFMA: expect ~1e-6, the parity bar is 1e-4).
+
+Typical call (libraries pre-built in the build container under build/ab/, which travels to the GPU box):
+    for v in base pre; do cp build/ab/libgcdm_$v.so bio-diffusion_amd/libgcdm_hip.so; python tools/ab_variant.py $v qm9 base; done
 """
 import ctypes as C
 import hashlib
@@ -34,6 +39,11 @@ dyn.plan(nn_)
 out = dyn.native_forward(xh.to(dev), t.to(dev))
 torch.cuda.synchronize()
 h_fwd = hashlib.sha256(out.cpu().numpy().tobytes()).hexdigest()[:16]
+torch.save(out.cpu(), f"/tmp/ab_{tag}_{case}.pt")
+rel = ""
+if len(sys.argv) > 3 and os.path.exists(f"/tmp/ab_{sys.argv[3]}_{case}.pt"):
+    other = torch.load(f"/tmp/ab_{sys.argv[3]}_{case}.pt")
+    rel = f" rel_vs_{sys.argv[3]}={(out.cpu() - other).abs().max().item() / other.abs().max().item():.2e}"
 N, D = xh.shape
 z = torch.empty((N, D), device=dev)
 flags = torch.zeros(1, dtype=torch.int32, device=dev)
@@ -54,4 +64,4 @@ for i in range(K):
     lib.gcdm_sample_step(h, zp, None, 986 - i, 1000, None, sd, fp, st)
 ev[1].record()
 torch.cuda.synchronize()
-print(f"AB {tag} {case} edge_tile={lib.gcdm_get_option(h, b'edge_tile')} fwd={h_fwd} z3={h_z} ms_per_step={ev[0].elapsed_time(ev[1]) / K:.4f} flags={int(flags.item())}")
+print(f"AB {tag} {case} edge_tile={lib.gcdm_get_option(h, b'edge_tile')} fwd={h_fwd} z3={h_z} ms_per_step={ev[0].elapsed_time(ev[1]) / K:.4f} flags={int(flags.item())}{rel}")
