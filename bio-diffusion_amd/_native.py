@@ -46,7 +46,7 @@ EXPORTS = [
     "gcdm_plan_batch", "gcdm_forward", "gcdm_sample_step", "gcdm_sample_final", "gcdm_sample_init", "gcdm_debug_read",
     "gcdm_debug_set_layer_limit", "gcdm_num_nodes", "gcdm_num_edges", "gcdm_forward_flops_executed",
     "gcdm_profile_enable", "gcdm_profile_edge_kernel_ms", "gcdm_set_option", "gcdm_get_option", "gcdm_check_stability", "gcdm_encode_samples", "gcdm_unnormalize_z", "gcdm_sample_step_to", "gcdm_forward_sc", "gcdm_sample_step_sc", "gcdm_sample_final_sc",
-    "gcdm_inpaint_center", "gcdm_inpaint_step", "gcdm_inpaint_jump",
+    "gcdm_inpaint_center", "gcdm_inpaint_step", "gcdm_inpaint_jump", "gcdm_timestep_index",
 ]
 
 _lib: Optional[C.CDLL] = None
@@ -106,6 +106,8 @@ def load() -> C.CDLL:
     lib.gcdm_inpaint_step.argtypes = [H, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p,
                                       C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p, C.c_void_p]
     lib.gcdm_inpaint_jump.argtypes = [H, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p]
+    lib.gcdm_timestep_index.argtypes = [C.c_float, C.c_int32]
+    lib.gcdm_timestep_index.restype = C.c_int32
     lib.gcdm_debug_read.argtypes = [H, C.c_char_p, C.c_void_p, C.c_int64]
     lib.gcdm_debug_read.restype = C.c_int64
     lib.gcdm_debug_set_layer_limit.argtypes = [H, C.c_int32]

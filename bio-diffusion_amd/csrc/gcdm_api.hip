@@ -803,12 +803,16 @@ static inline float softplusf(float x) { return x > 20.f ? x : log1pf(expf(x)); 
 static inline float logsigmoidf(float x) { return x < 0.f ? x - log1pf(expf(x)) : -log1pf(expf(-x)); }
 static inline float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
 
-static float gamma_lookup(const gcdm_handle* h, float t) {
-    long idx = lroundf(t * (float)h->cfg.num_timesteps);   // torch.round(t * T).long()  (variational_diffusion.py:252-255)
+// torch.round(t * T).long() (variational_diffusion.py:252-255): fp32 product, ties to EVEN -- rintf in the default rounding mode, not
+// lroundf (ties away from zero): with e.g. 400 sampling steps on the T = 1000 table every odd s gives t * T = k + 0.5 exactly
+int32_t gcdm_timestep_index(float t, int32_t num_timesteps) {
+    long idx = (long)rintf(t * (float)num_timesteps);
     if (idx < 0) idx = 0;
-    if (idx > h->cfg.num_timesteps) idx = h->cfg.num_timesteps;
-    return h->gamma[idx];
+    if (idx > num_timesteps) idx = num_timesteps;
+    return (int32_t)idx;
 }
+
+static float gamma_lookup(const gcdm_handle* h, float t) { return h->gamma[gcdm_timestep_index(t, h->cfg.num_timesteps)]; }
 
 static int launch_sample(gcdm_handle* h, StepArgs& sa, hipStream_t st) {
     sa.noff = h->d_noff; sa.N = h->N; sa.D = h->D; sa.node_base = h->node_base;

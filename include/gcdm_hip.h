@@ -154,6 +154,11 @@ int gcdm_inpaint_step(gcdm_handle* h, float* z, const float* xh0, const uint8_t*
 int gcdm_inpaint_jump(gcdm_handle* h, float* z, int32_t s_index, int32_t t_index, int32_t num_steps, const float* noise, uint64_t seed,
                       uint32_t draw, void* stream);
 
+/* Index into the gamma table for a normalised time t, exactly as PredefinedNoiseSchedule.forward does it (variational_diffusion.py:252-255:
+ * `torch.round(t * timesteps).long()`, fp32, ties to even), clamped to [0, num_timesteps].  Pure host function (no handle, no GPU); every
+ * step / jump / decode entry point uses it with t = s_index / num_steps computed in fp32. */
+int32_t gcdm_timestep_index(float t, int32_t num_timesteps);
+
 /* unnormalize_z (variational_diffusion.py:759-792): out [N,3+F] = continuous, un-normalised copy of the latent z -- one frame of the
  * chain visualisation (`mol_gen_sample(return_frames > 1)`, :1354-1361).  With frames the reference skips the final CoG re-projection
  * (:1389): set option "cog_fix" to 0 before gcdm_sample_final (default 1). */

@@ -300,3 +300,25 @@ int main(void) {
     assert r.returncode == 0, r.stderr
     run = subprocess.run([str(exe)], capture_output=True, text=True)
     assert run.returncode == 0 and run.stdout.strip() == "ok", (run.returncode, run.stdout, run.stderr)
+
+
+def test_timestep_index_rounds_like_torch():
+    """The gamma-table index of every sampler entry point (gcdm_timestep_index, pure host code) against the reference's formula
+    `torch.round(t * T).long()` (variational_diffusion.py:252-255) for t = s / n in fp32 -- including the step counts whose products are exact
+    ties (n = 16, 80, 400, 2000 on the T = 1000 table), which round to EVEN in torch."""
+    native = importlib.import_module("bio-diffusion_amd._native")
+    if not os.path.exists(native.LIB_PATH):
+        pytest.skip("library not built")
+    lib = native.load()
+    ties = 0
+    for T in (1000, 500, 8):
+        for n in (1, 2, 5, 6, 12, 16, 37, 80, 125, 400, 1000, 2000):
+            s = torch.arange(0, n + 1, dtype=torch.float32)
+            t = s / n
+            want = torch.round(t * T).long().clamp(0, T).tolist()
+            got = [lib.gcdm_timestep_index(float(v), T) for v in t.tolist()]
+            assert got == want, (T, n)
+            prod = (t * T)
+            ties += int(((prod - torch.floor(prod)) == 0.5).sum())
+    assert ties > 100                                         # the tie cases really occur
+    assert lib.gcdm_timestep_index(-0.3, 1000) == 0 and lib.gcdm_timestep_index(1.7, 1000) == 1000
