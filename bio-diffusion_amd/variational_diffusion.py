@@ -120,15 +120,17 @@ class NumNodesDistribution(nn.Module):
     def __init__(self, histogram: Dict[int, int], verbose: bool = False, eps: float = 1e-30):
         super().__init__()
         self.eps = eps
-        num_nodes, self.keys, prob = [], {}, []
-        for i, nodes in enumerate(histogram):
-            num_nodes.append(nodes)
-            self.keys[nodes] = i
-            prob.append(histogram[nodes])
-        self.register_buffer("num_nodes", torch.tensor(num_nodes))
-        self.register_buffer("prob", torch.tensor(prob))
-        self.prob = self.prob / torch.sum(self.prob)
-        self.m = torch.distributions.Categorical(self.prob)
+        sizes = list(histogram)                                  # insertion order = the order of the checkpoint's buffers
+        counts = torch.tensor([histogram[n] for n in sizes])
+        self.keys = {n: i for i, n in enumerate(sizes)}
+        self.register_buffer("num_nodes", torch.tensor(sizes))
+        self.register_buffer("prob", counts / counts.sum())      # same state-dict entries as the reference: sizes and normalised frequencies
+
+    @property
+    def m(self) -> torch.distributions.Categorical:
+        """Built from the CURRENT `prob` buffer (a checkpoint may have replaced it after construction) and on the CPU, so that a torch seed
+        draws the sizes the reference draws (its Categorical is created before the module moves to the GPU)."""
+        return torch.distributions.Categorical(self.prob.detach().cpu())
 
     def sample(self, n_samples: int = 1) -> torch.Tensor:
         idx = self.m.sample((n_samples,))
