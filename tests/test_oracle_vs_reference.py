@@ -182,3 +182,25 @@ def test_host_side_mirrors_live():
     assert torch.equal(mine.gamma.gamma, ddpm.gamma.gamma.detach())
     t = torch.tensor([[0.0], [0.0625], [0.0025], [0.5], [1.0]])
     assert torch.equal(mine.gamma(t), ddpm.gamma(t))
+
+
+@pytest.mark.parametrize("ds,cond", [("qm9", ()), ("qm9", ("alpha",)), ("geom", ())])
+def test_reference_state_dict_loads_into_the_whole_model_stand_in(ds, cond, tmp_path):
+    """A checkpoint whose `state_dict` is the reference's own `ddpm.*` (full-width dynamics network, gamma table, size distribution) loads into
+    the stand-in with no missing and no unexpected key, and every tensor arrives unchanged."""
+    import importlib
+
+    pkg = importlib.import_module("bio-diffusion_amd")
+    cfgs = rh.load_reference_cfgs(ds, cond)
+    net = rh.build_reference_dynamics(cfgs, seed=11)
+    ddpm = rh.build_reference_ddpm(cfgs, net, ds)
+    sd = {"ddpm." + k: v.clone() for k, v in ddpm.state_dict().items()}
+    path = str(tmp_path / "model-EMA.ckpt")
+    torch.save({"state_dict": sd, "epoch": 3, "hyper_parameters": {}}, path)
+    mine_cfgs = pkg.default_cfgs(ds, cond)
+    cls = pkg.GEOMMoleculeGenerationDDPM if ds == "geom" else pkg.QM9MoleculeGenerationDDPM
+    model = cls(**mine_cfgs).load_from_checkpoint(checkpoint_path=path, map_location="cpu", **mine_cfgs)
+    got = model.state_dict()
+    assert set(got) == set(sd), (sorted(set(got) ^ set(sd))[:6])
+    for k, v in sd.items():
+        assert got[k].shape == v.shape and torch.equal(got[k].to(v.dtype), v), k
