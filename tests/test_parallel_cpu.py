@@ -70,3 +70,56 @@ def test_two_rank_sampling_equals_independent_shards():
     assert nn_g.tolist() == nn_all.tolist()
     want = torch.cat([_sample_shard(par.shard_num_nodes(nn_all, r, 2), 100 + r) for r in range(2)], dim=0).numpy()
     assert full.shape == want.shape and np.array_equal(full, want)
+
+
+class _OracleDDPM:
+    """Stand-in with the `mol_gen_sample` signature `parallel.sample_sharded` calls; samples with the CPU oracle (test only)."""
+
+    def __init__(self):
+        self.calls = []
+
+    def mol_gen_sample(self, num_samples, num_nodes, device, num_timesteps=None, context=None, seed=1234, lanes=1):
+        self.calls.append((int(num_samples), [int(v) for v in num_nodes], None if context is None else context.clone(), seed, lanes))
+        out = _sample_shard(torch.as_tensor(num_nodes), seed)
+        if context is not None:                     # make the result depend on the context rows this rank was given
+            bi = torch.repeat_interleave(torch.arange(len(num_nodes)), torch.as_tensor(num_nodes))
+            out = out + context.to(out.dtype)[bi].sum(-1, keepdim=True)
+        return out, None, None
+
+
+def _worker_sharded(rank, world, port, nn_all, ctx_all, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    ddpm = _OracleDDPM()
+    xh, nn_g = par.sample_sharded(ddpm, nn_all, "cpu", context=ctx_all, num_timesteps=4, seed=50, lanes=2)
+    q.put((rank, xh.numpy(), nn_g.numpy(), ddpm.calls[0][1], ddpm.calls[0][3], ddpm.calls[0][4]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sample_sharded_two_ranks_with_context():
+    """`parallel.sample_sharded` end to end under gloo: every rank samples its contiguous block (own context rows, seed + rank), and every rank
+    receives all samples in the original molecule order."""
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    nn_all = torch.tensor([5, 7, 3, 6, 4])
+    ctx_all = torch.tensor([[0.5], [-1.0], [2.0], [0.25], [-0.75]])
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_sharded, args=(r, 2, port, nn_all, ctx_all, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=240) for _ in range(2)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    want = []
+    for r in range(2):
+        lo, hi = par.shard_range(5, r, 2)
+        o, _, _ = _OracleDDPM().mol_gen_sample(hi - lo, nn_all[lo:hi], "cpu", 4, ctx_all[lo:hi], 50 + r)
+        want.append(o)
+        assert res[r][3] == nn_all[lo:hi].tolist() and res[r][4] == 50 + r and res[r][5] == 2
+    want = torch.cat(want).numpy()
+    for r in range(2):
+        assert np.array_equal(res[r][1], want) and res[r][2].tolist() == nn_all.tolist()
