@@ -217,12 +217,22 @@ __device__ __forceinline__ bool gcp2_pre_x3(const float* __restrict__ wdd, const
         wrow[i] = wdd + (hh < ROWS ? hh : ROWS - 1) * V_IN;
     }
     const float* vp = VV + e;
+#ifdef GCDM_X3_PRE_SKIP
+    bool any_row[NH];
+#pragma unroll
+    for (int i = 0; i < NH; ++i) any_row[i] = __any(part + PARTS * i < ROWS);      // wave-uniform
+#endif
 #pragma unroll 8
     for (int c = 0; c < V_IN; ++c) {
         const float vx = vp[0], vy = vp[TP], vz = vp[2 * TP];
         vp += 3 * TP;
 #pragma unroll
         for (int i = 0; i < NH; ++i) {
+#ifdef GCDM_X3_PRE_SKIP
+            // EXPERIMENTAL (off by default): rows are dealt out as hh = part + PARTS * i, and for i >= 1 only parts < ROWS - PARTS * i own a real row
+            // -- the others recompute row ROWS-1 and throw it away.  Skip those FMAs where the whole wave has none (bit-identical results).
+            if (i > 0 && !any_row[i]) continue;
+#endif
             const float wc = wrow[i][c];
             ax[i] += wc * vx; ay[i] += wc * vy; az[i] += wc * vz;
         }
