@@ -31,9 +31,7 @@ struct LayerDev {
     const v4f* wpq; const float* bpq; const float* wddI; const float* wddJ;
     // split-precision (f16 x3) images of the edge-kernel GEMM weights
     const h8 *w0H, *w0L, *wg0H, *wg0L, *wH[3], *wL[3], *wgH[3], *wgL[3];
-#ifdef GCDM_X3_PRE_MFMA
-    const h8 *wddH[3], *wddL[3];
-#endif
+    const h8 *vpH[3], *vpL[3], *vf1[3], *vf2[3], *vf0H, *vf0L;   // vector path on the matrix pipe (gcdm_edge_x3.hip.h)
     int KB0, KB;
     GcpX3 ffx, posx;
     const h8 *wpqH, *wpqL;
@@ -184,6 +182,61 @@ struct WView {
     float at(int r, int c) const { return (*v)[(size_t)r * cols + c]; }
 };
 
+// ---- A operands of the vector path (v_mfma_f32_16x16x32_f16: lane l holds row l & 15, k = 8 (l >> 4) + j), see gcdm_edge_x3.hip.h ----
+std::vector<float> f16_words(const std::vector<uint16_t>& v) {
+    std::vector<float> o(v.size() / 2);
+    std::memcpy(o.data(), v.data(), v.size() * 2);
+    return o;
+}
+
+// [W_down (H = 8 rows); W_frames (3 rows)] x 32 channels; k = 8q + j <-> channel (j < 4 ? 4q + j : 16 + 4q + j - 4)
+template <typename WD, typename WF>
+void pack_vec_pre(const WD& wd, const WF& wdf, std::vector<float>& outH, std::vector<float>& outL) {
+    std::vector<uint16_t> H(64 * 8), L(64 * 8);
+    for (int lane = 0; lane < 64; ++lane)
+        for (int j = 0; j < 8; ++j) {
+            const int r = lane & 15, q = lane >> 4, c = j < 4 ? 4 * q + j : 16 + 4 * q + (j - 4);
+            const float wv = r < 8 ? wd.at(r, c) : (r < 11 ? wdf.at(r - 8, c) : 0.f);
+            split_f16(wv, H[lane * 8 + j], L[lane * 8 + j]);
+        }
+    outH = f16_words(H);
+    outL = f16_words(L);
+}
+
+// vector_up [32][8] against the B image [hi(4) | lo'(4)] of hidden channels 4q .. 4q+3 (q < 2):  A1 = [W_hi | 0],  A2 = [W_lo' | W_hi]
+template <typename WU>
+void pack_vec_fin(const WU& wu, std::vector<float>& out1, std::vector<float>& out2) {
+    std::vector<uint16_t> A1(2 * 64 * 8, 0), A2(2 * 64 * 8, 0);
+    for (int m = 0; m < 2; ++m)
+        for (int lane = 0; lane < 64; ++lane) {
+            const int c = 16 * m + (lane & 15), q = lane >> 4;
+            if (q >= 2) continue;
+            for (int j = 0; j < 8; ++j) {
+                uint16_t hi, lo;
+                split_f16(wu.at(c, 4 * q + (j & 3)), hi, lo);
+                const size_t o = ((size_t)m * 64 + lane) * 8 + j;
+                A1[o] = j < 4 ? hi : 0;
+                A2[o] = j < 4 ? lo : hi;
+            }
+        }
+    out1 = f16_words(A1);
+    out2 = f16_words(A2);
+}
+
+// vector_up of msg0 [32][H0], k = hidden channel (H0 <= 32)
+template <typename WU>
+void pack_vec_fin0(const WU& wu, int H0, std::vector<float>& outH, std::vector<float>& outL) {
+    std::vector<uint16_t> H(2 * 64 * 8, 0), L(2 * 64 * 8, 0);
+    for (int m = 0; m < 2; ++m)
+        for (int lane = 0; lane < 64; ++lane)
+            for (int j = 0; j < 8; ++j) {
+                const int c = 16 * m + (lane & 15), hch = 8 * (lane >> 4) + j;
+                if (hch < H0) split_f16(wu.at(c, hch), H[((size_t)m * 64 + lane) * 8 + j], L[((size_t)m * 64 + lane) * 8 + j]);
+            }
+    outH = f16_words(H);
+    outL = f16_words(L);
+}
+
 bool get_w(gcdm_handle* h, const std::string& key, int rows, int cols, WView& out) {
     auto it = h->host_w.find(key);
     if (it == h->host_w.end()) {
@@ -313,9 +366,7 @@ struct LayerOff {
     float ba;
     GcpOff mk[3], ff, pos;
     size_t w0H, w0L, wg0H, wg0L, wH[3], wL[3], wgH[3], wgL[3];
-#ifdef GCDM_X3_PRE_MFMA
-    size_t wddH[3], wddL[3];
-#endif
+    size_t vpH[3], vpL[3], vf1[3], vf2[3], vf0H, vf0L;
     size_t wpqH, wpqL;
     int KB0, KB;
 };
@@ -502,6 +553,8 @@ int gcdm_finalize_weights(gcdm_handle* h) {
             o.w0H = pool.add(xh); o.w0L = pool.add(xl); o.KB0 = Kx / 16;
             pack_gate_x3(Wg, xh, xl);
             o.wg0H = pool.add(xh); o.wg0L = pool.add(xl);
+            pack_vec_fin0(wu, H0, xh, xl);
+            o.vf0H = pool.add(xh); o.vf0L = pool.add(xl);
         }
         for (int k = 1; k <= 3; ++k) {
             const std::string p = lp + "interaction.message_fusion." + std::to_string(k) + ".";
@@ -521,23 +574,17 @@ int gcdm_finalize_weights(gcdm_handle* h) {
             for (int m = 0; m < V; ++m) for (int kk = 0; kk < S; ++kk) Wgd.at(m, kk) = wg.at(m, kk);
             pack_gate_x3(Wgd, xh, xl);
             o.wgH[k - 1] = pool.add(xh); o.wgL[k - 1] = pool.add(xl);
-#ifdef GCDM_X3_PRE_MFMA
-            {   // [W_down (8); W_frames (3)] x 32 channels as the A operand of v_mfma_f32_16x16x32_f16: lane l = row l & 15, k = 8 (l >> 4) + j
-                WView wd, wdf;
-                if (!get_w(h, p + "vector_down.weight", 8, V, wd) || !get_w(h, p + "vector_down_frames.weight", 3, V, wdf)) return -1;
-                std::vector<uint16_t> H16(64 * 8), L16(64 * 8);
-                for (int lane = 0; lane < 64; ++lane)
-                    for (int j = 0; j < 8; ++j) {
-                        const int r = lane & 15, c = 8 * (lane >> 4) + j;
-                        const float wv = r < 8 ? wd.at(r, c) : (r < 11 ? wdf.at(r - 8, c) : 0.f);
-                        split_f16(wv, H16[lane * 8 + j], L16[lane * 8 + j]);
-                    }
-                std::vector<float> ph(H16.size() / 2), pl(L16.size() / 2);
-                std::memcpy(ph.data(), H16.data(), H16.size() * 2);
-                std::memcpy(pl.data(), L16.data(), L16.size() * 2);
-                o.wddH[k - 1] = pool.add(ph); o.wddL[k - 1] = pool.add(pl);
+            {   // vector path on the matrix pipe: vector_down / vector_down_frames and vector_up as 16x16x32 A operands
+                WView wd, wdf, wu;
+                if (!get_w(h, p + "vector_down.weight", 8, V, wd) || !get_w(h, p + "vector_down_frames.weight", 3, V, wdf) ||
+                    !get_w(h, p + "vector_up.weight", V, 8, wu))
+                    return -1;
+                std::vector<float> a, b;
+                pack_vec_pre(wd, wdf, a, b);
+                o.vpH[k - 1] = pool.add(a); o.vpL[k - 1] = pool.add(b);
+                pack_vec_fin(wu, a, b);
+                o.vf1[k - 1] = pool.add(a); o.vf2[k - 1] = pool.add(b);
             }
-#endif
         }
         {
             WView wa, ba;
@@ -577,12 +624,12 @@ int gcdm_finalize_weights(gcdm_handle* h) {
         d.ffx = resolve_x3(o.ff, base); d.posx = resolve_x3(o.pos, base);
         d.wpqH = (const h8*)(base + o.wpqH); d.wpqL = (const h8*)(base + o.wpqL);
         d.wg0H = (const h8*)(base + o.wg0H); d.wg0L = (const h8*)(base + o.wg0L);
+        d.vf0H = (const h8*)(base + o.vf0H); d.vf0L = (const h8*)(base + o.vf0L);
         for (int k = 0; k < 3; ++k) {
             d.wH[k] = (const h8*)(base + o.wH[k]); d.wL[k] = (const h8*)(base + o.wL[k]);
             d.wgH[k] = (const h8*)(base + o.wgH[k]); d.wgL[k] = (const h8*)(base + o.wgL[k]);
-#ifdef GCDM_X3_PRE_MFMA
-            d.wddH[k] = (const h8*)(base + o.wddH[k]); d.wddL[k] = (const h8*)(base + o.wddL[k]);
-#endif
+            d.vpH[k] = (const h8*)(base + o.vpH[k]); d.vpL[k] = (const h8*)(base + o.vpL[k]);
+            d.vf1[k] = (const h8*)(base + o.vf1[k]); d.vf2[k] = (const h8*)(base + o.vf2[k]);
         }
     }
     if (!h->attr_set) {
@@ -766,9 +813,8 @@ int gcdm_forward_sc(gcdm_handle* h, const float* xh, const float* xh_sc, const f
             xa.base = ma;
             xa.w0H = d.w0H; xa.w0L = d.w0L; xa.KB0 = d.KB0; xa.wg0H = d.wg0H; xa.wg0L = d.wg0L; xa.KB = d.KB;
             for (int k = 0; k < 3; ++k) { xa.wH[k] = d.wH[k]; xa.wL[k] = d.wL[k]; xa.wgH[k] = d.wgH[k]; xa.wgL[k] = d.wgL[k]; }
-#ifdef GCDM_X3_PRE_MFMA
-            for (int k = 0; k < 3; ++k) { xa.wddH[k] = d.wddH[k]; xa.wddL[k] = d.wddL[k]; }
-#endif
+            for (int k = 0; k < 3; ++k) { xa.vpH[k] = d.vpH[k]; xa.vpL[k] = d.vpL[k]; xa.vf1[k] = d.vf1[k]; xa.vf2[k] = d.vf2[k]; }
+            xa.vf0H = d.vf0H; xa.vf0L = d.vf0L;
             xa.flags_dev = h->d_flags;
             if (d.KB != 18 || d.KB0 != (h->Se == 64 ? 7 : 4)) return fail(h, "internal: k-block counts differ from the kernel's compile-time constants");
             if (ET == 64) {

@@ -150,8 +150,30 @@ __device__ __forceinline__ void gate_partial_x3(f32x16 (&gm)[NT], f32x16 (&gl)[N
         }
 }
 
-// Gate partials of the 8 channel blocks are folded pairwise in two stages (LDS float atomics run at ~1 lane/clk on gfx950):
-// waves 0-3 store their partial into slot w, (barrier), waves 4-7 add theirs onto slot w-4.  Fixed order -> deterministic.
+// Gate partials PG[slot][e][32 c] (fp32, c contiguous: the vector waves read the four channels they own as one ds_read_b128 per slot).
+// 16-byte granule (c >> 2) of row e sits at granule index (c >> 2) ^ (e & 7): conflict-free both for the writers (32x32 accumulator
+// layout: lane = edge, 4 consecutive channels per register quad) and for the readers (16x16 layout of the vector-path MFMAs).
+// The 8 channel blocks are folded pairwise in two stages (LDS float atomics run at ~1 lane/clk on gfx950): waves 0-3 store their
+// partial into slot w, (barrier), waves 4-7 add theirs onto slot w-4.  Fixed order -> deterministic.
+template <int ET>
+__device__ __forceinline__ int pg_off(int slot, int e, int c4) { return ((slot * ET + e) * 32 + 4 * (c4 ^ (e & 7))); }
+
+template <int NT, int ET>
+__device__ __forceinline__ void put_gate_partial(float* PG, const f32x16 (&gm)[NT], const f32x16 (&gl)[NT], int slot, int lane, bool add) {
+    const int half = lane >> 5, l31 = lane & 31;
+#pragma unroll
+    for (int n = 0; n < NT; ++n)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            v4f v;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[i] = gm[n][4 * t + i] + gl[n][4 * t + i] * X3_INV_SCALE;
+            v4f* p = (v4f*)(PG + pg_off<ET>(slot, 32 * n + l31, 2 * t + half));      // channels 8t + 4 half + {0..3}
+            *p = add ? *p + v : v;
+        }
+}
+
+// (node kernels) gate partials PG[slot][c][e], same two-stage fold
 template <int NT>
 __device__ __forceinline__ void put_gate_partial(float* PG, const f32x16 (&gm)[NT], const f32x16 (&gl)[NT], int TP, int slot, int lane, bool add) {
     const int half = lane >> 5, l31 = lane & 31;
@@ -168,9 +190,8 @@ __device__ __forceinline__ void put_gate_partial(float* PG, const f32x16 (&gm)[N
 
 // hi / lo' images of the wave's fp32 state -> XH8 / XL8 (8 bytes per lane and group: channels 8q+4*half+{0..3})
 template <int MT, int NT>
-__device__ __forceinline__ bool store_state_x3(char* XH, char* XL, int gbase8, const f32x16 (&st)[MT][NT], int TP, int mt0, int lane) {
+__device__ __forceinline__ void store_state_x3(char* XH, char* XL, int gbase8, const f32x16 (&st)[MT][NT], int TP, int mt0, int lane, float& amax) {
     const int half = lane >> 5, l31 = lane & 31;
-    bool over = false;
 #pragma unroll
     for (int m = 0; m < MT; ++m)
 #pragma unroll
@@ -181,7 +202,7 @@ __device__ __forceinline__ bool store_state_x3(char* XH, char* XL, int gbase8, c
 #pragma unroll
                 for (int t = 0; t < 4; t += 2) {
                     const float x0 = st[m][n][4 * q + t], x1 = st[m][n][4 * q + t + 1];
-                    over |= fmaxf(fabsf(x0), fabsf(x1)) > X3_RANGE;
+                    amax = fmaxf(amax, fmaxf(fabsf(x0), fabsf(x1)));
                     h2 hi, lo;
                     split16x2(x0, x1, hi, lo);
                     vh[t] = hi[0]; vh[t + 1] = hi[1];
@@ -191,7 +212,13 @@ __device__ __forceinline__ bool store_state_x3(char* XH, char* XL, int gbase8, c
                 *(h4*)(XH + off) = vh;
                 *(h4*)(XL + off) = vl;
             }
-    return over;
+}
+
+template <int MT, int NT>
+__device__ __forceinline__ bool store_state_x3(char* XH, char* XL, int gbase8, const f32x16 (&st)[MT][NT], int TP, int mt0, int lane) {
+    float amax = 0.f;
+    store_state_x3<MT, NT>(XH, XL, gbase8, st, TP, mt0, lane, amax);
+    return amax > X3_RANGE;
 }
 
 __device__ __forceinline__ bool put16(char* XH, char* XL, int TP, int g8, int slot, int e, float x) {
@@ -203,141 +230,178 @@ __device__ __forceinline__ bool put16(char* XH, char* XL, int TP, int g8, int sl
     return fabsf(x) > X3_RANGE;
 }
 
-// pre-phase of a residual message GCP2 (H = 8, V_in = 32): same arithmetic as gcp2_pre, extended-K rows written as hi / lo'
-template <int T, int NTHR>
-__device__ __forceinline__ bool gcp2_pre_x3(const float* __restrict__ wdd, const float* VV, const float* FR, char* XH, char* XL,
-                                            int gN8, int gQ8, int gEnd8, float* VH, int e, int part) {
-    constexpr int H = 8, V_IN = GCDM_V, TP = T + 1, PARTS = NTHR / T, ROWS = H + 3, NH = (ROWS + PARTS - 1) / PARTS;
-    float ax[NH], ay[NH], az[NH];
-    const float* wrow[NH];
+// ---- the vector path of the message GCP2s on the matrix pipe ----------------------------------------------------------------
+// The per-edge vector contractions of a GCP2 -- vector_down / vector_down_frames ([11 x 32] . [32 x 3] per edge, gcpnet.py:442-459)
+// and vector_up ([32 x H] . [H x 3], :388-411) -- are GEMMs with a tiny M: as VALU FMAs they cost 13 % of the step for 2 % of the
+// FLOPs (8 threads share an edge and each re-reads all 96 vector components).  Here one wave per 16 edges ("vector wave" g = wave
+// < ET/16) evaluates them with v_mfma_f32_16x16x32_f16 (split precision, same error model as the scalar GEMMs):
+//   operand maps (lane l: q = l >> 4, n = l & 15):  A[row n][k = 8q + j]   B[k = 8q + j][col n]   D[row 4q + i][col n]
+//   columns = the wave's 16 edges, one MFMA set per spatial component x.
+// The fp32 master of the message vectors lives in LDS as float4 channel groups VV4[x][cg][e]; lane (q, n) owns groups cg = q and
+// 4 + q of edge n for the whole tile, which is at once
+//   * the D layout of vector_up (M-tile m = channels 16m .. 16m+15: rows 4q + i <-> channels 16m + 4q + i = group 4m + q), and
+//   * a valid B layout of vector_down, because the contraction order is free: k = 8q + j <-> channel (j < 4 ? 4q + j : 16 + 4q + j - 4)
+//     (the host packs A with that column permutation),
+// so finish(k) -> pre(k+1) runs on registers without any cross-lane traffic.  vector_down's D rows 0-7 (hidden vectors, lanes q < 2)
+// feed vector_up's B through a 16-byte image [hi(4) | lo'(4)] (k = 8q + j <-> hidden channel 4q + (j & 3); two MFMAs, A1 = [W_hi | 0],
+// A2 = [W_lo' | W_hi]); rows 8-10 (lanes q = 2) are the vector_down_frames vectors -> 9 frame scalars (scalarize).
+#define MFMA1632(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_f16((a), (b), (c), 0, 0, 0)
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void split4(const float (&x)[4], h4& hi, h4& lo, float& amax) {
 #pragma unroll
-    for (int i = 0; i < NH; ++i) {
-        ax[i] = ay[i] = az[i] = 0.f;
-        const int hh = part + PARTS * i;
-        wrow[i] = wdd + (hh < ROWS ? hh : ROWS - 1) * V_IN;
+    for (int s = 0; s < 4; s += 2) {
+        h2 a, b;
+        split16x2(x[s], x[s + 1], a, b);
+        hi[s] = a[0]; hi[s + 1] = a[1];
+        lo[s] = b[0]; lo[s + 1] = b[1];
+        amax = fmaxf(amax, fmaxf(fabsf(x[s]), fabsf(x[s + 1])));
     }
-    const float* vp = VV + e;
-#ifdef GCDM_X3_PRE_SKIP
-    bool any_row[NH];
-#pragma unroll
-    for (int i = 0; i < NH; ++i) any_row[i] = __any(part + PARTS * i < ROWS);      // wave-uniform
-#endif
-#pragma unroll 8
-    for (int c = 0; c < V_IN; ++c) {
-        const float vx = vp[0], vy = vp[TP], vz = vp[2 * TP];
-        vp += 3 * TP;
-#pragma unroll
-        for (int i = 0; i < NH; ++i) {
-#ifdef GCDM_X3_PRE_SKIP
-            // EXPERIMENTAL (off by default): rows are dealt out as hh = part + PARTS * i, and for i >= 1 only parts < ROWS - PARTS * i own a real row
-            // -- the others recompute row ROWS-1 and throw it away.  Skip those FMAs where the whole wave has none (bit-identical results).
-            if (i > 0 && !any_row[i]) continue;
-#endif
-            const float wc = wrow[i][c];
-            ax[i] += wc * vx; ay[i] += wc * vy; az[i] += wc * vz;
-        }
-    }
-    float f[9];
-#pragma unroll
-    for (int r = 0; r < 9; ++r) f[r] = FR[r * TP + e];
-    bool over = false;
-#pragma unroll
-    for (int i = 0; i < NH; ++i) {
-        const int hh = part + PARTS * i;
-        const float vx = ax[i], vy = ay[i], vz = az[i];
-        if (hh < H) {
-            over |= put16(XH, XL, TP, gN8 + (hh >> 3), hh & 7, e, sqrtf(vx * vx + vy * vy + vz * vz + 1e-8f) + 1e-8f);
-            VH[(hh * 3 + 0) * TP + e] = vx;
-            VH[(hh * 3 + 1) * TP + e] = vy;
-            VH[(hh * 3 + 2) * TP + e] = vz;
-        } else if (hh < ROWS) {
-            const int k = hh - H;
-#pragma unroll
-            for (int r = 0; r < 3; ++r) {
-                const int idx = 3 * k + r;
-                over |= put16(XH, XL, TP, gQ8 + (idx >> 3), idx & 7, e, f[3 * r] * vx + f[3 * r + 1] * vy + f[3 * r + 2] * vz);
-            }
-        }
-    }
-    if (part == PARTS - 1) {  // zero the padding slots (weights there are zero, LDS is not)
-        for (int idx = 9; idx < 16; ++idx) put16(XH, XL, TP, gQ8 + (idx >> 3), idx & 7, e, 0.f);
-        for (int g = gQ8 + 2; g < gEnd8; ++g) {
-            *(v4f*)(XH + (g * TP + e) * 16) = (v4f){0.f, 0.f, 0.f, 0.f};
-            *(v4f*)(XL + (g * TP + e) * 16) = (v4f){0.f, 0.f, 0.f, 0.f};
-        }
-    }
-    return over;
 }
 
-#ifdef GCDM_X3_PRE_MFMA
-// EXPERIMENTAL (off by default, not yet run on a GPU; data movement validated by tools/emu/pre_mfma_plan.py): the pre-phase of a residual
-// message GCP2 on the matrix pipe.  [W_down; W_frames] (11 x 32, padded to 16 rows) x v (32 channels x {x,y,z} x edges) is one
-// v_mfma_f32_16x16x32_f16 per component and 16 edges (x3 for the split precision): wave w < T/16 takes edges 16w..16w+15.
-//   A: lane l = row l&15, k = 8(l>>4)+j (host-packed)      B: lane l = edge l&15, channel 8(l>>4)+j      D: lane l = edge l&15, rows 4(l>>4)+i
-// so lanes 0-31 end up with the 8 hidden vectors (norms -> extended-K rows, vectors -> VH), lanes 32-47 with the three W_frames
-// vectors (-> 9 frame scalars) and lanes 48-63 write the zero padding.  Replaces 192 FMAs + 96 LDS reads + 64 per-lane weight loads
-// per thread on all waves (8.3 % of the QM9 step) by 24 LDS reads, 12 pair splits and 9 small MFMAs on T/16 waves.
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-template <int T>
-__device__ __forceinline__ bool gcp2_pre_mfma(const h8* __restrict__ wddH, const h8* __restrict__ wddL, const float* VV, const float* FR, char* XH,
-                                              char* XL, int gN8, int gQ8, int gEnd8, float* VH, int wave, int lane) {
-    constexpr int TP = T + 1;
-    bool over = false;
-    if (wave < T / 16) {
-        const int e = 16 * wave + (lane & 15), q = lane >> 4;
-        const h8 aH = wddH[lane], aL = wddL[lane];
-        float o[3][4];
+__device__ __forceinline__ h8 cat44(h4 a, h4 b) { return (h8){a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]}; }
+
+// vector_down + vector_down_frames of residual GCP2 `k` from the lane's own groups (va = group q, vb = group 4 + q) of the message
+// vectors: norms and frame scalars -> extended-K rows of the scalar GEMM (groups 32 | 33, 34 | 35 of XH8 / XL8), hidden vectors -> VHB.
+template <int ET>
+__device__ __forceinline__ void vec_pre_mfma(const h8 aH, const h8 aL, const v4f (&va)[3], const v4f (&vb)[3], const float* FR, char* XH, char* XL,
+                                             h8* VHB, int ve, int vq, float& amax) {
+    constexpr int ETP = ET + 1;
+    float o[3][4];
 #pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            h8 bh, bl;
+    for (int x = 0; x < 3; ++x) {
+        const float b0[4] = {va[x][0], va[x][1], va[x][2], va[x][3]}, b1[4] = {vb[x][0], vb[x][1], vb[x][2], vb[x][3]};
+        h4 h0, l0, h1, l1;
+        split4(b0, h0, l0, amax);
+        split4(b1, h1, l1, amax);
+        const h8 bh = cat44(h0, h1), bl = cat44(l0, l1);
+        f32x4 am = {0.f, 0.f, 0.f, 0.f}, al = {0.f, 0.f, 0.f, 0.f};
+        am = MFMA1632(aH, bh, am);
+        al = MFMA1632(aH, bl, al);
+        al = MFMA1632(aL, bh, al);
 #pragma unroll
-            for (int j = 0; j < 8; j += 2) {
-                const float x0 = VV[((q * 8 + j) * 3 + k) * TP + e], x1 = VV[((q * 8 + j + 1) * 3 + k) * TP + e];
-                over |= fmaxf(fabsf(x0), fabsf(x1)) > X3_RANGE;
-                h2 hi, lo;
-                split16x2(x0, x1, hi, lo);
-                bh[j] = hi[0]; bh[j + 1] = hi[1];
-                bl[j] = lo[0]; bl[j + 1] = lo[1];
-            }
-            f32x4 am = {0.f, 0.f, 0.f, 0.f}, al = {0.f, 0.f, 0.f, 0.f};
-            am = __builtin_amdgcn_mfma_f32_16x16x32_f16(aH, bh, am, 0, 0, 0);
-            al = __builtin_amdgcn_mfma_f32_16x16x32_f16(aH, bl, al, 0, 0, 0);
-            al = __builtin_amdgcn_mfma_f32_16x16x32_f16(aL, bh, al, 0, 0, 0);
+        for (int i = 0; i < 4; ++i) o[x][i] = am[i] + al[i] * X3_INV_SCALE;
+    }
+    if (vq < 2) {                       // rows 4q .. 4q+3 of W_down: norms -> extended-K group 32, hidden vectors -> VHB (gcpnet.py:442-452)
+        float nr[4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) o[k][i] = am[i] + al[i] * X3_INV_SCALE;
+        for (int i = 0; i < 4; ++i) nr[i] = sqrtf(o[0][i] * o[0][i] + o[1][i] * o[1][i] + o[2][i] * o[2][i] + 1e-8f) + 1e-8f;
+        h4 nh, nl;
+        split4(nr, nh, nl, amax);
+        const int off = (32 * ETP + ve) * 16 + 8 * vq;
+        *(h4*)(XH + off) = nh;
+        *(h4*)(XL + off) = nl;
+#pragma unroll
+        for (int x = 0; x < 3; ++x) {
+            h4 vh, vl;
+            split4(o[x], vh, vl, amax);
+            VHB[(x * 2 + vq) * ET + ve] = cat44(vh, vl);
         }
-        if (q < 2) {                    // rows 4q..4q+3 of W_down: hidden vectors -> VH, their norms -> extended-K rows (gcpnet.py:442-452)
+    } else if (vq == 2) {               // rows 8..10 = W_frames: q[3j + r] = F[r,:] . u_j (scalarize, components/__init__.py:174-219)
+        float f[9];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int r = 4 * q + i;
-                const float vx = o[0][i], vy = o[1][i], vz = o[2][i];
-                over |= put16(XH, XL, TP, gN8 + (r >> 3), r & 7, e, sqrtf(vx * vx + vy * vy + vz * vz + 1e-8f) + 1e-8f);
-                VH[(r * 3 + 0) * TP + e] = vx;
-                VH[(r * 3 + 1) * TP + e] = vy;
-                VH[(r * 3 + 2) * TP + e] = vz;
-            }
-        } else if (q == 2) {            // rows 8..10 = W_frames: q[3j + r] = F[r,:] . u_j (scalarize, components/__init__.py:174-219)
-            float f[9];
+        for (int r = 0; r < 9; ++r) f[r] = FR[r * ETP + ve];
+        float qv[12];
 #pragma unroll
-            for (int r = 0; r < 9; ++r) f[r] = FR[r * TP + e];
+        for (int j = 0; j < 3; ++j)
 #pragma unroll
-            for (int j = 0; j < 3; ++j)
+            for (int r = 0; r < 3; ++r) qv[3 * j + r] = f[3 * r] * o[0][j] + f[3 * r + 1] * o[1][j] + f[3 * r + 2] * o[2][j];
+        qv[9] = qv[10] = qv[11] = 0.f;
+        h4 h[3], l[3];
 #pragma unroll
-                for (int r = 0; r < 3; ++r) {
-                    const int idx = 3 * j + r;
-                    over |= put16(XH, XL, TP, gQ8 + (idx >> 3), idx & 7, e, f[3 * r] * o[0][j] + f[3 * r + 1] * o[1][j] + f[3 * r + 2] * o[2][j]);
-                }
-        } else {                        // zero the padding slots (weights there are zero, LDS is not)
-            for (int idx = 9; idx < 16; ++idx) put16(XH, XL, TP, gQ8 + (idx >> 3), idx & 7, e, 0.f);
-            for (int g = gQ8 + 2; g < gEnd8; ++g) {
-                *(v4f*)(XH + (g * TP + e) * 16) = (v4f){0.f, 0.f, 0.f, 0.f};
-                *(v4f*)(XL + (g * TP + e) * 16) = (v4f){0.f, 0.f, 0.f, 0.f};
-            }
+        for (int t = 0; t < 3; ++t) {
+            const float part[4] = {qv[4 * t], qv[4 * t + 1], qv[4 * t + 2], qv[4 * t + 3]};
+            split4(part, h[t], l[t], amax);
+        }
+        const h4 z4 = {(_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f};
+        *(h8*)(XH + (33 * ETP + ve) * 16) = cat44(h[0], h[1]);
+        *(h8*)(XL + (33 * ETP + ve) * 16) = cat44(l[0], l[1]);
+        *(h8*)(XH + (34 * ETP + ve) * 16) = cat44(h[2], z4);
+        *(h8*)(XL + (34 * ETP + ve) * 16) = cat44(l[2], z4);
+    } else {                            // zero the padding group (weights there are zero, LDS is not)
+        const h4 z4 = {(_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f};
+        *(h8*)(XH + (35 * ETP + ve) * 16) = cat44(z4, z4);
+        *(h8*)(XL + (35 * ETP + ve) * 16) = cat44(z4, z4);
+    }
+}
+
+// sigmoid(gate) of the four channels 16m + 4q + {0..3} of edge ve (gcpnet.py:396-401)
+template <int ET>
+__device__ __forceinline__ v4f vec_gate(const float* PG, const float* __restrict__ bg, int m, int ve, int vq) {
+    v4f g = *(const v4f*)(bg + 16 * m + 4 * vq);
+#pragma unroll
+    for (int s = 0; s < 4; ++s) g += *(const v4f*)(PG + pg_off<ET>(s, ve, 4 * m + vq));
+#pragma unroll
+    for (int i = 0; i < 4; ++i) g[i] = fast_sigmoid(g[i]);
+    return g;
+}
+
+// vector_up + gate of residual GCP2 `k` and the residual update of the message vectors (gcpnet.py:388-411, 701): va / vb <- updated groups
+template <int ET>
+__device__ __forceinline__ void vec_finish_mfma(const h8* __restrict__ a1, const h8* __restrict__ a2, const float* PG, const float* __restrict__ bg,
+                                                const h8* VHB, v4f* VV4, int ve, int vq, int lane, v4f (&va)[3], v4f (&vb)[3]) {
+    constexpr int ETP = ET + 1;
+    const h8 w1[2] = {a1[lane], a1[64 + lane]}, w2[2] = {a2[lane], a2[64 + lane]};
+    h8 b[3];
+#pragma unroll
+    for (int x = 0; x < 3; ++x) b[x] = VHB[(x * 2 + (vq & 1)) * ET + ve];     // lanes q >= 2 read a finite image, their A columns are zero
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+        const v4f sg = vec_gate<ET>(PG, bg, m, ve, vq);
+#pragma unroll
+        for (int x = 0; x < 3; ++x) {
+            f32x4 am = {0.f, 0.f, 0.f, 0.f}, al = {0.f, 0.f, 0.f, 0.f};
+            am = MFMA1632(w1[m], b[x], am);
+            al = MFMA1632(w2[m], b[x], al);
+            v4f* p = &VV4[(x * 8 + 4 * m + vq) * ETP + ve];
+            v4f v = *p;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[i] += (am[i] + al[i] * X3_INV_SCALE) * sg[i];
+            *p = v;
+            if (m == 0) va[x] = v; else vb[x] = v;
         }
     }
-    return over;
 }
-#endif
+
+// vector_up + gate of msg0 (H0 hidden vectors, written as fp32 rows VH[h*3 + x][e] by the pre-phase P1): va / vb <- message vectors
+template <int ET, int H0>
+__device__ __forceinline__ void vec_finish0_mfma(const h8* __restrict__ aH, const h8* __restrict__ aL, const float* PG, const float* __restrict__ bg,
+                                                 const float* VH, v4f* VV4, int ve, int vq, int lane, v4f (&va)[3], v4f (&vb)[3], float& amax) {
+    constexpr int ETP = ET + 1;
+    static_assert(H0 <= 32, "one k-block");
+    const h8 wH[2] = {aH[lane], aH[64 + lane]}, wL[2] = {aL[lane], aL[64 + lane]};
+    h8 bh[3], bl[3];
+#pragma unroll
+    for (int x = 0; x < 3; ++x) {
+        float v0[4], v1[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            v0[j] = VH[(min(8 * vq + j, H0 - 1) * 3 + x) * ETP + ve];         // rows >= H0: any finite value (A is zero there)
+            v1[j] = VH[(min(8 * vq + 4 + j, H0 - 1) * 3 + x) * ETP + ve];
+        }
+        h4 h0, l0, h1, l1;
+        split4(v0, h0, l0, amax);
+        split4(v1, h1, l1, amax);
+        bh[x] = cat44(h0, h1);
+        bl[x] = cat44(l0, l1);
+    }
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+        const v4f sg = vec_gate<ET>(PG, bg, m, ve, vq);
+#pragma unroll
+        for (int x = 0; x < 3; ++x) {
+            f32x4 am = {0.f, 0.f, 0.f, 0.f}, al = {0.f, 0.f, 0.f, 0.f};
+            am = MFMA1632(wH[m], bh[x], am);
+            al = MFMA1632(wH[m], bl[x], al);
+            al = MFMA1632(wL[m], bh[x], al);
+            v4f v;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[i] = (am[i] + al[i] * X3_INV_SCALE) * sg[i];
+            VV4[(x * 8 + 4 * m + vq) * ETP + ve] = v;
+            if (m == 0) va[x] = v; else vb[x] = v;
+        }
+    }
+}
 
 struct EdgeMsgX3Args {
     EdgeMsgArgs base;                 // everything the fp32 kernel takes (tables, biases, vector weights, attention)
@@ -346,9 +410,10 @@ struct EdgeMsgX3Args {
     const h8* wH[3]; const h8* wL[3]; int KB;       // msg1..3 scalar_out, packed [8][KB][64]
     const h8* wgH[3]; const h8* wgL[3];
     uint32_t* flags_dev;                            // bit GCDM_FLAG_F16_RANGE
-#ifdef GCDM_X3_PRE_MFMA
-    const h8* wddH[3]; const h8* wddL[3];           // msg1..3 [W_down; W_frames] (11 x 32 -> 16 x 32) as the A operand of one 16x16x32 MFMA, [64 lanes] x 8 f16
-#endif
+    // vector path (16x16x32 A operands, [64 lanes] x 8 f16 each; packing: gcdm_api.hip pack_vec_*)
+    const h8* vpH[3]; const h8* vpL[3];             // msg1..3 [W_down; W_frames] (11 x 32 -> 16 x 32), K permuted to the VV4 lane ownership
+    const h8* vf1[3]; const h8* vf2[3];             // msg1..3 vector_up [32 x 8] as two M-tiles: A1 = [W_hi | 0], A2 = [W_lo' | W_hi]
+    const h8* vf0H; const h8* vf0L;                 // msg0 vector_up [32 x H0] as two M-tiles, K = hidden channel
 };
 
 #define GCDM_FLAG_F16_RANGE_BIT 8u
@@ -368,7 +433,6 @@ __global__ __launch_bounds__(ET * 8) __attribute__((amdgpu_waves_per_eu(2, 2))) 
     char* XL = XH + X3_GROUPS8 * ETP * 16;              // [36][65] x 16 B : lo' images
     static_assert(2 * X3_GROUPS8 * ETP * 16 <= Geo::OFF_VV, "XH8/XL8 must fit the fp32 XS4 region");
     v4f* XS4 = (v4f*)(smem + Geo::OFF_XS);              // fp32 alias, used after the last GEMM (attention + aggregation)
-    float* VV = (float*)(smem + Geo::OFF_VV);
     float* VH = (float*)(smem + Geo::OFF_VH);
     float* PG = (float*)(smem + Geo::OFF_PG);
     float* FR = (float*)(smem + Geo::OFF_FR);
@@ -520,6 +584,13 @@ __global__ __launch_bounds__(ET * 8) __attribute__((amdgpu_waves_per_eu(2, 2))) 
     f32x16 gm[NT], gl[NT];
     const h8* xh8 = (const h8*)XH;
     const h8* xl8 = (const h8*)XL;
+    // vector path: wave g < ET/16 owns edges 16g .. 16g+15 (lane: q = lane >> 4, edge 16g + (lane & 15))
+    constexpr int NVW = ET / 16;
+    const bool vwave = wave < NVW;
+    const int vq = lane >> 4, ve = 16 * wave + (lane & 15);
+    v4f* VV4 = (v4f*)(smem + Geo::OFF_VV);               // [3][8][ETP] float4: message vectors, component x, channel group cg, edge
+    h8* VHB = (h8*)(smem + Geo::OFF_VHB);                // [3][2][ET]: hidden vectors of the current GCP2 as [hi(4) | lo'(4)] images
+    float amax = 0.f;                                    // largest |x| that went into an f16 image (range guard)
 
     // ---- P2: msg0 GEMM ----------------------------------------------------------------------------------------------------
     {
@@ -553,24 +624,24 @@ __global__ __launch_bounds__(ET * 8) __attribute__((amdgpu_waves_per_eu(2, 2))) 
 #pragma unroll
             for (int r = 0; r < 16; ++r) { gm[n][r] = 0.f; gl[n][r] = 0.f; }
         gate_partial_x3<MT, NT>(gm, gl, st, ax.wg0H, ax.wg0L, mt0, lane);
-        if (NW == 4) {               // four partials = the four slots vec_finish sums: no fold needed
-            put_gate_partial<NT>(PG, gm, gl, ETP, wave, lane, false);
+        if (NW == 4) {               // four partials = the four slots the vector waves sum: no fold needed
+            put_gate_partial<NT, ET>(PG, gm, gl, wave, lane, false);
         } else {
-            if (wave < 4) put_gate_partial<NT>(PG, gm, gl, ETP, wave, lane, false);
+            if (wave < 4) put_gate_partial<NT, ET>(PG, gm, gl, wave, lane, false);
             __syncthreads();
-            if (wave >= 4) put_gate_partial<NT>(PG, gm, gl, ETP, wave - 4, lane, true);
+            if (wave >= 4) put_gate_partial<NT, ET>(PG, gm, gl, wave - 4, lane, true);
         }
         STAMP(6);
     }
     __syncthreads();
     STAMP(7);
-    // ---- P3: state images + vector part of msg0 ---------------------------------------------------------------------------
-    over |= store_state_x3<MT, NT>(XH, XL, 0, st, ETP, mt0, lane);
-    vec_finish<ET, H0, EK_THREADS>(PG, a.bg0, a.wup0, GCDM_V, VH, e, part, [&](int c, float ox, float oy, float oz) {
-        VV[(c * 3 + 0) * ETP + e] = ox;
-        VV[(c * 3 + 1) * ETP + e] = oy;
-        VV[(c * 3 + 2) * ETP + e] = oz;
-    });
+    // ---- P3: state images (all waves) | vector part of msg0 and pre-phase of the first residual GCP2 (vector waves) ----------
+    store_state_x3<MT, NT>(XH, XL, 0, st, ETP, mt0, lane, amax);
+    if (vwave) {
+        v4f va[3], vb[3];
+        vec_finish0_mfma<ET, H0>(ax.vf0H, ax.vf0L, PG, a.bg0, VH, VV4, ve, vq, lane, va, vb, amax);
+        vec_pre_mfma<ET>(ax.vpH[0][lane], ax.vpL[0][lane], va, vb, FR, XH, XL, VHB, ve, vq, amax);
+    }
     STAMP(8);
     __syncthreads();
     STAMP(9);
@@ -578,14 +649,6 @@ __global__ __launch_bounds__(ET * 8) __attribute__((amdgpu_waves_per_eu(2, 2))) 
     // ---- residual message GCP2s k = 1..3 ---------------------------------------------------------------------------------
     for (int k = 0; k < 3; ++k) {
         const GcpW& w = a.mk[k];
-#ifdef GCDM_X3_PRE_MFMA
-        over |= gcp2_pre_mfma<ET>(ax.wddH[k], ax.wddL[k], VV, FR, XH, XL, 32, 33, 36, VH, wave, lane);
-#else
-        over |= gcp2_pre_x3<ET, EK_THREADS>(w.wdd, VV, FR, XH, XL, 32, 33, 36, VH, e, part);
-#endif
-        if (k == 0) STAMP(10);
-        __syncthreads();
-        if (k == 0) STAMP(11);
         acc_init_bias<MT, NT>(am, w.b, mt0, lane);
 #pragma unroll
         for (int m = 0; m < MT; ++m)
@@ -593,9 +656,8 @@ __global__ __launch_bounds__(ET * 8) __attribute__((amdgpu_waves_per_eu(2, 2))) 
             for (int n = 0; n < NT; ++n)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) al2[m][n][r] = 0.f;
-        if (k == 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); STAMP(21); }
+        if (k == 0) STAMP(10);
         tile_gemm_x3<MT, NT, PD, 18>(am, al2, ring, ax.wH[k] + (size_t)mt0 * 18 * 64, ax.wL[k] + (size_t)mt0 * 18 * 64, 18, xh8, xl8, ETP, lane);
-        if (k == 0) STAMP(22);
         if (k < 2) x3_prefetch<MT, PD>(ring, ax.wH[k + 1] + (size_t)mt0 * 18 * 64, ax.wL[k + 1] + (size_t)mt0 * 18 * 64, 18, lane);
         if (k == 0) STAMP(12);
 #pragma unroll
@@ -611,14 +673,14 @@ __global__ __launch_bounds__(ET * 8) __attribute__((amdgpu_waves_per_eu(2, 2))) 
             for (int r = 0; r < 16; ++r) { gm[n][r] = 0.f; gl[n][r] = 0.f; }
         gate_partial_x3<MT, NT>(gm, gl, am, ax.wgH[k], ax.wgL[k], mt0, lane);
         if (NW == 4) {
-            put_gate_partial<NT>(PG, gm, gl, ETP, wave, lane, false);
+            put_gate_partial<NT, ET>(PG, gm, gl, wave, lane, false);
         } else {
-            if (wave < 4) put_gate_partial<NT>(PG, gm, gl, ETP, wave, lane, false);
+            if (wave < 4) put_gate_partial<NT, ET>(PG, gm, gl, wave, lane, false);
             __syncthreads();
-            if (wave >= 4) put_gate_partial<NT>(PG, gm, gl, ETP, wave - 4, lane, true);
+            if (wave >= 4) put_gate_partial<NT, ET>(PG, gm, gl, wave - 4, lane, true);
         }
         if (k == 0) STAMP(14);
-        __syncthreads();                 // every wave is done reading the old XH8 / XL8 images
+        __syncthreads();                 // every wave is done reading the old XH8 / XL8 images; gate partials complete
         if (k == 0) STAMP(15);
 #pragma unroll
         for (int m = 0; m < MT; ++m)
@@ -627,20 +689,21 @@ __global__ __launch_bounds__(ET * 8) __attribute__((amdgpu_waves_per_eu(2, 2))) 
 #pragma unroll
                 for (int r = 0; r < 16; ++r) st[m][n][r] += am[m][n][r];       // residual add in fp32 (gcpnet.py:701)
         if (k < 2) {
-            over |= store_state_x3<MT, NT>(XH, XL, 0, st, ETP, mt0, lane);
+            store_state_x3<MT, NT>(XH, XL, 0, st, ETP, mt0, lane, amax);
         } else {                          // last GCP2: fp32 image for attention + segment sums (aliases XH8 / XL8)
             store_state<MT, NT, false>(XS4, 0, st, ETP, mt0, lane, 0);
         }
-        vec_finish<ET, 8, EK_THREADS>(PG, w.bg, w.wup, GCDM_V, VH, e, part, [&](int c, float ox, float oy, float oz) {
-            VV[(c * 3 + 0) * ETP + e] += ox;
-            VV[(c * 3 + 1) * ETP + e] += oy;
-            VV[(c * 3 + 2) * ETP + e] += oz;
-        });
+        if (vwave) {                      // vector part of this GCP2, then the pre-phase of the next one from the same registers
+            v4f va[3], vb[3];
+            vec_finish_mfma<ET>(ax.vf1[k], ax.vf2[k], PG, w.bg, VHB, VV4, ve, vq, lane, va, vb);
+            if (k < 2) vec_pre_mfma<ET>(ax.vpH[k + 1][lane], ax.vpL[k + 1][lane], va, vb, FR, XH, XL, VHB, ve, vq, amax);
+        }
         if (k == 0) STAMP(16);
         __syncthreads();
         if (k == 0) STAMP(17);
     }
     STAMP(18);
+    over |= amax > X3_RANGE;
     if (__any(over) && lane == 0) atomicOr(ax.flags_dev, GCDM_FLAG_F16_RANGE_BIT);
 
     // ---- scalar message attention + aggregation: identical to the fp32 kernel (fp32 data) ---------------------------------
@@ -682,9 +745,10 @@ __global__ __launch_bounds__(ET * 8) __attribute__((amdgpu_waves_per_eu(2, 2))) 
                     for (int t = 0; t < 4; ++t) atomicAdd(dst + 4 * un + t, s[t]);
                 }
             } else {
-                const int r = un - GCDM_SG;
+                const int r = un - GCDM_SG, c = r / 3, comp = r - 3 * c;      // AGG column S + 3c + comp (reference flatten layout)
+                const float* vp = (const float*)(VV4 + (comp * 8 + (c >> 2)) * ETP) + (c & 3);
                 float s = 0.f;
-                for (int x = sb; x < en; ++x) s += VV[r * ETP + x];
+                for (int x = sb; x < en; ++x) s += vp[4 * x];
                 if (whole) dst[GCDM_S + r] = s;
                 else atomicAdd(dst + GCDM_S + r, s);
             }

@@ -1,0 +1,81 @@
+"""Long-horizon golden: the REFERENCE's own `mol_gen_sample` (src/models/components/variational_diffusion.py:1282-1412), free-running on a
+noise tape for the FULL 1000 steps at full width (QM9 production architecture, 4 molecules n = 5, 19, 3, 11, seed-recreated weights x 0.25),
+once in fp32 and once with the same code in fp64 (the adjudicator).  Stored: the latent z after the step to s = 900, 800, ..., 0 and
+after selected early steps, and the final decode.  -> tests/golden/long_full_qm9.npz   (contract (iii))
+
+    python tests/golden/make_long_golden.py        (build container only; ~10 min of CPU)
+
+Only data is stored (inputs = num_nodes + seeds, outputs); the weights are re-created from `synth.make_weights(..., seed=LONG_WEIGHT_SEED,
+scale_2d=0.25)` and the noise from `TapeNoise(LONG_NOISE_SEED)` wherever the fixture is used.
+"""
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path[:0] = [HERE, os.path.dirname(HERE), os.path.dirname(os.path.dirname(HERE))]
+import ref_harness as rh  # noqa: E402
+import synth  # noqa: E402
+
+torch.set_num_threads(8)
+
+LONG_WEIGHT_SEED = 61
+LONG_NOISE_SEED = 4321
+SIZES = [5, 19, 3, 11]
+CHECKPOINTS = [999, 990, 950] + list(range(900, -1, -100))      # z after the step that lands on s
+
+
+def run(dtype):
+    prev = torch.get_default_dtype()
+    torch.set_default_dtype(dtype)          # the reference hard-wires the default dtype in localize / scalarize
+    try:
+        cfgs = rh.load_reference_cfgs("qm9", ())
+        d = synth.DATASET_DIMS["qm9"]
+        net = rh.build_reference_dynamics(cfgs, seed=0)
+        shapes = synth.dynamics_shapes(d["S"], d["V"], d["Se"], d["Ve"], d["L"], synth.dims_h_in(d))
+        net.load_state_dict(synth.make_weights(shapes, seed=LONG_WEIGHT_SEED, scale_2d=0.25))
+        net = net.to(dtype)
+        ddpm = rh.build_reference_ddpm(cfgs, net, "qm9").to(dtype)
+        nn_ = torch.tensor(SIZES)
+        zs = {}
+        orig = ddpm.sample_p_zs_given_zt
+
+        def spy(*a, **kw):                  # observes the reference's own step (no change of behaviour)
+            out = orig(*a, **kw)
+            s = int(round(float(kw["s"].flatten()[0]) * 1000))
+            if s in CHECKPOINTS:
+                zs[s] = out.detach().clone()
+            return out
+
+        ddpm.sample_p_zs_given_zt = spy
+        t0 = time.time()
+        with rh.NoiseTape(LONG_NOISE_SEED) as tape, torch.no_grad():
+            xh, bi, _ = ddpm.mol_gen_sample(num_samples=len(nn_), num_nodes=nn_, device="cpu")
+        print(f"{dtype}: {time.time() - t0:.0f} s, {len(tape.calls)} randn calls, max|x| = {xh[:, :3].abs().max().item():.3e}", flush=True)
+        return xh, zs
+    finally:
+        torch.set_default_dtype(prev)
+
+
+def main():
+    assert rh.reference_available(), "reference checkout not found"
+    x32, z32 = run(torch.float32)
+    x64, z64 = run(torch.float64)
+    out = dict(num_nodes=np.array(SIZES), weight_seed=LONG_WEIGHT_SEED, weight_scale=0.25, noise_seed=LONG_NOISE_SEED, T=1000,
+               checkpoints=np.array(CHECKPOINTS), final32=x32.float().numpy(), final64=x64.double().numpy())
+    for s in CHECKPOINTS:
+        out[f"z32_{s}"] = z32[s].float().numpy()
+        out[f"z64_{s}"] = z64[s].double().numpy()
+        gap = (z32[s].double() - z64[s]).abs().max().item()
+        print(f"s={s:4d}  max|z| = {z64[s].abs().max().item():.4e}   |ref32 - ref64| = {gap:.3e}")
+    print("final: |ref32 - ref64| x =", (x32[:, :3].double() - x64[:, :3]).abs().max().item(), " discrete equal:", bool((x32[:, 3:].double() == x64[:, 3:]).all()))
+    path = os.path.join(HERE, "long_full_qm9.npz")
+    np.savez_compressed(path, **out)
+    print(f"wrote {path} ({os.path.getsize(path) / 1024:.0f} KiB)")
+
+
+if __name__ == "__main__":
+    main()
