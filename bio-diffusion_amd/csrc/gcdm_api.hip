@@ -560,12 +560,15 @@ int gcdm_finalize_weights(gcdm_handle* h) {
             const std::string p = lp + "interaction.message_fusion." + std::to_string(k) + ".";
             if (!build_gcp(h, pool, p, S, V, S, V, 4, false, o.mk[k - 1])) return -1;
             // split-precision images: K' = [m.s (256) | n (8) | q (9 -> 16) | pad] = 288
-            WView ws, wg;
-            if (!get_w(h, p + "scalar_out.weight", S, S + 8 + 9, ws) || !get_w(h, p + "vector_out_scale.weight", V, S, wg)) return -1;
+            WView ws, wg, wb;
+            if (!get_w(h, p + "scalar_out.weight", S, S + 8 + 9, ws) || !get_w(h, p + "vector_out_scale.weight", V, S, wg) ||
+                !get_w(h, p + "scalar_out.bias", 1, S, wb))
+                return -1;
             Dense Wx(S, 288);
             for (int m = 0; m < S; ++m) {
                 for (int kk = 0; kk < S + 8; ++kk) Wx.at(m, kk) = ws.at(m, kk);
                 for (int kk = 0; kk < 9; ++kk) Wx.at(m, S + 8 + kk) = ws.at(m, S + 8 + kk);
+                Wx.at(m, 287) = wb.at(0, m);      // last extended-K row: the kernel keeps a constant 1 there (bias as a weight column)
             }
             std::vector<float> xh, xl;
             pack_x3(Wx, xh, xl);

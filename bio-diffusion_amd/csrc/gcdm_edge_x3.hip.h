@@ -14,6 +14,7 @@
 //     GCDM_FLAG_F16_RANGE is raised and the caller re-runs in fp32 mode.
 #pragma once
 #include "gcdm_kernels.hip.h"
+#include <type_traits>
 
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef _Float16 h4 __attribute__((ext_vector_type(4)));
@@ -121,10 +122,62 @@ __device__ __forceinline__ void tile_gemm_x3(f32x16 (&am)[MT][NT], f32x16 (&al)[
         if (k0 + r < KB) body(r);
 }
 
+// Fully unrolled variant for compile-time k-block counts whose FIRST block starts the accumulators from the MFMA's inline zero C operand
+// (ZAM: the main accumulator too; ZAL: the 2^-11-scaled one) -- saves the v_mov initialisation of 16 registers per accumulator tile.
+template <int I0, int I1, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I0 < I1) {
+        f(std::integral_constant<int, I0>{});
+        static_for<I0 + 1, I1>(f);
+    }
+}
+
+template <int MT, int NT, int PD, int KB, bool ZAM, bool ZAL>
+__device__ __forceinline__ void tile_gemm_x3z(f32x16 (&am)[MT][NT], f32x16 (&al)[MT][NT], X3Ring<MT, PD>& ring, const h8* __restrict__ wH,
+                                              const h8* __restrict__ wL, const h8* xh8, const h8* xl8, int TP, int lane) {
+    constexpr int R = PD + 1;
+    constexpr int wstride = KB * 64;
+    const h8* wh = wH + lane + PD * 64;
+    const h8* wl = wL + lane + PD * 64;
+    const int boff = (lane >> 5) * TP + (lane & 31);
+    const h8* sh = xh8 + boff;
+    const h8* sl = xl8 + boff;
+    h8 bh[2][NT], bl[2][NT];
+    const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int n = 0; n < NT; ++n) { bh[0][n] = sh[n * 32]; bl[0][n] = sl[n * 32]; }
+    static_for<0, KB>([&](auto rc) {
+        constexpr int r = decltype(rc)::value;
+#pragma unroll
+        for (int m = 0; m < MT; ++m) { ring.ah[(r + PD) % R][m] = wh[m * wstride]; ring.alo[(r + PD) % R][m] = wl[m * wstride]; }
+        wh += 64;
+        wl += 64;
+        sh += 2 * TP;
+        sl += 2 * TP;
+#pragma unroll
+        for (int n = 0; n < NT; ++n) { bh[(r + 1) & 1][n] = sh[n * 32]; bl[(r + 1) & 1][n] = sl[n * 32]; }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int n = 0; n < NT; ++n) am[m][n] = MFMA16(ring.ah[r % R][m], bh[r & 1][n], (ZAM && r == 0) ? zero : am[m][n]);
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int n = 0; n < NT; ++n) al[m][n] = MFMA16(ring.ah[r % R][m], bl[r & 1][n], (ZAL && r == 0) ? zero : al[m][n]);
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int n = 0; n < NT; ++n) al[m][n] = MFMA16(ring.alo[r % R][m], bh[r & 1][n], al[m][n]);
+        __builtin_amdgcn_sched_barrier(0);
+    });
+}
+
 // gate partial from registers: contraction over the channels this wave holds (two 16-deep blocks per M-tile)
-template <int MT, int NT>
+template <int MT, int NT, bool ZERO = false>
 __device__ __forceinline__ void gate_partial_x3(f32x16 (&gm)[NT], f32x16 (&gl)[NT], const f32x16 (&act)[MT][NT], const h8* __restrict__ wgH,
                                                 const h8* __restrict__ wgL, int mt0, int lane) {
+    const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int m = 0; m < MT; ++m)
 #pragma unroll
@@ -142,9 +195,9 @@ __device__ __forceinline__ void gate_partial_x3(f32x16 (&gm)[NT], f32x16 (&gl)[N
                     bl[n][s] = lo[0]; bl[n][s + 1] = lo[1];
                 }
 #pragma unroll
-            for (int n = 0; n < NT; ++n) gm[n] = MFMA16(aH, bh[n], gm[n]);
+            for (int n = 0; n < NT; ++n) gm[n] = MFMA16(aH, bh[n], (ZERO && m == 0 && j == 0) ? zero : gm[n]);
 #pragma unroll
-            for (int n = 0; n < NT; ++n) gl[n] = MFMA16(aH, bl[n], gl[n]);
+            for (int n = 0; n < NT; ++n) gl[n] = MFMA16(aH, bl[n], (ZERO && m == 0 && j == 0) ? zero : gl[n]);
 #pragma unroll
             for (int n = 0; n < NT; ++n) gl[n] = MFMA16(aL, bh[n], gl[n]);
         }
@@ -245,6 +298,16 @@ __device__ __forceinline__ bool put16(char* XH, char* XL, int TP, int g8, int sl
 // so finish(k) -> pre(k+1) runs on registers without any cross-lane traffic.  vector_down's D rows 0-7 (hidden vectors, lanes q < 2)
 // feed vector_up's B through a 16-byte image [hi(4) | lo'(4)] (k = 8q + j <-> hidden channel 4q + (j & 3); two MFMAs, A1 = [W_hi | 0],
 // A2 = [W_lo' | W_hi]); rows 8-10 (lanes q = 2) are the vector_down_frames vectors -> 9 frame scalars (scalarize).
+#ifdef GCDM_PRIO_VALU
+#define PRIO_GEMM() __builtin_amdgcn_s_setprio(0)
+#define PRIO_VALU() __builtin_amdgcn_s_setprio(GCDM_PRIO_VALU)
+#elif defined(GCDM_PRIO_GEMM)
+#define PRIO_GEMM() __builtin_amdgcn_s_setprio(GCDM_PRIO_GEMM)
+#define PRIO_VALU() __builtin_amdgcn_s_setprio(0)
+#else
+#define PRIO_GEMM()
+#define PRIO_VALU()
+#endif
 #define MFMA1632(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_f16((a), (b), (c), 0, 0, 0)
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -318,9 +381,10 @@ __device__ __forceinline__ void vec_pre_mfma(const h8 aH, const h8 aL, const v4f
         *(h8*)(XL + (33 * ETP + ve) * 16) = cat44(l[0], l[1]);
         *(h8*)(XH + (34 * ETP + ve) * 16) = cat44(h[2], z4);
         *(h8*)(XL + (34 * ETP + ve) * 16) = cat44(l[2], z4);
-    } else {                            // zero the padding group (weights there are zero, LDS is not)
+    } else {                            // padding group: zeros (LDS is not), and the constant 1 whose weight column is the scalar_out bias
         const h4 z4 = {(_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f};
-        *(h8*)(XH + (35 * ETP + ve) * 16) = cat44(z4, z4);
+        const h4 one = {(_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)X3_PRE};
+        *(h8*)(XH + (35 * ETP + ve) * 16) = cat44(z4, one);
         *(h8*)(XL + (35 * ETP + ve) * 16) = cat44(z4, z4);
     }
 }
@@ -338,10 +402,9 @@ __device__ __forceinline__ v4f vec_gate(const float* PG, const float* __restrict
 
 // vector_up + gate of residual GCP2 `k` and the residual update of the message vectors (gcpnet.py:388-411, 701): va / vb <- updated groups
 template <int ET>
-__device__ __forceinline__ void vec_finish_mfma(const h8* __restrict__ a1, const h8* __restrict__ a2, const float* PG, const float* __restrict__ bg,
-                                                const h8* VHB, v4f* VV4, int ve, int vq, int lane, v4f (&va)[3], v4f (&vb)[3]) {
+__device__ __forceinline__ void vec_finish_mfma(const h8 (&w1)[2], const h8 (&w2)[2], const float* PG, const float* __restrict__ bg,
+                                                const h8* VHB, v4f* VV4, int ve, int vq, v4f (&va)[3], v4f (&vb)[3]) {
     constexpr int ETP = ET + 1;
-    const h8 w1[2] = {a1[lane], a1[64 + lane]}, w2[2] = {a2[lane], a2[64 + lane]};
     h8 b[3];
 #pragma unroll
     for (int x = 0; x < 3; ++x) b[x] = VHB[(x * 2 + (vq & 1)) * ET + ve];     // lanes q >= 2 read a finite image, their A columns are zero
@@ -365,11 +428,10 @@ __device__ __forceinline__ void vec_finish_mfma(const h8* __restrict__ a1, const
 
 // vector_up + gate of msg0 (H0 hidden vectors, written as fp32 rows VH[h*3 + x][e] by the pre-phase P1): va / vb <- message vectors
 template <int ET, int H0>
-__device__ __forceinline__ void vec_finish0_mfma(const h8* __restrict__ aH, const h8* __restrict__ aL, const float* PG, const float* __restrict__ bg,
-                                                 const float* VH, v4f* VV4, int ve, int vq, int lane, v4f (&va)[3], v4f (&vb)[3], float& amax) {
+__device__ __forceinline__ void vec_finish0_mfma(const h8 (&wH)[2], const h8 (&wL)[2], const float* PG, const float* __restrict__ bg,
+                                                 const float* VH, v4f* VV4, int ve, int vq, v4f (&va)[3], v4f (&vb)[3], float& amax) {
     constexpr int ETP = ET + 1;
     static_assert(H0 <= 32, "one k-block");
-    const h8 wH[2] = {aH[lane], aH[64 + lane]}, wL[2] = {aL[lane], aL[64 + lane]};
     h8 bh[3], bl[3];
 #pragma unroll
     for (int x = 0; x < 3; ++x) {
@@ -466,6 +528,24 @@ __global__ __launch_bounds__(ET * 8) __attribute__((amdgpu_waves_per_eu(2, 2))) 
     const int mt0 = MT * wave;   // first M-tile (32 output channels each) of this wave
     X3Ring<MT, PD> ring;
     x3_prefetch<MT, PD>(ring, ax.w0H + (size_t)mt0 * KB0C * 64, ax.w0L + (size_t)mt0 * KB0C * 64, KB0C, lane);   // flies during P1
+    // node-level halves of msg0 (PQ4 rows of this lane's GEMM-layout edges): requested now, consumed after P1
+    v4f pqi[MT][NT][4], pqj[MT][NT][4];
+    {
+        const int half_ = lane >> 5, l31_ = lane & 31;
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+            const int eg = min(e0 + 32 * n + l31_, E - 1);
+            const int ri = a.EROW[eg], cj = a.ECOL[eg];
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int g = 8 * (mt0 + m) + 2 * q + half_;
+                    pqi[m][n][q] = a.PQ4[(size_t)g * N + ri];
+                    pqj[m][n][q] = a.PQ4[(size_t)(64 + g) * N + cj];
+                }
+        }
+    }
 
     if (wave == 0) {
         const bool own = lane < ET;
@@ -585,31 +665,31 @@ __global__ __launch_bounds__(ET * 8) __attribute__((amdgpu_waves_per_eu(2, 2))) 
     const h8* xh8 = (const h8*)XH;
     const h8* xl8 = (const h8*)XL;
     // vector path: wave g < ET/16 owns edges 16g .. 16g+15 (lane: q = lane >> 4, edge 16g + (lane & 15))
+    // The role alternates between the two halves of the workgroup from phase to phase (the state is handed over in LDS), so that
+    // every SIMD carries the same share of the vector work whatever the placement of the co-resident workgroup.
     constexpr int NVW = ET / 16;
-    const bool vwave = wave < NVW;
-    const int vq = lane >> 4, ve = 16 * wave + (lane & 15);
+    static_assert(NW == 2 * NVW, "two alternating sets of vector waves");
+    const int vhalf = wave / NVW;                        // which set this wave belongs to
+    const int vq = lane >> 4, ve = 16 * (wave - vhalf * NVW) + (lane & 15);
     v4f* VV4 = (v4f*)(smem + Geo::OFF_VV);               // [3][8][ETP] float4: message vectors, component x, channel group cg, edge
     h8* VHB = (h8*)(smem + Geo::OFF_VHB);                // [3][2][ET]: hidden vectors of the current GCP2 as [hi(4) | lo'(4)] images
     float amax = 0.f;                                    // largest |x| that went into an f16 image (range guard)
 
+    h8 vw0[2], vw1[2], vpw[2];                           // A operands of the coming vector phase (vector waves only)
     // ---- P2: msg0 GEMM ----------------------------------------------------------------------------------------------------
     {
 #pragma unroll
-        for (int n = 0; n < NT; ++n) {
-            const int ri = m_row[32 * n + l31], cj = m_col[32 * n + l31];
+        for (int n = 0; n < NT; ++n)
 #pragma unroll
             for (int m = 0; m < MT; ++m)
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int g = 8 * (mt0 + m) + 2 * q + half;
-                    const v4f p = a.PQ4[(size_t)g * N + ri];
-                    const v4f qq = a.PQ4[(size_t)(64 + g) * N + cj];
+                for (int q = 0; q < 4; ++q)
 #pragma unroll
-                    for (int t = 0; t < 4; ++t) { am[m][n][4 * q + t] = p[t] + qq[t]; al2[m][n][4 * q + t] = 0.f; }
-                }
-        }
+                    for (int t = 0; t < 4; ++t) am[m][n][4 * q + t] = pqi[m][n][q][t] + pqj[m][n][q][t];
         STAMP(3);
-        tile_gemm_x3<MT, NT, PD, KB0C>(am, al2, ring, ax.w0H + (size_t)mt0 * KB0C * 64, ax.w0L + (size_t)mt0 * KB0C * 64, KB0C, xh8, xl8, ETP, lane);
+        PRIO_GEMM();
+        tile_gemm_x3z<MT, NT, PD, KB0C, false, true>(am, al2, ring, ax.w0H + (size_t)mt0 * KB0C * 64, ax.w0L + (size_t)mt0 * KB0C * 64, xh8, xl8, ETP, lane);
+        PRIO_VALU();
         x3_prefetch<MT, PD>(ring, ax.wH[0] + (size_t)mt0 * 18 * 64, ax.wL[0] + (size_t)mt0 * 18 * 64, 18, lane);
         STAMP(4);
 #pragma unroll
@@ -619,11 +699,11 @@ __global__ __launch_bounds__(ET * 8) __attribute__((amdgpu_waves_per_eu(2, 2))) 
 #pragma unroll
                 for (int r = 0; r < 16; ++r) st[m][n][r] = fast_silu(am[m][n][r] + al2[m][n][r] * X3_INV_SCALE);
         STAMP(5);
-#pragma unroll
-        for (int n = 0; n < NT; ++n)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) { gm[n][r] = 0.f; gl[n][r] = 0.f; }
-        gate_partial_x3<MT, NT>(gm, gl, st, ax.wg0H, ax.wg0L, mt0, lane);
+        gate_partial_x3<MT, NT, true>(gm, gl, st, ax.wg0H, ax.wg0L, mt0, lane);
+        if (vhalf == 0) {            // A operands of the vector phase behind the barrier: requested now
+            vw0[0] = ax.vf0H[lane]; vw0[1] = ax.vf0H[64 + lane]; vw1[0] = ax.vf0L[lane]; vw1[1] = ax.vf0L[64 + lane];
+            vpw[0] = ax.vpH[0][lane]; vpw[1] = ax.vpL[0][lane];
+        }
         if (NW == 4) {               // four partials = the four slots the vector waves sum: no fold needed
             put_gate_partial<NT, ET>(PG, gm, gl, wave, lane, false);
         } else {
@@ -637,10 +717,10 @@ __global__ __launch_bounds__(ET * 8) __attribute__((amdgpu_waves_per_eu(2, 2))) 
     STAMP(7);
     // ---- P3: state images (all waves) | vector part of msg0 and pre-phase of the first residual GCP2 (vector waves) ----------
     store_state_x3<MT, NT>(XH, XL, 0, st, ETP, mt0, lane, amax);
-    if (vwave) {
+    if (vhalf == 0) {
         v4f va[3], vb[3];
-        vec_finish0_mfma<ET, H0>(ax.vf0H, ax.vf0L, PG, a.bg0, VH, VV4, ve, vq, lane, va, vb, amax);
-        vec_pre_mfma<ET>(ax.vpH[0][lane], ax.vpL[0][lane], va, vb, FR, XH, XL, VHB, ve, vq, amax);
+        vec_finish0_mfma<ET, H0>(vw0, vw1, PG, a.bg0, VH, VV4, ve, vq, va, vb, amax);
+        vec_pre_mfma<ET>(vpw[0], vpw[1], va, vb, FR, XH, XL, VHB, ve, vq, amax);
     }
     STAMP(8);
     __syncthreads();
@@ -649,15 +729,10 @@ __global__ __launch_bounds__(ET * 8) __attribute__((amdgpu_waves_per_eu(2, 2))) 
     // ---- residual message GCP2s k = 1..3 ---------------------------------------------------------------------------------
     for (int k = 0; k < 3; ++k) {
         const GcpW& w = a.mk[k];
-        acc_init_bias<MT, NT>(am, w.b, mt0, lane);
-#pragma unroll
-        for (int m = 0; m < MT; ++m)
-#pragma unroll
-            for (int n = 0; n < NT; ++n)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) al2[m][n][r] = 0.f;
-        if (k == 0) STAMP(10);
-        tile_gemm_x3<MT, NT, PD, 18>(am, al2, ring, ax.wH[k] + (size_t)mt0 * 18 * 64, ax.wL[k] + (size_t)mt0 * 18 * 64, 18, xh8, xl8, ETP, lane);
+        if (k == 0) STAMP(10);           // no accumulator initialisation: zero C on the first k-block, the bias is the last extended-K row
+        PRIO_GEMM();
+        tile_gemm_x3z<MT, NT, PD, 18, true, true>(am, al2, ring, ax.wH[k] + (size_t)mt0 * 18 * 64, ax.wL[k] + (size_t)mt0 * 18 * 64, xh8, xl8, ETP, lane);
+        PRIO_VALU();
         if (k < 2) x3_prefetch<MT, PD>(ring, ax.wH[k + 1] + (size_t)mt0 * 18 * 64, ax.wL[k + 1] + (size_t)mt0 * 18 * 64, 18, lane);
         if (k == 0) STAMP(12);
 #pragma unroll
@@ -667,11 +742,12 @@ __global__ __launch_bounds__(ET * 8) __attribute__((amdgpu_waves_per_eu(2, 2))) 
 #pragma unroll
                 for (int r = 0; r < 16; ++r) am[m][n][r] = fast_silu(am[m][n][r] + al2[m][n][r] * X3_INV_SCALE);
         if (k == 0) STAMP(13);
-#pragma unroll
-        for (int n = 0; n < NT; ++n)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) { gm[n][r] = 0.f; gl[n][r] = 0.f; }
-        gate_partial_x3<MT, NT>(gm, gl, am, ax.wgH[k], ax.wgL[k], mt0, lane);
+        gate_partial_x3<MT, NT, true>(gm, gl, am, ax.wgH[k], ax.wgL[k], mt0, lane);
+        const bool vwave = vhalf == ((k + 1) & 1);
+        if (vwave) {
+            vw0[0] = ax.vf1[k][lane]; vw0[1] = ax.vf1[k][64 + lane]; vw1[0] = ax.vf2[k][lane]; vw1[1] = ax.vf2[k][64 + lane];
+            if (k < 2) { vpw[0] = ax.vpH[k + 1][lane]; vpw[1] = ax.vpL[k + 1][lane]; }
+        }
         if (NW == 4) {
             put_gate_partial<NT, ET>(PG, gm, gl, wave, lane, false);
         } else {
@@ -693,10 +769,13 @@ __global__ __launch_bounds__(ET * 8) __attribute__((amdgpu_waves_per_eu(2, 2))) 
         } else {                          // last GCP2: fp32 image for attention + segment sums (aliases XH8 / XL8)
             store_state<MT, NT, false>(XS4, 0, st, ETP, mt0, lane, 0);
         }
+        if (k == 0) STAMP(11);
         if (vwave) {                      // vector part of this GCP2, then the pre-phase of the next one from the same registers
             v4f va[3], vb[3];
-            vec_finish_mfma<ET>(ax.vf1[k], ax.vf2[k], PG, w.bg, VHB, VV4, ve, vq, lane, va, vb);
-            if (k < 2) vec_pre_mfma<ET>(ax.vpH[k + 1][lane], ax.vpL[k + 1][lane], va, vb, FR, XH, XL, VHB, ve, vq, amax);
+            vec_finish_mfma<ET>(vw0, vw1, PG, w.bg, VHB, VV4, ve, vq, va, vb);
+            if (k == 0) STAMP(21);
+            if (k < 2) vec_pre_mfma<ET>(vpw[0], vpw[1], va, vb, FR, XH, XL, VHB, ve, vq, amax);
+            if (k == 0) STAMP(22);
         }
         if (k == 0) STAMP(16);
         __syncthreads();

@@ -39,14 +39,16 @@ torch.cuda.synchronize()
 nw = 4 if lib.gcdm_get_option(h, b"edge_tile") == 32 else 8
 ph = net.debug_read("phase").view(-1, 8, 24)[:, :nw]
 lib.gcdm_profile_enable(h, 0)
-names = {1: "P1 msg0 pre", 2: "barrier", 3: "PQ gather", 4: "GEMM0", 5: "silu", 6: "gate+PG", 7: "barrier", 8: "state+vecfinish", 9: "barrier",
-         10: "k1 pre", 11: "barrier", 12: "k1 GEMM", 13: "k1 silu", 14: "k1 gate+PG", 15: "barrier", 16: "k1 state+finish", 17: "barrier",
+names = {1: "P1 msg0 pre", 2: "barrier", 3: "PQ gather", 4: "GEMM0", 5: "silu", 6: "gate+PG", 7: "barrier", 8: "state+vec0+pre1", 9: "barrier",
+         10: "k1 acc init", 12: "k1 GEMM", 13: "k1 silu", 14: "k1 gate+PG", 15: "barrier", 16: "k1 state+vector", 17: "barrier",
          18: "k2,k3 (all)", 19: "attention", 20: "aggregate"}
 mean = ph.mean(dim=(0, 1))
-mx = ph.max(dim=1)[0].mean(0)
-print("phase breakdown (shader cycles, mean over tiles x waves; cumulative -> delta):")
-prev = 0.0
-for i in range(1, 21):
-    print(f"  {i:2d} {names[i]:<18s} delta={mean[i]-prev:10.0f}  cum={mean[i]:10.0f}")
-    prev = mean[i]
-print("  extra stamps: 21 (acc init done) = %.0f, 22 (gemm done) = %.0f  -> pure gemm %.0f" % (mean[21], mean[22], mean[22] - mean[21]))
+print("phase breakdown (shader cycles, mean over tiles x waves; cumulative -> delta); per-wave deltas in brackets:")
+prev, prevw = 0.0, torch.zeros(nw)
+pw = ph.mean(dim=0)          # [nw, 24]
+for i in sorted(names):
+    dw = pw[:, i] - prevw
+    print(f"  {i:2d} {names[i]:<18s} delta={mean[i]-prev:10.0f}  cum={mean[i]:10.0f}   [" + " ".join(f"{x:7.0f}" for x in dw.tolist()) + "]")
+    prev, prevw = mean[i], pw[:, i]
+print("  k1 vector phase on the vector waves: state store %s  finish %s  pre %s" % tuple(
+    " ".join(f"{x:6.0f}" for x in (pw[:, b] - pw[:, a_]).tolist()) for a_, b in ((15, 11), (11, 21), (21, 22))))
