@@ -1117,6 +1117,8 @@ int64_t gcdm_debug_read(gcdm_handle* h, const char* name, float* host_out, int64
     else if (k == "fbar") { p = h->FBAR; cnt = 9 * n; }
     else if (k == "chi0") { p = h->CHI0; cnt = (h->sc ? 12 : 6) * n; }
     else if (k == "vel") { p = h->VEL; cnt = 3 * n; }
+    else if (k == "erow") { p = (const float*)h->d_erow; cnt = e; }        // int32 bit patterns (edge list of the plan: row / col node per flat edge)
+    else if (k == "ecol") { p = (const float*)h->d_ecol; cnt = e; }
     else if (k == "phase") { p = h->PROF; cnt = ((e + h->tile() - 1) / h->tile()) * 192; }
     else return fail(h, "gcdm_debug_read: unknown buffer " + k);
     if (!host_out) return cnt;

@@ -165,7 +165,8 @@ int32_t gcdm_timestep_index(float t, int32_t num_timesteps);
 int gcdm_unnormalize_z(gcdm_handle* h, const float* z, float* out, void* stream);
 
 /* Introspection for the parity tests: copies an internal buffer of the LAST forward to host (synchronises).
- * names: "h","chi","x","agg","ep","alpha","frames","pq","hin","fbar","chi0".  Returns number of floats written
+ * names: "h","chi","x","agg","ep","alpha","frames","pq","hin","fbar","chi0", and "erow" / "ecol" -- the plan's edge list as int32 bit
+ * patterns (row / col node of every flat edge: what replaces get_fully_connected_edge_index, gcpnet.py:1054-1066).  Returns number of floats written
  * (or needed if host_out is NULL), <0 on error.  Layouts are documented in DESIGN.md. */
 int64_t gcdm_debug_read(gcdm_handle* h, const char* name, float* host_out, int64_t capacity);
 /* Stops the next forward after `num_layers_to_run` interaction layers (-1 = all; test hook). */

@@ -263,3 +263,26 @@ def test_f16x3_emulation_matches_fp32_accuracy(golden_dir):
     err_x3 = (out - g["out64"]).abs().max().item()
     err_f32 = (g["out32"] - g["out64"]).abs().max().item()
     assert err_x3 <= 3e-6 and err_x3 <= 4 * err_f32 + 1e-6
+
+
+def test_oracle_follows_long_horizon_golden_first_50_steps(golden_dir):
+    """The oracle's free-running sampler against the reference's own 1000-step run (tests/golden/long_full_qm9.npz, make_long_golden.py):
+    the first 50 of the 1000 steps at full width on the same tape (the whole run is compared on the GPU, tests/test_gpu_parity.py)."""
+    g = np.load(os.path.join(golden_dir, "long_full_qm9.npz"))
+    d = synth.DATASET_DIMS["qm9"]
+    W = synth.make_weights(synth.dynamics_shapes(d["S"], d["V"], d["Se"], d["Ve"], d["L"], synth.dims_h_in(d)), seed=int(g["weight_seed"]),
+                           scale_2d=float(g["weight_scale"]))
+    cfg = O.OracleConfig(num_layers=d["L"])
+    nn_ = torch.tensor(g["num_nodes"])
+    B = len(nn_)
+    bi = O.num_nodes_to_batch_index(nn_)
+    mask = torch.ones_like(bi).bool()
+    gam = O.gamma_table(cfg)
+    noise = O.TapeNoise(int(g["noise_seed"]))
+    z = O.sample_combined_noise(noise, bi, B, mask, cfg.num_node_scalar_features, torch.float32)
+    for s in range(999, 949, -1):
+        z, _ = O.sample_p_zs_given_zt(W, cfg, gam, s / 1000, (s + 1) / 1000, z, bi, B, mask, None, noise)
+        if s in (999, 990, 950):
+            r32, r64 = torch.tensor(g[f"z32_{s}"]).double(), torch.tensor(g[f"z64_{s}"])
+            bound = 4.0 * (r32 - r64).abs().max().item() + 1e-4 * r64.abs().max().item()
+            assert (z.double() - r32).abs().max().item() <= bound, s
