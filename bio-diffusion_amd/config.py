@@ -137,7 +137,11 @@ def load_cfg_tree(config_root: str, dataset: str = "qm9", conditioning: Iterable
 
     cfgs["model_cfg"].update(to_attr(rd(f"model/model_cfg/{tag}_mol_gen_ddpm_gcp_model.yaml")))
     mod = rd(f"model/module_cfg/{tag}_mol_gen_ddpm_gcp_module.yaml")
-    mod.pop("selected_GCP", None)
+    sel = mod.pop("selected_GCP", None)
+    if sel is not None:          # configs/model/module_cfg/*.yaml: {_target_: src.models.components.gcpnet.GCP2, _partial_: true}
+        target = sel.get("_target_", "") if isinstance(sel, dict) else str(getattr(sel, "__name__", sel))
+        if target.rsplit(".", 1)[-1] != "GCP2":
+            raise NotImplementedError(f"module_cfg.selected_GCP = {target!r}: only GCP2 (the production module, gcpnet.py:265-491) is built")
     mod.pop("nonlinearities", None)
     keep_cond = cfgs["module_cfg"]["conditioning"]
     cfgs["module_cfg"].update(to_attr(mod))

@@ -13,6 +13,7 @@ from __future__ import annotations
 import io
 import os
 import pickle
+import re
 from typing import Any, Callable, Dict, List, Optional, Tuple
 
 import numpy as np
@@ -41,10 +42,27 @@ class _Dummy:
 
 
 class _StateDictUnpickler(pickle.Unpickler):
-    _SAFE_PREFIXES = ("torch", "collections", "numpy", "builtins", "_codecs")
+    """Resolves ONLY the globals a tensor state-dict needs, by (module, name); everything else in a Lightning checkpoint (omegaconf nodes,
+    callbacks, optimizer objects, ...) becomes an inert placeholder.  In particular nothing from `builtins` that can run code (eval, exec,
+    getattr, __import__, ...) and no `os` / `subprocess` / `torch.*` callables beyond the tensor rebuild helpers are reachable."""
+    _ALLOWED = {
+        ("collections", "OrderedDict"), ("collections", "defaultdict"),
+        ("builtins", "dict"), ("builtins", "list"), ("builtins", "tuple"), ("builtins", "set"), ("builtins", "frozenset"),
+        ("builtins", "int"), ("builtins", "float"), ("builtins", "bool"), ("builtins", "str"), ("builtins", "bytes"), ("builtins", "complex"),
+        ("builtins", "slice"), ("builtins", "range"),
+        ("_codecs", "encode"),
+        ("torch._utils", "_rebuild_tensor_v2"), ("torch._utils", "_rebuild_tensor"), ("torch._utils", "_rebuild_parameter"),
+        ("torch._utils", "_rebuild_parameter_with_state"), ("torch._tensor", "_rebuild_from_type_v2"), ("torch", "Size"), ("torch", "device"),
+        ("torch", "Tensor"), ("torch.nn.parameter", "Parameter"), ("torch.serialization", "_get_layout"),
+        ("numpy.core.multiarray", "_reconstruct"), ("numpy.core.multiarray", "scalar"), ("numpy._core.multiarray", "_reconstruct"),
+        ("numpy._core.multiarray", "scalar"), ("numpy", "ndarray"), ("numpy", "dtype"),
+    }
+    _TORCH_TYPED = re.compile(r"^(Float|Double|Half|BFloat16|Long|Int|Short|Char|Byte|Bool|ComplexFloat|ComplexDouble)Storage$|^(float|double|half|bfloat16|"
+                              r"float16|float32|float64|int8|int16|int32|int64|uint8|bool|long|int|short|complex64|complex128|strided)$")
 
     def find_class(self, module, name):
-        if module.split(".")[0] in self._SAFE_PREFIXES:
+        if (module, name) in self._ALLOWED or (module in ("torch", "torch.storage") and self._TORCH_TYPED.match(name)) or \
+                (module == "torch.storage" and name in ("UntypedStorage", "TypedStorage", "_load_from_bytes")):
             try:
                 return super().find_class(module, name)
             except Exception:
@@ -135,8 +153,9 @@ class _MoleculeGenerationDDPM(nn.Module):
                 context = self.props_distr.sample_batch(num_nodes)
         else:
             context = None
-        if "lanes" not in kw and "noise_fn" not in kw and not fix_noise and num_samples >= 256:
-            kw["lanes"] = 2            # big batches: two slices of the flat batch on two streams (same samples up to fp summation order, +4-5 %)
+        plain = not any(k in kw for k in ("lanes", "noise_fn", "step_callback", "_init_xh")) and kw.get("return_frames", 1) == 1
+        if plain and not fix_noise and num_samples >= 256 and (node_mask is None or bool(node_mask.all())):
+            kw["lanes"] = 2            # big plain batches: two slices of the flat batch on two streams (same samples up to fp summation order, +4-5 %)
         xh, batch_index, _ = self.ddpm.mol_gen_sample(num_samples=num_samples, num_nodes=num_nodes, node_mask=node_mask,
                                                       context=context, fix_noise=fix_noise, fix_self_conditioning_noise=fix_noise,
                                                       device=self.device, num_timesteps=num_timesteps, **kw)

@@ -5,7 +5,8 @@ Mirror of the *sampling subset* of ``src/models/components/variational_diffusion
 ``sigma_and_alpha_t_given_s`` (:342-367), ``sample_combined_position_feature_noise`` (:795-819),
 ``sample_normal`` (:822-837), ``sample_p_zs_given_zt`` (:1204-1278), ``sample_p_xh_given_z0`` (:840-907) and
 ``mol_gen_sample`` (:1282-1412), plus ``NumNodesDistribution`` (src/models/__init__.py:264-308).
-Training (loss), inpainting and guided optimisation are out of scope.
+RePaint inpainting (``inpaint``, :1582-1789) and the property-guided optimisation loop (``mol_gen_optimize``, :1416-1546) are built
+below on the same step / decode entry points; the training loss is out of scope.
 
 Two ways to take a step:
   * ``sample_p_zs_given_zt`` -- the reference's method signature, torch ops on the device for the O(N) algebra
@@ -278,6 +279,8 @@ class EquivariantVariationalDiffusion(nn.Module):
         t_norm = _t_norm if _t_norm is not None else (self.T if norm_with_original_timesteps else num_timesteps)
         if num_timesteps > t_norm:
             raise ValueError("num_timesteps exceeds the normalising number of timesteps")
+        if node_mask is not None and not bool(node_mask.all()):
+            raise NotImplementedError("masked nodes are not built (sampling uses an all-True mask)")
         if lanes > 1 and not _retry_fp32 and len(num_nodes) >= 2 * lanes:
             if noise_fn is not None or return_frames != 1 or _init_xh is not None or step_callback is not None:
                 raise NotImplementedError("lanes > 1 supports plain sampling with on-device noise only")
@@ -286,8 +289,6 @@ class EquivariantVariationalDiffusion(nn.Module):
         dyn, lib, h = self._native(device)
         num_nodes = torch.as_tensor(num_nodes)
         batch_index = num_nodes_to_batch_index(num_samples, num_nodes.to(device), device=device)
-        if node_mask is not None and not bool(node_mask.all()):
-            raise NotImplementedError("masked nodes are not built (sampling uses an all-True mask)")
         node_mask = torch.ones_like(batch_index).bool()
         dyn.plan(num_nodes.cpu())
         N, D = int(batch_index.shape[0]), self.num_x_dims + self.num_node_scalar_features
@@ -498,6 +499,11 @@ class EquivariantVariationalDiffusion(nn.Module):
             _native.check(self.lib, self.h, self.lib.gcdm_set_gamma(self.h, C.c_void_p(g.data_ptr()), g.numel()), "gcdm_set_gamma")
             self.lib.gcdm_set_option(self.h, b"mfma_mode", dyn.mfma_mode)
             self.stream = torch.cuda.Stream(device)
+            self.key = ddpm._lane_key(device)
+
+        def fresh(self, ddpm: "EquivariantVariationalDiffusion", device: torch.device) -> bool:
+            """Still a copy of the primary handle's weights / schedule / device?"""
+            return self.h is not None and self.key == ddpm._lane_key(device)
 
         def close(self):
             if self.h:
@@ -517,10 +523,7 @@ class EquivariantVariationalDiffusion(nn.Module):
         contexts = contexts if contexts is not None else [None] * K
         seeds = seeds if seeds is not None else [1234 + b for b in range(K)]
         self._native(device)                                   # validates the dynamics network, uploads the primary handle
-        lanes = getattr(self, "_lanes", None) or []
-        while len(lanes) < K:
-            lanes.append(self._Lane(self, device))
-        self._lanes = lanes
+        lanes = self._get_lanes(K, device)
         D = self.num_x_dims + self.num_node_scalar_features
         work = []
         for b in range(K):
@@ -563,6 +566,27 @@ class EquivariantVariationalDiffusion(nn.Module):
             results.append((w["out"], w["bi"], torch.ones_like(w["bi"]).bool()))
         return results
 
+    def _lane_key(self, device: torch.device):
+        dyn = self.dynamics_network
+        idx = device.index if device.index is not None else torch.cuda.current_device()
+        g = self.gamma.gamma
+        return (dyn._params_fingerprint(), idx, g.data_ptr(), g._version)
+
+    def _get_lanes(self, K: int, device: torch.device):
+        """K extra handles that mirror the primary one.  A lane is a COPY of the weights: after load_state_dict / an EMA swap / fine-tuning /
+        `.to(other device)` the stale ones are rebuilt (the primary handle re-uploads through sync_weights)."""
+        lanes = [ln for ln in (getattr(self, "_lanes", None) or [])]
+        for i, ln in enumerate(lanes):
+            if not ln.fresh(self, device):
+                ln.close()
+                lanes[i] = self._Lane(self, device)
+        while len(lanes) < K:
+            lanes.append(self._Lane(self, device))
+        for ln in lanes:
+            ln.lib.gcdm_set_option(ln.h, b"mfma_mode", self.dynamics_network.mfma_mode)
+        self._lanes = lanes
+        return lanes
+
     def release_lanes(self):
         for ln in getattr(self, "_lanes", None) or []:
             ln.close()
@@ -590,10 +614,7 @@ class EquivariantVariationalDiffusion(nn.Module):
             cuts = slice_cuts(nn_, K)
             self.cuts = cuts
             self.node_off = torch.cat((torch.zeros(1, dtype=torch.long), nn_.long().cumsum(0))).tolist()
-            lanes = getattr(ddpm, "_lanes", None) or []
-            while len(lanes) < K:
-                lanes.append(ddpm._Lane(ddpm, device))
-            ddpm._lanes = lanes
+            lanes = ddpm._get_lanes(K, device)
             self.batch_index = num_nodes_to_batch_index(Bm, nn_.to(device), device=device)
             N, D = int(self.batch_index.shape[0]), ddpm.num_x_dims + ddpm.num_node_scalar_features
             self.ctx = None

@@ -17,9 +17,17 @@ def pytest_configure(config):
 def pytest_collection_modifyitems(config, items):
     have_ref = os.path.isdir("/root/reference/src/models/components")
     skip_ref = pytest.mark.skip(reason="/root/reference not present (GPU box)")
+    try:
+        import torch
+        have_gpu = torch.cuda.is_available() and os.path.exists(os.path.join(ROOT, "bio-diffusion_amd", "libgcdm_hip.so"))
+    except Exception:
+        have_gpu = False
+    skip_gpu = pytest.mark.skip(reason="needs an MI355X and the built libgcdm_hip.so (run on the GPU box: pytest -m gpu)")
     for item in items:
         if "needs_reference" in item.keywords and not have_ref:
             item.add_marker(skip_ref)
+        if "gpu" in item.keywords and not have_gpu:
+            item.add_marker(skip_gpu)
 
 
 @pytest.fixture(scope="session")

@@ -241,3 +241,87 @@ def test_chain_sampling_entry_points(tmp_path):
     assert torch.equal(mols[-1][0], fr[0, :, :3].cpu()) and torch.equal(mols[0][0], fr[7, :, :3].cpu())
     with pytest.raises(AssertionError):
         model.generate_molecules(ddpm_mode="unconditional", num_samples=2, sample_chain=True)
+
+
+def _two_rank_model(cond):
+    cfgs = pkg.default_cfgs("qm9", ("alpha",) if cond else ())
+    torch.manual_seed(0)
+    model = pkg.QM9MoleculeGenerationDDPM(**cfgs)
+    with torch.no_grad():
+        for p in model.ddpm.dynamics_network.parameters():
+            if p.dim() == 2:
+                p.mul_(0.25)
+    return model.cuda()
+
+
+def _two_rank_worker(rank, world, port, nn_all, ctx_all, q):
+    """One rank of the multi-GPU recipe, all ranks on GPU 0 (one-GPU box): HIP path + `parallel.sample_sharded` + gloo gather."""
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    par = importlib.import_module("bio-diffusion_amd.parallel")
+    model = _two_rank_model(ctx_all is not None)
+    xh, nn_g = par.sample_sharded(model.ddpm, nn_all, "cuda", context=ctx_all, num_timesteps=6, seed=40, lanes=1)
+    maps = open("/proc/self/maps").read()
+    q.put((rank, xh.cpu().numpy(), nn_g.cpu().numpy(), "libgcdm_hip.so" in maps))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cond", [False, True])
+def test_two_ranks_on_one_gpu_equal_independent_shard_runs(cond):
+    """SURVEY 8(e) on hardware: 2 processes (both on GPU 0: this pool has one-GPU boxes) run `parallel.sample_sharded` with the HIP path;
+    every rank ends up with all samples, in the original molecule order, bit-identical to the two independent single-handle runs of the
+    shards (seed + rank, own context rows)."""
+    import socket
+    import torch.multiprocessing as mp
+    par = importlib.import_module("bio-diffusion_amd.parallel")
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    nn_all = torch.tensor([19, 5, 12, 7, 19, 3, 9])
+    ctx_all = torch.tensor([[0.5], [-1.0], [2.0], [0.25], [-0.75], [1.5], [0.0]]) if cond else None
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_two_rank_worker, args=(r, 2, port, nn_all, ctx_all, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=600) for _ in range(2)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    model = _two_rank_model(cond)
+    want = []
+    for r in range(2):
+        lo, hi = par.shard_range(len(nn_all), r, 2)
+        o, _, _ = model.ddpm.mol_gen_sample(num_samples=hi - lo, num_nodes=nn_all[lo:hi], device="cuda", num_timesteps=6,
+                                            context=None if ctx_all is None else ctx_all[lo:hi], seed=40 + r, lanes=1)
+        want.append(o.cpu().clone())
+    want = torch.cat(want).numpy()
+    for r in range(2):
+        assert res[r][3], "the rank did not load the HIP library"
+        assert np.array_equal(res[r][1], want) and res[r][2].tolist() == nn_all.tolist()
+
+
+@pytest.mark.gpu
+def test_lanes_follow_weight_updates():
+    """Extra handles (lanes) are copies of the weights: after the parameters change, a sliced run must use the NEW weights."""
+    model = _two_rank_model(False)
+    ddpm = model.ddpm
+    nn_ = torch.tensor([19, 5, 12, 7, 19, 3, 9, 11])
+    kw = dict(num_samples=len(nn_), num_nodes=nn_, device="cuda", num_timesteps=5, seed=9)
+    a2, _, _ = ddpm.mol_gen_sample(lanes=2, **kw)
+    a2 = a2.clone()
+    with torch.no_grad():
+        for p in ddpm.dynamics_network.parameters():
+            if p.dim() == 2:
+                p.mul_(1.5)
+    b1, _, _ = ddpm.mol_gen_sample(lanes=1, **kw)
+    b1 = b1.clone()
+    b2, _, _ = ddpm.mol_gen_sample(lanes=2, **kw)
+    scale = max(1.0, b1[:, :3].abs().max().item())
+    assert (b2[:, :3] - b1[:, :3]).abs().max().item() <= 1e-4 * scale          # new weights in the lanes ...
+    assert (b2[:, :3] - a2[:, :3]).abs().max().item() > 3e-4 * scale           # ... and they do differ from the old ones
+    ddpm.release_lanes()
