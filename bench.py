@@ -71,14 +71,15 @@ def algorithmic_flops(N, E, dims):
     return total, edge_layer
 
 
-def cpu_baseline(dataset, cond, dims, seconds_budget=20.0):
-    """Oracle (CPU restatement pinned to the reference) on a bounded sample: B=16 molecules, a few denoise steps."""
+def cpu_baseline(dataset, cond, dims, seconds_budget=25.0):
+    """Oracle (CPU restatement pinned to the reference) on a bounded sample of BASELINE.json configs[0]'s shape: 64 QM9 molecules x 19 atoms
+    (GEOM: 16 x 44), >= 10 denoise steps, extrapolated to the 1001 network evaluations of a sample."""
     import synth
     from oracle import gcdm_oracle as O
     case = "geom" if dataset == "geom" else ("qm9cond" if cond else "qm9")
     d = synth.DATASET_DIMS[case]
     n = 44 if dataset == "geom" else 19       # ragged workloads: the CPU sample uses the fixed README sizes (same per-edge cost)
-    Bc = 8 if dataset == "geom" else 16
+    Bc = 16 if dataset == "geom" else 64
     threads = min(os.cpu_count() or 1, int(os.environ.get("GCDM_CPU_THREADS", "32")))
     torch.set_num_threads(threads)     # very wide hosts: torch CPU ops on these sizes stop scaling (and thrash) past ~32 threads
     W = synth.make_weights(synth.dynamics_shapes(d["S"], d["V"], d["Se"], d["Ve"], d["L"], synth.dims_h_in(d)), seed=0, scale_2d=0.25)
@@ -95,14 +96,27 @@ def cpu_baseline(dataset, cond, dims, seconds_budget=20.0):
         z, _ = O.sample_p_zs_given_zt(W, ocfg, gam, 0.999, 1.0, z, bi, Bc, mask, ctx, noise)   # warm-up
         t0 = time.time()
         steps = 0
-        while steps < 3 or (time.time() - t0 < seconds_budget and steps < 50):
+        while steps < 10 or (time.time() - t0 < seconds_budget and steps < 50):
             s = 998 - steps
             z, _ = O.sample_p_zs_given_zt(W, ocfg, gam, s / 1000, (s + 1) / 1000, z, bi, Bc, mask, ctx, noise)
             steps += 1
         dt = (time.time() - t0) / steps
     return {"value": Bc / (dt * NET_EVALS_PER_SAMPLE), "unit": "molecules/s", "cores": torch.get_num_threads(), "kind": "port",
             "ms_per_step": dt * 1e3,
-            "sample": f"CPU oracle (torch fp32), {Bc} molecules x {n} atoms, {steps} denoise steps timed, extrapolated x{NET_EVALS_PER_SAMPLE}"}
+            "host_cpu_count": os.cpu_count(),
+            "sample": f"CPU oracle (torch fp32, {torch.get_num_threads()} threads), {Bc} molecules x {n} atoms (BASELINE.json configs[0] shape), "
+                      f"{steps} denoise steps timed, extrapolated x{NET_EVALS_PER_SAMPLE}"}
+
+
+def csrc_sha16():
+    """Fingerprint of the device/host sources the library is built from: a PMC summary collected on other sources is stale."""
+    import hashlib
+    hsh = hashlib.sha256()
+    d = os.path.join(ROOT, "bio-diffusion_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        with open(os.path.join(d, f), "rb") as fh:
+            hsh.update(f.encode() + b"\0" + fh.read())
+    return hsh.hexdigest()[:16]
 
 
 def load_pmc_summary(workload, x3):
@@ -114,12 +128,58 @@ def load_pmc_summary(workload, x3):
         return {}
     with open(files[-1]) as f:
         d = json.load(f)
+    meta = d.get("_meta", {})
     for k, v in d.items():
         if k.startswith("k_edge_msg_x3" if x3 else "k_edge_msg<"):
             out = dict(v)
             out["source"] = os.path.relpath(files[-1], ROOT)
+            out["collected_at_commit"] = meta.get("git_head")
+            out["stale"] = meta.get("csrc_sha16") != csrc_sha16()       # counters of an older kernel are not this kernel's
+            if out["stale"]:
+                out["hbm_bytes_per_launch"] = None
+                out["mfma_busy_frac"] = None
             return out
     return {}
+
+
+def quick_config(pkg, name, dev, rank, lanes=2, steps=24, warmup=10):
+    """ms/step of another BASELINE.json config on this GPU (same code path as the headline: the batch as `lanes` slices, Philox noise);
+    a short run, reported as extra fields of the one JSON line (configs[2] = qm9cond, configs[3] = geom)."""
+    import synth
+    wl = WORKLOADS[name]
+    case = "geom" if wl["dataset"] == "geom" else ("qm9cond" if wl["cond"] else "qm9")
+    d = synth.DATASET_DIMS[case]
+    cfgs = pkg.default_cfgs(wl["dataset"], wl["cond"])
+    torch.manual_seed(0)
+    net = pkg.GCPNetDynamics(**cfgs)
+    with torch.no_grad():
+        for p in net.parameters():
+            if p.dim() == 2:
+                p.mul_(0.25)
+    net = net.to(dev)
+    ddpm = pkg.EquivariantVariationalDiffusion(net, cfgs["diffusion_cfg"], cfgs["dataloader_cfg"], pkg.dataset_info("geom" if wl["dataset"] == "geom" else "qm9"))
+    B = wl["B"]
+    num_nodes = torch.full((B,), wl["n"], dtype=torch.int32)
+    ctx_b = None
+    if d["n_ctx"]:
+        ctx_b = torch.randn((B, 1), generator=torch.Generator().manual_seed(2 + rank)).to(dev)
+    sl = ddpm._SlicedBatch(ddpm, num_nodes, dev, ctx_b, 1234 + rank, lanes)
+    sl.init()
+    s_idx = 999
+    for _ in range(warmup):
+        sl.step(s_idx, 1000); s_idx -= 1
+    sl.wait(); torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        sl.step(s_idx, 1000); s_idx -= 1
+    sl.wait(); torch.cuda.synchronize(dev)
+    ms = (time.perf_counter() - t0) / steps * 1e3
+    flags = int(sl.flags.max().item())
+    sl.close()
+    ddpm.release_lanes()
+    net.release()
+    return {"workload": wl["name"], "ms_per_step": ms, "value": B / (ms * 1e-3 * NET_EVALS_PER_SAMPLE), "unit": "molecules/s", "steps": steps,
+            "slices_of_the_batch": lanes, "flags": flags}
 
 
 def log(msg):
@@ -139,6 +199,7 @@ def main():
                                                                    "used when profiling so that the kernel statistics show the default mode only")
     ap.add_argument("--lanes", type=int, default=2, help="sample the ONE flat batch as this many slices of molecules on separate handles / HIP "
                                                          "streams (same semantics, same noise; fills the round-quantisation tails)")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the short runs of BASELINE.json configs[2] / configs[3] (extra fields of the JSON line)")
     ap.add_argument("--streams", type=int, default=1, help="independent batches in flight per GPU, each on its own handle and HIP stream "
                                                            "(the evaluation driver's concurrent_batches; for small batches)")
     args = ap.parse_args()
@@ -271,38 +332,39 @@ def main():
         sliced = None
     else:
         sliced_flags, sliced_finite = 0, True
-    # dominant-kernel timing (HIP events on the launch stream, separate un-timed steps)
-    for _ in range(3):          # settle clocks / caches on the single-handle path before measuring it
-        step(max(s_idx, 0))
-        s_idx -= 1
-    torch.cuda.synchronize(dev)
-    lib.gcdm_profile_enable(h, 1)
-    tot, cnt = 0.0, 0
-    for _ in range(5):
-        step(max(s_idx, 0))
-        s_idx -= 1
-        ms, nl = C.c_double(), C.c_int32()
-        native.check(lib, h, lib.gcdm_profile_edge_kernel_ms(h, C.byref(ms), C.byref(nl)), "gcdm_profile_edge_kernel_ms")
-        tot += ms.value
-        cnt += nl.value
-    lib.gcdm_profile_enable(h, 0)
-    edge_ms = tot / max(cnt, 1)
-
-    # the exact-fp32 MFMA mode, i.e. what a run costs if an activation leaves the f16 range of the split-precision kernels and the
-    # guard (GCDM_FLAG_F16_RANGE) makes the caller re-run it (a few un-timed steps on the whole batch; reported for transparency)
-    x3_mode = int(lib.gcdm_get_option(h, b"mfma_mode"))
-    fallback_ms = None
-    if x3_mode == 1 and not args.no_fp32_timing:
-        lib.gcdm_set_option(h, b"mfma_mode", 0)
-        for _ in range(2):
+    # Both matrix modes on the same footing: whole batch on ONE handle, wall clock over 8 steps + the dominant kernel's launch time from
+    # HIP events recorded by the library on the launch stream (separate un-timed steps).  f16x3 = the default (split-precision MFMA
+    # operands, fp32-equivalent accuracy), f32 = exact fp32 MFMA (also what the automatic re-run costs if an activation leaves the f16 range).
+    def single_handle_mode(mode):
+        nonlocal s_idx
+        lib.gcdm_set_option(h, b"mfma_mode", mode)
+        for _ in range(3):          # settle clocks / caches
             step(max(s_idx, 0)); s_idx -= 1
         torch.cuda.synchronize(dev)
         tf = time.perf_counter()
         for _ in range(8):
             step(max(s_idx, 0)); s_idx -= 1
         torch.cuda.synchronize(dev)
-        fallback_ms = (time.perf_counter() - tf) / 8 * 1e3
+        wall_ms = (time.perf_counter() - tf) / 8 * 1e3
+        lib.gcdm_profile_enable(h, 1)
+        tot, cnt = 0.0, 0
+        for _ in range(5):
+            step(max(s_idx, 0)); s_idx -= 1
+            ms, nl = C.c_double(), C.c_int32()
+            native.check(lib, h, lib.gcdm_profile_edge_kernel_ms(h, C.byref(ms), C.byref(nl)), "gcdm_profile_edge_kernel_ms")
+            tot += ms.value
+            cnt += nl.value
+        lib.gcdm_profile_enable(h, 0)
+        return wall_ms, tot / max(cnt, 1)
+
+    x3_mode = int(lib.gcdm_get_option(h, b"mfma_mode"))
+    mode_ms = {}
+    mode_ms[x3_mode] = single_handle_mode(x3_mode)
+    if x3_mode == 1 and not args.no_fp32_timing:
+        mode_ms[0] = single_handle_mode(0)
         lib.gcdm_set_option(h, b"mfma_mode", 1)
+    edge_ms = mode_ms[x3_mode][1]
+    fallback_ms = mode_ms[0][0] if 0 in mode_ms and x3_mode == 1 else None
 
     # finish the sample properly once (decode) so the path is exercised end to end, and gather like a real run would
     native.check(lib, h, lib.gcdm_sample_final(h, zp, cptr, None, seed, C.c_void_p(out.data_ptr()), fp, stream), "gcdm_sample_final")
@@ -339,7 +401,8 @@ def main():
         res = {
             "metric": "molecules/sec (1000-step DDPM sample)", "value": world * B * max(1, args.streams) / (ms_per_step * 1e-3 * NET_EVALS_PER_SAMPLE),
             "unit": "molecules/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32 (f16x3 split MFMA operands: x = hi + 2^-11 lo', 22 significant bits, fp32 accumulate)" if x3_mode else "f32", "data": "synthetic",
             "config": {"workload": wl["name"], "molecules_per_gpu": B * max(1, args.streams), "batches_in_flight": max(1, args.streams), "slices_of_the_batch": max(1, args.lanes), "atoms_per_molecule": wl["n"] if wl["n"] is not None else round(N / B, 2), "nodes_per_gpu": N,
                        "edges_per_gpu": E, "noise": "on-device Philox", "weights": "default init, 2-D x0.25 (SURVEY 8d)",
                        "value_definition": f"molecules / ({NET_EVALS_PER_SAMPLE} x measured s/step)", "parallelism": f"shard{world}",
@@ -364,6 +427,21 @@ def main():
                          "measured_on": "whole-batch launches on one handle, HIP events, un-timed steps after the timed loop (= bench.py --lanes 1, the command "
                                         "profiled under profiles/); the timed loop runs the batch as config.slices_of_the_batch slices"},
         }
+        def mode_entry(mode):
+            wall, ems = mode_ms[mode]
+            pk = PEAK_F16_MFMA_TFLOPS / 3.0 if mode else PEAK_FP32_MFMA_TFLOPS
+            ach = alg_edge_layer / (ems * 1e-3) / 1e12
+            return {"ms_per_step": wall, "value": world * B / (wall * 1e-3 * NET_EVALS_PER_SAMPLE), "unit": "molecules/s",
+                    "roofline": {"bound": "mfma", "kernel": "k_edge_msg_x3" if mode else "k_edge_msg", "avg_launch_ms": ems, "achieved": ach, "peak": pk,
+                                 "unit": "TFLOP/s", "frac": ach / pk}}
+        # both matrix modes, measured the same way (whole batch, one handle); quote them together
+        res["modes"] = {("f16x3" if m else "f32"): mode_entry(m) for m in sorted(mode_ms, reverse=True)}
+        res["modes"]["measured_on"] = "whole batch on one handle, 8 steps wall clock after 3 settling steps; the headline ms_per_step runs the default mode as config.slices_of_the_batch slices"
+        res["roofline"]["pmc_stale"] = pmc.get("stale")
+        res["roofline"]["pmc_collected_at_commit"] = pmc.get("collected_at_commit")
+        if args.workload == "qm9" and world == 1 and not args.no_other_configs and args.streams == 1:
+            log("other configs ...")
+            res["other_configs"] = {"configs[2] qm9cond": quick_config(pkg, "qm9cond", dev, rank), "configs[3] geom": quick_config(pkg, "geom", dev, rank)}
         if not args.no_cpu_baseline and world == 1:
             log("cpu baseline ...")
             res["cpu_baseline"] = cpu_baseline(wl["dataset"], wl["cond"], dims)

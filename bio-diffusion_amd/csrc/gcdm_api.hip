@@ -100,6 +100,22 @@ int fail(gcdm_handle* h, const std::string& msg) {
         if (_e != hipSuccess) return fail(h, std::string(#expr) + ": " + hipGetErrorString(_e));     \
     } while (0)
 
+// Binds the handle's device for the duration of an entry point and restores the caller's current device afterwards: a handle on
+// cuda:1 used while device 0 is current must neither launch on the wrong device nor change the caller's (torch's) current device.
+struct DeviceGuard {
+    int prev = -1;
+    explicit DeviceGuard(int dev) {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != dev) (void)hipSetDevice(dev);
+        else prev = -1;
+    }
+    ~DeviceGuard() {
+        if (prev >= 0) (void)hipSetDevice(prev);
+    }
+    DeviceGuard(const DeviceGuard&) = delete;
+    DeviceGuard& operator=(const DeviceGuard&) = delete;
+};
+
 // ---- pool builder: 16-byte aligned sub-arrays of one device allocation ---------------------------
 struct Pool {
     std::vector<float> host;
@@ -422,7 +438,7 @@ int gcdm_create(const GcdmConfig* cfg, gcdm_handle** out) {
     h->H0 = (2 * GCDM_V + h->Ve) / 4;
     if (const char* et = getenv("GCDM_EDGE_TILE")) h->edge_tile = (atoi(et) == 32) ? 32 : 64;
     if (const char* mm = getenv("GCDM_MFMA")) h->mfma_x3 = (std::strcmp(mm, "f16x3") == 0) ? 1 : 0;
-    HIP_OK(h, hipSetDevice(cfg->device));
+    DeviceGuard guard(cfg->device);
     HIP_OK(h, hipMalloc(&h->d_flags, 4 * sizeof(uint32_t)));            // [0] flag word, [1..2] statistics of gcdm_encode_samples
     HIP_OK(h, hipMemset(h->d_flags, 0, 4 * sizeof(uint32_t)));
     return 0;
@@ -430,7 +446,7 @@ int gcdm_create(const GcdmConfig* cfg, gcdm_handle** out) {
 
 int gcdm_destroy(gcdm_handle* h) {
     if (!h) return 0;
-    (void)hipSetDevice(h->cfg.device);
+    DeviceGuard guard(h->cfg.device);
     free_plan(h);
     for (auto& e : h->ev) (void)hipEventDestroy(e);
     if (h->wpool) (void)hipFree(h->wpool);
@@ -457,7 +473,7 @@ int gcdm_set_gamma(gcdm_handle* h, const float* host_gamma, int64_t numel) {
 
 int gcdm_finalize_weights(gcdm_handle* h) {
     if (!h) return -1;
-    HIP_OK(h, hipSetDevice(h->cfg.device));
+    DeviceGuard guard(h->cfg.device);
     const int S = GCDM_S, V = GCDM_V, Se = h->Se, Ve = h->Ve, H0 = h->H0, L = h->L;
     Pool pool;
     g_split_absmax = 0.f;
@@ -655,7 +671,7 @@ int gcdm_finalize_weights(gcdm_handle* h) {
 
 int gcdm_plan_batch(gcdm_handle* h, int32_t B, const int32_t* nn) {
     if (!h || B <= 0 || !nn) return fail(h, "gcdm_plan_batch: bad argument");
-    HIP_OK(h, hipSetDevice(h->cfg.device));
+    DeviceGuard guard(h->cfg.device);
     free_plan(h);
     std::vector<int> noff(B + 1, 0);
     int64_t E = 0;
@@ -741,6 +757,7 @@ int gcdm_forward_sc(gcdm_handle* h, const float* xh, const float* xh_sc, const f
     if (!h->N) return fail(h, "gcdm_forward: no batch plan");
     if (!xh || !t || !out) return fail(h, "gcdm_forward: null tensor");
     if (h->C && !context) return fail(h, "gcdm_forward: context required");
+    DeviceGuard guard(h->cfg.device);
     hipStream_t st = (hipStream_t)stream_;
     const int N = h->N, B = h->B;
     const int E = (int)h->E;
@@ -864,6 +881,7 @@ int32_t gcdm_timestep_index(float t, int32_t num_timesteps) {
 static float gamma_lookup(const gcdm_handle* h, float t) { return h->gamma[gcdm_timestep_index(t, h->cfg.num_timesteps)]; }
 
 static int launch_sample(gcdm_handle* h, StepArgs& sa, hipStream_t st) {
+    DeviceGuard guard(h->cfg.device);
     sa.noff = h->d_noff; sa.N = h->N; sa.D = h->D; sa.node_base = h->node_base;
     if (h->fix_noise) {                 // pre-pass: mean of this draw over all nodes (deterministic order)
         if (!h->d_gmean) HIP_OK(h, hipMalloc(&h->d_gmean, 4 * sizeof(float)));
@@ -884,6 +902,7 @@ int gcdm_sample_init(gcdm_handle* h, float* z, const float* noise, uint64_t seed
 
 int gcdm_encode_samples(gcdm_handle* h, const float* xh, float* z, uint32_t* flags, void* stream_) {
     if (!h || !xh || !z || !h->N) return fail(h, "gcdm_encode_samples: bad argument / no plan");
+    DeviceGuard guard(h->cfg.device);
     hipStream_t st = (hipStream_t)stream_;
     HIP_OK(h, hipMemsetAsync(h->d_flags + 1, 0, 2 * sizeof(uint32_t), st));
     EncodeArgs ea{};
@@ -898,6 +917,7 @@ int gcdm_encode_samples(gcdm_handle* h, const float* xh, float* z, uint32_t* fla
 }
 
 static int fill_t(gcdm_handle* h, float value, hipStream_t st) {
+    DeviceGuard guard(h->cfg.device);
     hipLaunchKernelGGL(k_fill, dim3((h->N + 255) / 256), dim3(256), 0, st, h->TBUF, h->N, value);
     HIP_OK(h, hipGetLastError());
     return 0;
@@ -959,6 +979,7 @@ int gcdm_sample_final_sc(gcdm_handle* h, const float* z0, const float* self_cond
                          float* out, uint32_t* flags, void* stream_) {
     if (!h || !z0 || !out) return fail(h, "gcdm_sample_final: bad argument");
     if ((int64_t)h->gamma.size() != (int64_t)h->cfg.num_timesteps + 1) return fail(h, "gcdm_sample_final: gamma table not set");
+    DeviceGuard guard(h->cfg.device);
     hipStream_t st = (hipStream_t)stream_;
     if (fill_t(h, 0.0f, st)) return -1;
     if (gcdm_forward_sc(h, z0, self_cond, h->TBUF, context, h->EPS, flags, stream_)) return -1;
@@ -982,6 +1003,7 @@ int gcdm_sample_final_sc(gcdm_handle* h, const float* z0, const float* self_cond
 // ---- RePaint inpainting (variational_diffusion.py:1582-1789) ----
 int gcdm_inpaint_center(gcdm_handle* h, const float* xh, const uint8_t* fixed, float* xh0, void* stream_) {
     if (!h || !xh || !fixed || !xh0 || !h->N) return fail(h, "gcdm_inpaint_center: bad argument / no plan");
+    DeviceGuard guard(h->cfg.device);
     hipLaunchKernelGGL(k_inpaint_center, dim3(h->B), dim3(64), 0, (hipStream_t)stream_, xh, fixed, h->d_noff, h->D, xh0);
     HIP_OK(h, hipGetLastError());
     return 0;
@@ -993,6 +1015,7 @@ int gcdm_inpaint_step(gcdm_handle* h, float* z, const float* xh0, const uint8_t*
     if (!h || !z || !xh0 || !fixed || num_steps <= 0 || s_index < 0 || s_index >= num_steps || !h->N) return fail(h, "gcdm_inpaint_step: bad argument / no plan");
     if ((h->sc != 0) != (self_cond != nullptr)) return fail(h, "gcdm_inpaint_step: self_cond must be given exactly when the handle has self_condition");
     if ((int64_t)h->gamma.size() != (int64_t)h->cfg.num_timesteps + 1) return fail(h, "gcdm_inpaint_step: gamma table not set");
+    DeviceGuard guard(h->cfg.device);
     hipStream_t st = (hipStream_t)stream_;
     const float s = (float)s_index / (float)num_steps, t = (float)(s_index + 1) / (float)num_steps;
     // known nodes: q(z_s | x, h) of the given molecule (compute_noised_representation, :910-931)
@@ -1026,6 +1049,7 @@ int gcdm_inpaint_jump(gcdm_handle* h, float* z, int32_t s_index, int32_t t_index
 
 int gcdm_unnormalize_z(gcdm_handle* h, const float* z, float* out, void* stream_) {
     if (!h || !z || !out || !h->N) return fail(h, "gcdm_unnormalize_z: bad argument / no plan");
+    DeviceGuard guard(h->cfg.device);
     const int total = h->N * h->D;
     hipLaunchKernelGGL(k_unnormalize, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream_, z, out, h->N, h->D, h->cfg.num_atom_types,
                        h->cfg.norm_values[0], h->cfg.norm_values[1], h->cfg.norm_values[2], h->cfg.norm_biases[1], h->cfg.norm_biases[2]);
@@ -1070,7 +1094,7 @@ int gcdm_get_option(const gcdm_handle* h, const char* name) {
 
 int gcdm_profile_enable(gcdm_handle* h, int32_t enable) {
     if (!h) return -1;
-    HIP_OK(h, hipSetDevice(h->cfg.device));
+    DeviceGuard guard(h->cfg.device);
     if (enable && h->ev.empty()) {
         h->ev.resize(2 * (size_t)h->L);
         for (auto& e : h->ev) HIP_OK(h, hipEventCreate(&e));
@@ -1123,7 +1147,8 @@ int64_t gcdm_debug_read(gcdm_handle* h, const char* name, float* host_out, int64
     else return fail(h, "gcdm_debug_read: unknown buffer " + k);
     if (!host_out) return cnt;
     if (capacity < cnt) return fail(h, "gcdm_debug_read: capacity too small");
-    if (hipSetDevice(h->cfg.device) != hipSuccess || hipDeviceSynchronize() != hipSuccess ||
+    DeviceGuard guard(h->cfg.device);
+    if (hipDeviceSynchronize() != hipSuccess ||
         hipMemcpy(host_out, p, cnt * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess)
         return fail(h, "gcdm_debug_read: copy failed");
     return cnt;
