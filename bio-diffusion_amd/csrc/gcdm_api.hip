@@ -76,7 +76,7 @@ struct gcdm_handle {
     // 100-molecule evaluation batches; QM9 molecules have <= 29 atoms, so a row is cut into at most 2 pieces and the result stays
     // bit-reproducible), everything else 64 (GEOM: +-1 %, and rows of 44+ edges would be cut into >= 3 atomically added pieces)
     int tile() const { return edge_tile ? edge_tile : ((use_x3() && Se == 64) ? 32 : 64); }
-    bool x3_weights_ok = true;       // every GEMM weight fits the split-precision images (|W| < 255); else mfma_mode 1 is refused
+    bool x3_weights_ok = true;       // every GEMM weight fits the split-precision images (|W| < 31.9); else mfma_mode 1 is refused
     int mfma_x3 = 1;                 // requested mode -- 1: split-precision f16 x3 kernels (default; env GCDM_MFMA=f16x3|f32), 0: fp32 MFMA
     bool use_x3() const { return mfma_x3 && x3_weights_ok; }   // effective mode: models whose weights do not fit the split images run fp32 MFMA
     bool attr_set = false;
@@ -147,13 +147,13 @@ std::vector<float> pack_mfma(Dense& W) {
 }
 
 // split-precision images: x = hi + 2^-11 lo', both f16.  packed[mt][kb][lane][8] = W[32 mt + (lane & 31)][16 kb + 8 (lane >> 5) + s]
-// Packed split-precision weights carry a factor 2^8 (exact): the kernels keep every activation image pre-multiplied by 2^-8 (X3_PRE,
-// gcdm_edge_x3.hip.h), which moves the f16 overflow bound of the activations from 6.5e4 to 1.7e7 at no cost in accuracy (f16
-// denormals are honoured by the MFMA, tools/mfma_denorm.hip); weights stay representable while |W| < 255.
+// Packed split-precision weights carry a factor 2^11 (exact): the kernels keep every activation image pre-multiplied by 2^-11 (X3_PRE,
+// gcdm_edge_x3.hip.h), which moves the f16 overflow bound of the activations from 6.5e4 to 1.2e8 at no cost in accuracy (f16
+// denormals are honoured by the MFMA, tools/mfma_denorm.hip); weights stay representable while |W| < 31.9.
 thread_local float g_split_absmax = 0.f;      // largest |W| seen by split_f16 since gcdm_finalize_weights reset it (NaN counts as too large)
 void split_f16(float x, uint16_t& hi, uint16_t& lo) {
     g_split_absmax = (fabsf(x) <= g_split_absmax) ? g_split_absmax : (x == x ? fabsf(x) : INFINITY);
-    x *= 256.0f;
+    x *= 2048.0f;
     const _Float16 h = (_Float16)x;
     const _Float16 l = (_Float16)((x - (float)h) * 2048.0f);
     std::memcpy(&hi, &h, 2);
@@ -205,31 +205,35 @@ std::vector<float> f16_words(const std::vector<uint16_t>& v) {
     return o;
 }
 
-// [W_down (H = 8 rows); W_frames (3 rows)] x 32 channels; k = 8q + j <-> channel (j < 4 ? 4q + j : 16 + 4q + j - 4)
+// [W_down (H = 8 rows); W_frames (3 rows)] x 32 channels.  MFMA row 4q + i = hidden vector 3q + i (i < 3, real while < 8) or frame vector q
+// (i = 3, q < 3), so that every lane class q of the D layout runs the same code; k = 8q + j <-> channel (j < 4 ? 4q + j : 16 + 4q + j - 4)
 template <typename WD, typename WF>
 void pack_vec_pre(const WD& wd, const WF& wdf, std::vector<float>& outH, std::vector<float>& outL) {
     std::vector<uint16_t> H(64 * 8), L(64 * 8);
     for (int lane = 0; lane < 64; ++lane)
         for (int j = 0; j < 8; ++j) {
-            const int r = lane & 15, q = lane >> 4, c = j < 4 ? 4 * q + j : 16 + 4 * q + (j - 4);
-            const float wv = r < 8 ? wd.at(r, c) : (r < 11 ? wdf.at(r - 8, c) : 0.f);
+            const int r = lane & 15, rq = r >> 2, ri = r & 3, q = lane >> 4, c = j < 4 ? 4 * q + j : 16 + 4 * q + (j - 4);
+            float wv = 0.f;
+            if (ri < 3) { if (3 * rq + ri < 8) wv = wd.at(3 * rq + ri, c); }
+            else if (rq < 3) wv = wdf.at(rq, c);
             split_f16(wv, H[lane * 8 + j], L[lane * 8 + j]);
         }
     outH = f16_words(H);
     outL = f16_words(L);
 }
 
-// vector_up [32][8] against the B image [hi(4) | lo'(4)] of hidden channels 4q .. 4q+3 (q < 2):  A1 = [W_hi | 0],  A2 = [W_lo' | W_hi]
+// vector_up [32][8] against the B image [hi(3) 0 | lo'(3) 0] of hidden channels 3q .. 3q+2:  A1 = [W_hi | 0],  A2 = [W_lo' | W_hi]
 template <typename WU>
 void pack_vec_fin(const WU& wu, std::vector<float>& out1, std::vector<float>& out2) {
     std::vector<uint16_t> A1(2 * 64 * 8, 0), A2(2 * 64 * 8, 0);
     for (int m = 0; m < 2; ++m)
         for (int lane = 0; lane < 64; ++lane) {
             const int c = 16 * m + (lane & 15), q = lane >> 4;
-            if (q >= 2) continue;
             for (int j = 0; j < 8; ++j) {
+                const int hch = 3 * q + (j & 3);
+                if ((j & 3) == 3 || hch >= 8) continue;
                 uint16_t hi, lo;
-                split_f16(wu.at(c, 4 * q + (j & 3)), hi, lo);
+                split_f16(wu.at(c, hch), hi, lo);
                 const size_t o = ((size_t)m * 64 + lane) * 8 + j;
                 A1[o] = j < 4 ? hi : 0;
                 A2[o] = j < 4 ? lo : hi;
@@ -580,11 +584,17 @@ int gcdm_finalize_weights(gcdm_handle* h) {
             if (!get_w(h, p + "scalar_out.weight", S, S + 8 + 9, ws) || !get_w(h, p + "vector_out_scale.weight", V, S, wg) ||
                 !get_w(h, p + "scalar_out.bias", 1, S, wb))
                 return -1;
+            // extended-K rows as the vector stage writes them (gcdm_edge_x3.hip.h): group 32 + g = [n(3g) n(3g+1) n(3g+2) | q(3g) q(3g+1) q(3g+2) | 0 | *],
+            // the last slot of group 35 holds a constant 1 (bias as a weight column)
             Dense Wx(S, 288);
             for (int m = 0; m < S; ++m) {
-                for (int kk = 0; kk < S + 8; ++kk) Wx.at(m, kk) = ws.at(m, kk);
-                for (int kk = 0; kk < 9; ++kk) Wx.at(m, S + 8 + kk) = ws.at(m, S + 8 + kk);
-                Wx.at(m, 287) = wb.at(0, m);      // last extended-K row: the kernel keeps a constant 1 there (bias as a weight column)
+                for (int kk = 0; kk < S; ++kk) Wx.at(m, kk) = ws.at(m, kk);
+                for (int g = 0; g < 3; ++g)
+                    for (int t = 0; t < 3; ++t) {
+                        if (3 * g + t < 8) Wx.at(m, S + 8 * g + t) = ws.at(m, S + 3 * g + t);          // norms of the hidden vectors
+                        Wx.at(m, S + 8 * g + 3 + t) = ws.at(m, S + 8 + 3 * g + t);                     // frame scalars q[3g + t]
+                    }
+                Wx.at(m, 287) = wb.at(0, m);
             }
             std::vector<float> xh, xl;
             pack_x3(Wx, xh, xl);
@@ -662,8 +672,8 @@ int gcdm_finalize_weights(gcdm_handle* h) {
             return -1;
         h->attr_set = true;
     }
-    // split-precision images hold 2^8 W in f16: a checkpoint with a matrix weight of 255 or more (or NaN) cannot use them -> fp32 MFMA only
-    h->x3_weights_ok = g_split_absmax < 255.0f;
+    // split-precision images hold 2^11 W in f16: a checkpoint with a matrix weight of 31.9 or more (or NaN) cannot use them -> fp32 MFMA only
+    h->x3_weights_ok = g_split_absmax < 31.9f;
     h->finalized = true;
     h->host_w.clear();
     return 0;
@@ -1062,7 +1072,7 @@ int gcdm_set_option(gcdm_handle* h, const char* name, int32_t value) {
     const std::string k(name);
     if (k == "mfma_mode") {                 // 0: fp32 MFMA, 1: split-precision f16 x3 (fp32-equivalent, 5.3x the matrix rate)
         if (value != 0 && value != 1) return fail(h, "gcdm_set_option(mfma_mode): 0 or 1");
-        if (value == 1 && !h->x3_weights_ok) return fail(h, "gcdm_set_option(mfma_mode): a weight of this model is >= 255 in magnitude, outside the split-precision images; only mode 0 (fp32 MFMA) is available");
+        if (value == 1 && !h->x3_weights_ok) return fail(h, "gcdm_set_option(mfma_mode): a weight of this model is >= 31.9 in magnitude, outside the split-precision images; only mode 0 (fp32 MFMA) is available");
         h->mfma_x3 = value;
         return 0;
     }

@@ -10,11 +10,14 @@
 //   * weights are split once on the host (two packed f16 arrays, same bytes as fp32);
 //   * the message scalars live as fp32 in REGISTERS of the wave that owns their 64 channels (residual adds are exact fp32);
 //     LDS holds only their hi / lo' images in 8-channel groups (XH8 / XL8: 16 B per group, same footprint as fp32);
-//   * f16 range: images hold x * 2^-8 (the packed weights carry the 2^8), so |x| up to 1.5e7 is representable; beyond that
+//   * f16 range: images hold x * 2^-11 (the packed weights carry the 2^11), so |x| up to 1.2e8 is representable; beyond that
 //     GCDM_FLAG_F16_RANGE is raised and the caller re-runs in fp32 mode.
 #pragma once
 #include "gcdm_kernels.hip.h"
 #include <type_traits>
+
+// v_sqrt_f32 (1 ulp) instead of the ~20-instruction correctly rounded expansion: the argument is >= 1e-8, never denormal
+__device__ __forceinline__ float fast_sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
 
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef _Float16 h4 __attribute__((ext_vector_type(4)));
@@ -22,13 +25,15 @@ typedef _Float16 h4 __attribute__((ext_vector_type(4)));
 #define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16((a), (b), (c), 0, 0, 0)
 #define X3_SCALE 2048.0f
 #define X3_INV_SCALE (1.0f / 2048.0f)
-#define X3_PRE (1.0f / 256.0f)           // every image holds x * 2^-8, the packed weights carry the 2^8 (gcdm_api.hip: split_f16)
-#define X3_RANGE (6.0e4f * 256.0f)       // bound on the un-scaled activation
+#define X3_PRE (1.0f / 2048.0f)          // every image holds x * 2^-11, the packed weights carry the 2^11 (gcdm_api.hip: split_f16); with
+                                         // PRE = 1 / SCALE the lo' image is f16(x - hi * 2^11): one mixed FMA, no extra multiply
+#define X3_RANGE (6.0e4f * 2048.0f)      // bound on the un-scaled activation
 
 __device__ __forceinline__ void split16(float x, _Float16& hi, _Float16& lo) {
     hi = (_Float16)(x * X3_PRE);
     // (x 2^-8 - hi) * 2^11, written so that it maps to one mixed-precision FMA (v_fma_mixlo_f16): both products are exact (powers of two)
-    lo = (_Float16)__builtin_fmaf((float)hi, -X3_SCALE, x * (X3_SCALE * X3_PRE));
+    static_assert(X3_SCALE * X3_PRE == 1.0f, "lo' = x - hi * 2^11");
+    lo = (_Float16)__builtin_fmaf((float)hi, -X3_SCALE, x);
 }
 
 // Two values at once, 3 VALU instructions per value: one multiply (x * 2^3) and two mixed-precision FMAs -- v_fma_mix{lo,hi}_f16 writes
@@ -38,7 +43,7 @@ typedef _Float16 h2 __attribute__((ext_vector_type(2)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void split16x2(float x0, float x1, h2& hi, h2& lo) {
     const float pre = X3_PRE, neg = -X3_SCALE;
-    const float s0 = x0 * (X3_SCALE * X3_PRE), s1 = x1 * (X3_SCALE * X3_PRE);
+    const float s0 = x0, s1 = x1;
     uint32_t hiu, lou;
     // hi = f16(x * 2^-8) (round to nearest), both halves of one register
     asm("v_fma_mixlo_f16 %0, %1, %2, 0 op_sel_hi:[0,0,0]" : "=v"(hiu) : "v"(x0), "s"(pre));
@@ -62,6 +67,12 @@ struct X3Ring {
 // NOTE: the prefetches run PD k-blocks (A) / one k-block (B) past the end of the contraction without clamping: the packed weight
 // arrays carry X3_TAIL_BLOCKS zero blocks of padding behind the last M-tile, and the LDS reads stay inside the XH8|XL8|VV allocation.
 #define X3_TAIL_BLOCKS 4
+#ifndef GCDM_X3_PD
+#define GCDM_X3_PD 1             // k-blocks of weight prefetch distance in the edge kernel (register ring of PD + 1 sets)
+#endif
+#ifndef GCDM_VEC_PER_MFMA
+#define GCDM_VEC_PER_MFMA 6      // instructions of a vector stage issued behind each MFMA of the hosting k-block
+#endif
 
 template <int MT, int PD>
 __device__ __forceinline__ void x3_prefetch(X3Ring<MT, PD>& ring, const h8* __restrict__ wH, const h8* __restrict__ wL, int KB, int lane) {
@@ -286,8 +297,12 @@ __device__ __forceinline__ bool put16(char* XH, char* XL, int TP, int g8, int sl
 // ---- the vector path of the message GCP2s on the matrix pipe ----------------------------------------------------------------
 // The per-edge vector contractions of a GCP2 -- vector_down / vector_down_frames ([11 x 32] . [32 x 3] per edge, gcpnet.py:442-459)
 // and vector_up ([32 x H] . [H x 3], :388-411) -- are GEMMs with a tiny M: as VALU FMAs they cost 13 % of the step for 2 % of the
-// FLOPs (8 threads share an edge and each re-reads all 96 vector components).  Here one wave per 16 edges ("vector wave" g = wave
-// < ET/16) evaluates them with v_mfma_f32_16x16x32_f16 (split precision, same error model as the scalar GEMMs):
+// FLOPs (8 threads share an edge and each re-reads all 96 vector components).  Here one wave per 16 edges ("vector wave") evaluates
+// them with v_mfma_f32_16x16x32_f16 (split precision, same error model as the scalar GEMMs), and -- because a SIMD does not overlap
+// one wave's VALU work with another wave's MFMAs (tools/mfma_ubench6.hip) -- it does so IN THE SHADOW OF ITS OWN SCALAR GEMM: the
+// vector part of GCP2 k-1 (vector_up, gate, residual update) and the pre-phase of GCP2 k (vector_down, norms, frame scalars) are cut
+// into 16 branch-free stages that are issued between the MFMAs of the first 16 k-blocks of GEMM k; the last two k-blocks (the
+// extended-K rows the pre-phase produces) follow after a workgroup barrier.
 //   operand maps (lane l: q = l >> 4, n = l & 15):  A[row n][k = 8q + j]   B[k = 8q + j][col n]   D[row 4q + i][col n]
 //   columns = the wave's 16 edges, one MFMA set per spatial component x.
 // The fp32 master of the message vectors lives in LDS as float4 channel groups VV4[x][cg][e]; lane (q, n) owns groups cg = q and
@@ -295,19 +310,11 @@ __device__ __forceinline__ bool put16(char* XH, char* XL, int TP, int g8, int sl
 //   * the D layout of vector_up (M-tile m = channels 16m .. 16m+15: rows 4q + i <-> channels 16m + 4q + i = group 4m + q), and
 //   * a valid B layout of vector_down, because the contraction order is free: k = 8q + j <-> channel (j < 4 ? 4q + j : 16 + 4q + j - 4)
 //     (the host packs A with that column permutation),
-// so finish(k) -> pre(k+1) runs on registers without any cross-lane traffic.  vector_down's D rows 0-7 (hidden vectors, lanes q < 2)
-// feed vector_up's B through a 16-byte image [hi(4) | lo'(4)] (k = 8q + j <-> hidden channel 4q + (j & 3); two MFMAs, A1 = [W_hi | 0],
-// A2 = [W_lo' | W_hi]); rows 8-10 (lanes q = 2) are the vector_down_frames vectors -> 9 frame scalars (scalarize).
-#ifdef GCDM_PRIO_VALU
-#define PRIO_GEMM() __builtin_amdgcn_s_setprio(0)
-#define PRIO_VALU() __builtin_amdgcn_s_setprio(GCDM_PRIO_VALU)
-#elif defined(GCDM_PRIO_GEMM)
-#define PRIO_GEMM() __builtin_amdgcn_s_setprio(GCDM_PRIO_GEMM)
-#define PRIO_VALU() __builtin_amdgcn_s_setprio(0)
-#else
-#define PRIO_GEMM()
-#define PRIO_VALU()
-#endif
+// so vector_up(k-1) -> vector_down(k) runs on registers without any cross-lane traffic.
+// vector_down's 16 output rows are dealt out so that all lanes run the same code: D row 4q + i = hidden vector 3q + i for i < 3 (8 real
+// ones), = frame vector q for i = 3 (3 real ones).  Lane (q, n) therefore produces the 16-byte extended-K group 32 + q of its edge,
+// [n(3q) n(3q+1) n(3q+2) | q(3q) q(3q+1) q(3q+2) | 0 | 1 (q = 3: the bias column)], and the image [hi(3) 0 | lo'(3) 0] of its three hidden
+// vectors that feeds vector_up's B operand (k = 8q + j <-> hidden channel 3q + (j & 3); two MFMAs, A1 = [W_hi | 0], A2 = [W_lo' | W_hi]).
 #define MFMA1632(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_f16((a), (b), (c), 0, 0, 0)
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -324,145 +331,223 @@ __device__ __forceinline__ void split4(const float (&x)[4], h4& hi, h4& lo, floa
 
 __device__ __forceinline__ h8 cat44(h4 a, h4 b) { return (h8){a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]}; }
 
-// vector_down + vector_down_frames of residual GCP2 `k` from the lane's own groups (va = group q, vb = group 4 + q) of the message
-// vectors: norms and frame scalars -> extended-K rows of the scalar GEMM (groups 32 | 33, 34 | 35 of XH8 / XL8), hidden vectors -> VHB.
-template <int ET>
-__device__ __forceinline__ void vec_pre_mfma(const h8 aH, const h8 aL, const v4f (&va)[3], const v4f (&vb)[3], const float* FR, char* XH, char* XL,
-                                             h8* VHB, int ve, int vq, float& amax) {
-    constexpr int ETP = ET + 1;
+template <int ET, int H0, bool FIRST>
+struct VecStage {
+    static constexpr int ETP = ET + 1;
+    static constexpr int NSTAGES = 16;
+    // tile state (LDS) and this lane's place in it
+    const float* PG; const float* bg; const float* FR; const float* VH; h8* VHB; v4f* VV4; char* XH; char* XL;
+    const h8* fA; const h8* fB;          // A operands of the finish part [2][64]: residual GCP2: A1, A2; msg0 (FIRST): W_hi, W_lo'
+    const h8* pH; const h8* pL;          // A operand of the pre part [64]
+    int ve, vq, lane;
+    // registers handed from stage to stage
+    v4f g0, g1;
+    h8 w1[2], w2[2], pa[2];
+    h8 bh[3], bl[3];
+    v4f va[3], vb[3];
     float o[3][4];
-#pragma unroll
-    for (int x = 0; x < 3; ++x) {
-        const float b0[4] = {va[x][0], va[x][1], va[x][2], va[x][3]}, b1[4] = {vb[x][0], vb[x][1], vb[x][2], vb[x][3]};
-        h4 h0, l0, h1, l1;
-        split4(b0, h0, l0, amax);
-        split4(b1, h1, l1, amax);
-        const h8 bh = cat44(h0, h1), bl = cat44(l0, l1);
-        f32x4 am = {0.f, 0.f, 0.f, 0.f}, al = {0.f, 0.f, 0.f, 0.f};
-        am = MFMA1632(aH, bh, am);
-        al = MFMA1632(aH, bl, al);
-        al = MFMA1632(aL, bh, al);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) o[x][i] = am[i] + al[i] * X3_INV_SCALE;
-    }
-    if (vq < 2) {                       // rows 4q .. 4q+3 of W_down: norms -> extended-K group 32, hidden vectors -> VHB (gcpnet.py:442-452)
-        float nr[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) nr[i] = sqrtf(o[0][i] * o[0][i] + o[1][i] * o[1][i] + o[2][i] * o[2][i] + 1e-8f) + 1e-8f;
-        h4 nh, nl;
-        split4(nr, nh, nl, amax);
-        const int off = (32 * ETP + ve) * 16 + 8 * vq;
-        *(h4*)(XH + off) = nh;
-        *(h4*)(XL + off) = nl;
-#pragma unroll
-        for (int x = 0; x < 3; ++x) {
-            h4 vh, vl;
-            split4(o[x], vh, vl, amax);
-            VHB[(x * 2 + vq) * ET + ve] = cat44(vh, vl);
-        }
-    } else if (vq == 2) {               // rows 8..10 = W_frames: q[3j + r] = F[r,:] . u_j (scalarize, components/__init__.py:174-219)
-        float f[9];
-#pragma unroll
-        for (int r = 0; r < 9; ++r) f[r] = FR[r * ETP + ve];
-        float qv[12];
-#pragma unroll
-        for (int j = 0; j < 3; ++j)
-#pragma unroll
-            for (int r = 0; r < 3; ++r) qv[3 * j + r] = f[3 * r] * o[0][j] + f[3 * r + 1] * o[1][j] + f[3 * r + 2] * o[2][j];
-        qv[9] = qv[10] = qv[11] = 0.f;
-        h4 h[3], l[3];
-#pragma unroll
-        for (int t = 0; t < 3; ++t) {
-            const float part[4] = {qv[4 * t], qv[4 * t + 1], qv[4 * t + 2], qv[4 * t + 3]};
-            split4(part, h[t], l[t], amax);
-        }
-        const h4 z4 = {(_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f};
-        *(h8*)(XH + (33 * ETP + ve) * 16) = cat44(h[0], h[1]);
-        *(h8*)(XL + (33 * ETP + ve) * 16) = cat44(l[0], l[1]);
-        *(h8*)(XH + (34 * ETP + ve) * 16) = cat44(h[2], z4);
-        *(h8*)(XL + (34 * ETP + ve) * 16) = cat44(l[2], z4);
-    } else {                            // padding group: zeros (LDS is not), and the constant 1 whose weight column is the scalar_out bias
-        const h4 z4 = {(_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f};
-        const h4 one = {(_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)X3_PRE};
-        *(h8*)(XH + (35 * ETP + ve) * 16) = cat44(z4, one);
-        *(h8*)(XL + (35 * ETP + ve) * 16) = cat44(z4, z4);
-    }
-}
+    float vraw[8];
+    float ev[6];
+    h4 sh0, sl0, sh1, sl1;
+    float amax = 0.f;
 
-// sigmoid(gate) of the four channels 16m + 4q + {0..3} of edge ve (gcpnet.py:396-401)
-template <int ET>
-__device__ __forceinline__ v4f vec_gate(const float* PG, const float* __restrict__ bg, int m, int ve, int vq) {
-    v4f g = *(const v4f*)(bg + 16 * m + 4 * vq);
+    __device__ __forceinline__ v4f gate_sum(int m) const {
+        v4f g = *(const v4f*)(bg + 16 * m + 4 * vq);
 #pragma unroll
-    for (int s = 0; s < 4; ++s) g += *(const v4f*)(PG + pg_off<ET>(s, ve, 4 * m + vq));
+        for (int s = 0; s < 4; ++s) g += *(const v4f*)(PG + pg_off<ET>(s, ve, 4 * m + vq));
+        return g;
+    }
+    static __device__ __forceinline__ v4f sig4(v4f g) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) g[i] = fast_sigmoid(g[i]);
-    return g;
-}
-
-// vector_up + gate of residual GCP2 `k` and the residual update of the message vectors (gcpnet.py:388-411, 701): va / vb <- updated groups
-template <int ET>
-__device__ __forceinline__ void vec_finish_mfma(const h8 (&w1)[2], const h8 (&w2)[2], const float* PG, const float* __restrict__ bg,
-                                                const h8* VHB, v4f* VV4, int ve, int vq, v4f (&va)[3], v4f (&vb)[3]) {
-    constexpr int ETP = ET + 1;
-    h8 b[3];
+        for (int i = 0; i < 4; ++i) g[i] = fast_sigmoid(g[i]);
+        return g;
+    }
+    // vector_up of component x (both M-tiles), gate, (residual) update of the message vectors
+    // (`b` = which image register set holds the B operand, `x` = the spatial component it belongs to)
+    __device__ __forceinline__ void finish_x(int b, int x = -1) {
+        if (x < 0) x = b;
 #pragma unroll
-    for (int x = 0; x < 3; ++x) b[x] = VHB[(x * 2 + (vq & 1)) * ET + ve];     // lanes q >= 2 read a finite image, their A columns are zero
-#pragma unroll
-    for (int m = 0; m < 2; ++m) {
-        const v4f sg = vec_gate<ET>(PG, bg, m, ve, vq);
-#pragma unroll
-        for (int x = 0; x < 3; ++x) {
+        for (int m = 0; m < 2; ++m) {
             f32x4 am = {0.f, 0.f, 0.f, 0.f}, al = {0.f, 0.f, 0.f, 0.f};
-            am = MFMA1632(w1[m], b[x], am);
-            al = MFMA1632(w2[m], b[x], al);
+            if (FIRST) {
+                am = MFMA1632(w1[m], bh[b], am);
+                al = MFMA1632(w1[m], bl[b], al);
+                al = MFMA1632(w2[m], bh[b], al);
+            } else {
+                am = MFMA1632(w1[m], bh[b], am);
+                al = MFMA1632(w2[m], bh[b], al);
+            }
+            const v4f sg = m == 0 ? g0 : g1;
             v4f* p = &VV4[(x * 8 + 4 * m + vq) * ETP + ve];
-            v4f v = *p;
+            v4f v = {0.f, 0.f, 0.f, 0.f};
+            if (!FIRST) v = *p;
 #pragma unroll
             for (int i = 0; i < 4; ++i) v[i] += (am[i] + al[i] * X3_INV_SCALE) * sg[i];
             *p = v;
             if (m == 0) va[x] = v; else vb[x] = v;
         }
     }
-}
+    __device__ __forceinline__ void load_vh(int x) {                                              // msg0: hidden channels 8q .. 8q+7 of component x
+#pragma unroll
+        for (int j = 0; j < 8; ++j) vraw[j] = VH[(min(8 * vq + j, H0 - 1) * 3 + x) * ETP + ve];    // rows >= H0: any finite value (A is zero there)
+    }
+    __device__ __forceinline__ void split_vh(int b) {
+        const float v0[4] = {vraw[0], vraw[1], vraw[2], vraw[3]}, v1[4] = {vraw[4], vraw[5], vraw[6], vraw[7]};
+        split4(v0, sh0, sl0, amax);
+        split4(v1, sh1, sl1, amax);
+        bh[b] = cat44(sh0, sh1);
+        bl[b] = cat44(sl0, sl1);
+    }
+    __device__ __forceinline__ void split_vv(int x) {                                             // B images of vector_down: own groups q | 4 + q
+        const float b0[4] = {va[x][0], va[x][1], va[x][2], va[x][3]}, b1[4] = {vb[x][0], vb[x][1], vb[x][2], vb[x][3]};
+        split4(b0, sh0, sl0, amax);
+        split4(b1, sh1, sl1, amax);
+    }
+    __device__ __forceinline__ void pre_x(int x) {
+        const h8 xh = cat44(sh0, sh1), xl = cat44(sl0, sl1);
+        f32x4 am = {0.f, 0.f, 0.f, 0.f}, al = {0.f, 0.f, 0.f, 0.f};
+        am = MFMA1632(pa[0], xh, am);
+        al = MFMA1632(pa[0], xl, al);
+        al = MFMA1632(pa[1], xh, al);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) o[x][i] = am[i] + al[i] * X3_INV_SCALE;
+    }
+    __device__ __forceinline__ void vhb_x(int x, h8& img) {                                       // [hi(3) 0 | lo'(3) 0] of hidden vectors 3q .. 3q+2
+        const float v[4] = {o[x][0], o[x][1], o[x][2], 0.f};
+        h4 vh, vl;
+        split4(v, vh, vl, amax);
+        img = cat44(vh, vl);
+    }
 
-// vector_up + gate of msg0 (H0 hidden vectors, written as fp32 rows VH[h*3 + x][e] by the pre-phase P1): va / vb <- message vectors
-template <int ET, int H0>
-__device__ __forceinline__ void vec_finish0_mfma(const h8 (&wH)[2], const h8 (&wL)[2], const float* PG, const float* __restrict__ bg,
-                                                 const float* VH, v4f* VV4, int ve, int vq, v4f (&va)[3], v4f (&vb)[3], float& amax) {
-    constexpr int ETP = ET + 1;
-    static_assert(H0 <= 32, "one k-block");
-    h8 bh[3], bl[3];
+    // the common tail: vector_down of GCP2 k from va / vb (stages T0 .. T0+9)
+    template <int I, int T0>
+    __device__ __forceinline__ void pre_stage() {
+        if constexpr (I == T0) { pa[0] = pH[lane]; pa[1] = pL[lane]; split_vv(0); }
+        else if constexpr (I == T0 + 1) { pre_x(0); split_vv(1); }
+        else if constexpr (I == T0 + 2) { pre_x(1); split_vv(2); }
+        else if constexpr (I == T0 + 3) pre_x(2);
+        else if constexpr (I == T0 + 4) {       // norms of the hidden vectors (gcpnet.py:442-452), frame scalars q[3j + r] = F[r,:] . u_j (scalarize)
+            float f[9];
 #pragma unroll
-    for (int x = 0; x < 3; ++x) {
-        float v0[4], v1[4];
+            for (int r = 0; r < 9; ++r) f[r] = FR[r * ETP + ve];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            v0[j] = VH[(min(8 * vq + j, H0 - 1) * 3 + x) * ETP + ve];         // rows >= H0: any finite value (A is zero there)
-            v1[j] = VH[(min(8 * vq + 4 + j, H0 - 1) * 3 + x) * ETP + ve];
-        }
-        h4 h0, l0, h1, l1;
-        split4(v0, h0, l0, amax);
-        split4(v1, h1, l1, amax);
-        bh[x] = cat44(h0, h1);
-        bl[x] = cat44(l0, l1);
-    }
+            for (int i = 0; i < 3; ++i) ev[i] = fast_sqrt(o[0][i] * o[0][i] + o[1][i] * o[1][i] + o[2][i] * o[2][i] + 1e-8f) + 1e-8f;
 #pragma unroll
-    for (int m = 0; m < 2; ++m) {
-        const v4f sg = vec_gate<ET>(PG, bg, m, ve, vq);
+            for (int r = 0; r < 3; ++r) ev[3 + r] = f[3 * r] * o[0][3] + f[3 * r + 1] * o[1][3] + f[3 * r + 2] * o[2][3];
+        } else if constexpr (I == T0 + 5) {       // extended-K group 32 + q of this edge
+            const float c0[4] = {ev[0], ev[1], ev[2], ev[3]}, c1[4] = {ev[4], ev[5], 0.f, vq == 3 ? 1.0f : 0.f};
+            h4 h0_, l0_, h1_, l1_;
+            split4(c0, h0_, l0_, amax);
+            split4(c1, h1_, l1_, amax);
+            *(h8*)(XH + ((32 + vq) * ETP + ve) * 16) = cat44(h0_, h1_);
+            *(h8*)(XL + ((32 + vq) * ETP + ve) * 16) = cat44(l0_, l1_);
+        } else if constexpr (I == T0 + 6) { vhb_x(0, bh[0]); }
+        else if constexpr (I == T0 + 7) { vhb_x(1, bh[1]); }
+        else if constexpr (I == T0 + 8) {
+            vhb_x(2, bh[2]);
+            if (vq < 3) {
 #pragma unroll
-        for (int x = 0; x < 3; ++x) {
-            f32x4 am = {0.f, 0.f, 0.f, 0.f}, al = {0.f, 0.f, 0.f, 0.f};
-            am = MFMA1632(wH[m], bh[x], am);
-            al = MFMA1632(wH[m], bl[x], al);
-            al = MFMA1632(wL[m], bh[x], al);
-            v4f v;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) v[i] = (am[i] + al[i] * X3_INV_SCALE) * sg[i];
-            VV4[(x * 8 + 4 * m + vq) * ETP + ve] = v;
-            if (m == 0) va[x] = v; else vb[x] = v;
+                for (int x = 0; x < 3; ++x) VHB[(x * 3 + vq) * ET + ve] = bh[x];
+            }
         }
     }
+
+    template <int I>
+    __device__ __forceinline__ void run() {
+        if constexpr (FIRST) {        // vector_up of msg0 (hidden vectors: fp32 rows VH[h*3 + x][e] written by P1) ...
+            if constexpr (I == 0) {
+                w1[0] = fA[lane]; w1[1] = fA[64 + lane]; w2[0] = fB[lane]; w2[1] = fB[64 + lane];
+                g0 = gate_sum(0);
+            } else if constexpr (I == 1) {
+                g0 = sig4(g0);
+                g1 = gate_sum(1);
+                load_vh(0);
+            } else if constexpr (I == 2) {
+                g1 = sig4(g1);
+                split_vh(0);
+            } else if constexpr (I == 3) { finish_x(0); load_vh(1); }
+            else if constexpr (I == 4) { split_vh(0); finish_x(0, 1); load_vh(2); }
+            else if constexpr (I == 5) { split_vh(0); finish_x(0, 2); }
+            else pre_stage<I, 6>();   // ... then vector_down of the first residual GCP2
+        } else {
+            if constexpr (I == 0) {
+                w1[0] = fA[lane]; w1[1] = fA[64 + lane]; w2[0] = fB[lane]; w2[1] = fB[64 + lane];
+                g0 = gate_sum(0);
+            } else if constexpr (I == 1) {
+                g0 = sig4(g0);
+                g1 = gate_sum(1);
+#pragma unroll
+                for (int x = 0; x < 3; ++x) bh[x] = VHB[(x * 3 + min(vq, 2)) * ET + ve];      // lanes q = 3 read a finite image, their A columns are zero
+            } else if constexpr (I == 2) g1 = sig4(g1);
+            else if constexpr (I == 3) finish_x(0);
+            else if constexpr (I == 4) finish_x(1);
+            else if constexpr (I == 5) finish_x(2);
+            else pre_stage<I, 6>();
+        }
+    }
+    // vector part of the LAST GCP2 (no GEMM left to hide it in)
+    __device__ __forceinline__ void finish_only() {
+        run<0>(); run<1>(); run<2>(); run<3>(); run<4>(); run<5>();
+    }
+};
+
+// Scalar GEMM of a residual GCP2 with the vector stages in its shadow: k-blocks [0, SPLIT) carry hook(stage r) between their MFMAs
+// (vector waves; the others pass a no-op), then a workgroup barrier (the extended-K rows are complete), then k-blocks [SPLIT, KB).
+template <int MT, int NT, int PD, int KB, int SPLIT, bool HOOKED, class Hook>
+__device__ __forceinline__ void tile_gemm_x3s(f32x16 (&am)[MT][NT], f32x16 (&al)[MT][NT], X3Ring<MT, PD>& ring, const h8* __restrict__ wH,
+                                              const h8* __restrict__ wL, const h8* xh8, const h8* xl8, int TP, int lane, Hook&& hook) {
+    constexpr int R = PD + 1;
+    constexpr int wstride = KB * 64;
+    const h8* wh = wH + lane + PD * 64;
+    const h8* wl = wL + lane + PD * 64;
+    const int boff = (lane >> 5) * TP + (lane & 31);
+    const h8* sh = xh8 + boff;
+    const h8* sl = xl8 + boff;
+    h8 bh[2][NT], bl[2][NT];
+    const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int n = 0; n < NT; ++n) { bh[0][n] = sh[n * 32]; bl[0][n] = sl[n * 32]; }
+    auto body = [&](auto rc, auto hooked) {
+        constexpr int r = decltype(rc)::value;
+        constexpr bool HK = decltype(hooked)::value;
+#pragma unroll
+        for (int m = 0; m < MT; ++m) { ring.ah[(r + PD) % R][m] = wh[m * wstride]; ring.alo[(r + PD) % R][m] = wl[m * wstride]; }
+        wh += 64;
+        wl += 64;
+        sh += 2 * TP;
+        sl += 2 * TP;
+        if constexpr (r + 1 != SPLIT) {          // the block behind the barrier is read after the barrier
+#pragma unroll
+            for (int n = 0; n < NT; ++n) { bh[(r + 1) & 1][n] = sh[n * 32]; bl[(r + 1) & 1][n] = sl[n * 32]; }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int n = 0; n < NT; ++n) am[m][n] = MFMA16(ring.ah[r % R][m], bh[r & 1][n], r == 0 ? zero : am[m][n]);
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int n = 0; n < NT; ++n) al[m][n] = MFMA16(ring.ah[r % R][m], bl[r & 1][n], r == 0 ? zero : al[m][n]);
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int n = 0; n < NT; ++n) al[m][n] = MFMA16(ring.alo[r % R][m], bh[r & 1][n], al[m][n]);
+        if constexpr (HK) {
+            hook(rc);
+#pragma unroll
+            for (int i = 0; i < 3 * MT * NT; ++i) {      // one MFMA, then up to GCDM_VEC_PER_MFMA other instructions of the stage, ...
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002 | 0x004 | 0x080 | 0x400 | 0x020, GCDM_VEC_PER_MFMA, 0);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    static_for<0, SPLIT>([&](auto rc) { body(rc, std::integral_constant<bool, HOOKED>{}); });
+    __syncthreads();
+#pragma unroll
+    for (int n = 0; n < NT; ++n) { bh[SPLIT & 1][n] = sh[n * 32]; bl[SPLIT & 1][n] = sl[n * 32]; }
+    static_for<SPLIT, KB>([&](auto rc) { body(rc, std::false_type{}); });
 }
 
 struct EdgeMsgX3Args {
@@ -524,7 +609,7 @@ __global__ __launch_bounds__(ET * 8) __attribute__((amdgpu_waves_per_eu(2, 2))) 
     const int ni = a.EROW[eid], nj = a.ECOL[eid];
     const uint64_t t_start = a.prof ? __builtin_amdgcn_s_memtime() : 0;
     bool over = false;
-    constexpr int PD = 2;
+    constexpr int PD = GCDM_X3_PD;
     const int mt0 = MT * wave;   // first M-tile (32 output channels each) of this wave
     X3Ring<MT, PD> ring;
     x3_prefetch<MT, PD>(ring, ax.w0H + (size_t)mt0 * KB0C * 64, ax.w0L + (size_t)mt0 * KB0C * 64, KB0C, lane);   // flies during P1
@@ -632,7 +717,7 @@ __global__ __launch_bounds__(ET * 8) __attribute__((amdgpu_waves_per_eu(2, 2))) 
             const float vy = gi[i][1] + beta[i] * u1 + beta2[i] * s1 + gj[i][1];
             const float vz = gi[i][2] + beta[i] * u2 + beta2[i] * s2 + gj[i][2];
             if (hh < H0) {
-                over |= put16(XH, XL, ETP, N8 + (hh >> 3), hh & 7, e, sqrtf(vx * vx + vy * vy + vz * vz + 1e-8f) + 1e-8f);
+                over |= put16(XH, XL, ETP, N8 + (hh >> 3), hh & 7, e, fast_sqrt(vx * vx + vy * vy + vz * vz + 1e-8f) + 1e-8f);
                 VH[(hh * 3 + 0) * ETP + e] = vx;
                 VH[(hh * 3 + 1) * ETP + e] = vy;
                 VH[(hh * 3 + 2) * ETP + e] = vz;
@@ -664,18 +749,17 @@ __global__ __launch_bounds__(ET * 8) __attribute__((amdgpu_waves_per_eu(2, 2))) 
     f32x16 gm[NT], gl[NT];
     const h8* xh8 = (const h8*)XH;
     const h8* xl8 = (const h8*)XL;
-    // vector path: wave g < ET/16 owns edges 16g .. 16g+15 (lane: q = lane >> 4, edge 16g + (lane & 15))
-    // The role alternates between the two halves of the workgroup from phase to phase (the state is handed over in LDS), so that
-    // every SIMD carries the same share of the vector work whatever the placement of the co-resident workgroup.
+    // vector path: the workgroup's waves form two sets of ET/16 "vector waves" (wave g of a set owns edges 16g .. 16g+15; lane: q = lane >> 4,
+    // edge 16g + (lane & 15)).  The role alternates between the sets from GCP2 to GCP2 (the state is handed over in LDS), so that every
+    // SIMD carries the same share of the vector work whatever the placement of the co-resident workgroup.
     constexpr int NVW = ET / 16;
     static_assert(NW == 2 * NVW, "two alternating sets of vector waves");
     const int vhalf = wave / NVW;                        // which set this wave belongs to
     const int vq = lane >> 4, ve = 16 * (wave - vhalf * NVW) + (lane & 15);
     v4f* VV4 = (v4f*)(smem + Geo::OFF_VV);               // [3][8][ETP] float4: message vectors, component x, channel group cg, edge
-    h8* VHB = (h8*)(smem + Geo::OFF_VHB);                // [3][2][ET]: hidden vectors of the current GCP2 as [hi(4) | lo'(4)] images
+    h8* VHB = (h8*)(smem + Geo::OFF_VHB);                // [3][3][ET]: hidden vectors of the current GCP2 as [hi(3) 0 | lo'(3) 0] images
     float amax = 0.f;                                    // largest |x| that went into an f16 image (range guard)
 
-    h8 vw0[2], vw1[2], vpw[2];                           // A operands of the coming vector phase (vector waves only)
     // ---- P2: msg0 GEMM ----------------------------------------------------------------------------------------------------
     {
 #pragma unroll
@@ -687,9 +771,7 @@ __global__ __launch_bounds__(ET * 8) __attribute__((amdgpu_waves_per_eu(2, 2))) 
 #pragma unroll
                     for (int t = 0; t < 4; ++t) am[m][n][4 * q + t] = pqi[m][n][q][t] + pqj[m][n][q][t];
         STAMP(3);
-        PRIO_GEMM();
         tile_gemm_x3z<MT, NT, PD, KB0C, false, true>(am, al2, ring, ax.w0H + (size_t)mt0 * KB0C * 64, ax.w0L + (size_t)mt0 * KB0C * 64, xh8, xl8, ETP, lane);
-        PRIO_VALU();
         x3_prefetch<MT, PD>(ring, ax.wH[0] + (size_t)mt0 * 18 * 64, ax.wL[0] + (size_t)mt0 * 18 * 64, 18, lane);
         STAMP(4);
 #pragma unroll
@@ -700,10 +782,6 @@ __global__ __launch_bounds__(ET * 8) __attribute__((amdgpu_waves_per_eu(2, 2))) 
                 for (int r = 0; r < 16; ++r) st[m][n][r] = fast_silu(am[m][n][r] + al2[m][n][r] * X3_INV_SCALE);
         STAMP(5);
         gate_partial_x3<MT, NT, true>(gm, gl, st, ax.wg0H, ax.wg0L, mt0, lane);
-        if (vhalf == 0) {            // A operands of the vector phase behind the barrier: requested now
-            vw0[0] = ax.vf0H[lane]; vw0[1] = ax.vf0H[64 + lane]; vw1[0] = ax.vf0L[lane]; vw1[1] = ax.vf0L[64 + lane];
-            vpw[0] = ax.vpH[0][lane]; vpw[1] = ax.vpL[0][lane];
-        }
         if (NW == 4) {               // four partials = the four slots the vector waves sum: no fold needed
             put_gate_partial<NT, ET>(PG, gm, gl, wave, lane, false);
         } else {
@@ -715,25 +793,31 @@ __global__ __launch_bounds__(ET * 8) __attribute__((amdgpu_waves_per_eu(2, 2))) 
     }
     __syncthreads();
     STAMP(7);
-    // ---- P3: state images (all waves) | vector part of msg0 and pre-phase of the first residual GCP2 (vector waves) ----------
+    // ---- P3: state images ---------------------------------------------------------------------------------------------------
     store_state_x3<MT, NT>(XH, XL, 0, st, ETP, mt0, lane, amax);
-    if (vhalf == 0) {
-        v4f va[3], vb[3];
-        vec_finish0_mfma<ET, H0>(vw0, vw1, PG, a.bg0, VH, VV4, ve, vq, va, vb, amax);
-        vec_pre_mfma<ET>(vpw[0], vpw[1], va, vb, FR, XH, XL, VHB, ve, vq, amax);
-    }
     STAMP(8);
     __syncthreads();
     STAMP(9);
 
-    // ---- residual message GCP2s k = 1..3 ---------------------------------------------------------------------------------
-    for (int k = 0; k < 3; ++k) {
+    // ---- residual message GCP2s k = 1..3; the vector part of the previous GCP2 rides in the shadow of each GEMM ------------------
+    static_for<0, 3>([&](auto kc) {
+        constexpr int k = decltype(kc)::value;
         const GcpW& w = a.mk[k];
-        if (k == 0) STAMP(10);           // no accumulator initialisation: zero C on the first k-block, the bias is the last extended-K row
-        PRIO_GEMM();
-        tile_gemm_x3z<MT, NT, PD, 18, true, true>(am, al2, ring, ax.wH[k] + (size_t)mt0 * 18 * 64, ax.wL[k] + (size_t)mt0 * 18 * 64, xh8, xl8, ETP, lane);
-        PRIO_VALU();
-        if (k < 2) x3_prefetch<MT, PD>(ring, ax.wH[k + 1] + (size_t)mt0 * 18 * 64, ax.wL[k + 1] + (size_t)mt0 * 18 * 64, 18, lane);
+        const h8* gwH = ax.wH[k] + (size_t)mt0 * 18 * 64;
+        const h8* gwL = ax.wL[k] + (size_t)mt0 * 18 * 64;
+        if (k == 0) STAMP(10);
+        if (vhalf == (k & 1)) {
+            VecStage<ET, H0, k == 0> vs;
+            vs.PG = PG; vs.bg = k == 0 ? a.bg0 : a.mk[k == 0 ? 0 : k - 1].bg; vs.FR = FR; vs.VH = VH; vs.VHB = VHB; vs.VV4 = VV4; vs.XH = XH; vs.XL = XL;
+            vs.fA = k == 0 ? ax.vf0H : ax.vf1[k == 0 ? 0 : k - 1]; vs.fB = k == 0 ? ax.vf0L : ax.vf2[k == 0 ? 0 : k - 1];
+            vs.pH = ax.vpH[k]; vs.pL = ax.vpL[k];
+            vs.ve = ve; vs.vq = vq; vs.lane = lane;
+            tile_gemm_x3s<MT, NT, PD, 18, 16, true>(am, al2, ring, gwH, gwL, xh8, xl8, ETP, lane, [&](auto rc) { vs.template run<decltype(rc)::value>(); });
+            amax = fmaxf(amax, vs.amax);
+        } else {
+            tile_gemm_x3s<MT, NT, PD, 18, 16, false>(am, al2, ring, gwH, gwL, xh8, xl8, ETP, lane, [](auto) {});
+        }
+        if (k < 2) x3_prefetch<MT, PD>(ring, ax.wH[k < 2 ? k + 1 : 2] + (size_t)mt0 * 18 * 64, ax.wL[k < 2 ? k + 1 : 2] + (size_t)mt0 * 18 * 64, 18, lane);
         if (k == 0) STAMP(12);
 #pragma unroll
         for (int m = 0; m < MT; ++m)
@@ -743,11 +827,6 @@ __global__ __launch_bounds__(ET * 8) __attribute__((amdgpu_waves_per_eu(2, 2))) 
                 for (int r = 0; r < 16; ++r) am[m][n][r] = fast_silu(am[m][n][r] + al2[m][n][r] * X3_INV_SCALE);
         if (k == 0) STAMP(13);
         gate_partial_x3<MT, NT, true>(gm, gl, am, ax.wgH[k], ax.wgL[k], mt0, lane);
-        const bool vwave = vhalf == ((k + 1) & 1);
-        if (vwave) {
-            vw0[0] = ax.vf1[k][lane]; vw0[1] = ax.vf1[k][64 + lane]; vw1[0] = ax.vf2[k][lane]; vw1[1] = ax.vf2[k][64 + lane];
-            if (k < 2) { vpw[0] = ax.vpH[k + 1][lane]; vpw[1] = ax.vpL[k + 1][lane]; }
-        }
         if (NW == 4) {
             put_gate_partial<NT, ET>(PG, gm, gl, wave, lane, false);
         } else {
@@ -766,21 +845,20 @@ __global__ __launch_bounds__(ET * 8) __attribute__((amdgpu_waves_per_eu(2, 2))) 
                 for (int r = 0; r < 16; ++r) st[m][n][r] += am[m][n][r];       // residual add in fp32 (gcpnet.py:701)
         if (k < 2) {
             store_state_x3<MT, NT>(XH, XL, 0, st, ETP, mt0, lane, amax);
-        } else {                          // last GCP2: fp32 image for attention + segment sums (aliases XH8 / XL8)
+        } else {                          // last GCP2: fp32 image for attention + segment sums (aliases XH8 / XL8), and its vector part
             store_state<MT, NT, false>(XS4, 0, st, ETP, mt0, lane, 0);
-        }
-        if (k == 0) STAMP(11);
-        if (vwave) {                      // vector part of this GCP2, then the pre-phase of the next one from the same registers
-            v4f va[3], vb[3];
-            vec_finish_mfma<ET>(vw0, vw1, PG, w.bg, VHB, VV4, ve, vq, va, vb);
-            if (k == 0) STAMP(21);
-            if (k < 2) vec_pre_mfma<ET>(vpw[0], vpw[1], va, vb, FR, XH, XL, VHB, ve, vq, amax);
-            if (k == 0) STAMP(22);
+            if (vhalf == 1) {
+                VecStage<ET, H0, false> vs;
+                vs.PG = PG; vs.bg = a.mk[2].bg; vs.FR = FR; vs.VH = VH; vs.VHB = VHB; vs.VV4 = VV4; vs.XH = XH; vs.XL = XL;
+                vs.fA = ax.vf1[2]; vs.fB = ax.vf2[2]; vs.pH = nullptr; vs.pL = nullptr;
+                vs.ve = ve; vs.vq = vq; vs.lane = lane;
+                vs.finish_only();
+            }
         }
         if (k == 0) STAMP(16);
         __syncthreads();
         if (k == 0) STAMP(17);
-    }
+    });
     STAMP(18);
     over |= amax > X3_RANGE;
     if (__any(over) && lane == 0) atomicOr(ax.flags_dev, GCDM_FLAG_F16_RANGE_BIT);

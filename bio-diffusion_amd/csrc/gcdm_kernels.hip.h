@@ -530,8 +530,8 @@ struct EdgeGeo {
     static constexpr int OFF_PG = OFF_VH + 60 * TP * 4;
     static constexpr int OFF_FR = OFF_PG + 4 * 32 * TP * 4;
     static constexpr int OFF_META = OFF_FR + 9 * TP * 4;
-    static constexpr int OFF_VHB = (OFF_META + (T + T + (T + 2) + T + 4) * 4 + 15) & ~15;   // split-precision kernel: hidden-vector images [3][2][T] x 16 B
-    static constexpr int LDS_BYTES = OFF_VHB + 3 * 2 * T * 16;
+    static constexpr int OFF_VHB = (OFF_META + (T + T + (T + 2) + T + 4) * 4 + 15) & ~15;   // split-precision kernel: hidden-vector images [3][3][T] x 16 B
+    static constexpr int LDS_BYTES = OFF_VHB + 3 * 3 * T * 16;
 };
 
 template <int SE, int VE, int ET>

@@ -53,7 +53,7 @@ __device__ __forceinline__ bool gcp2_pre_x3g(const float* __restrict__ wdd, cons
         const int hh = part + PARTS * i;
         const float vx = ax[i], vy = ay[i], vz = az[i];
         if (hh < H) {
-            over |= put16(XH, XL, TP, gN8 + (hh >> 3), hh & 7, e, sqrtf(vx * vx + vy * vy + vz * vz + 1e-8f) + 1e-8f);
+            over |= put16(XH, XL, TP, gN8 + (hh >> 3), hh & 7, e, fast_sqrt(vx * vx + vy * vy + vz * vz + 1e-8f) + 1e-8f);
             VH[(hh * 3 + 0) * TP + e] = vx;
             VH[(hh * 3 + 1) * TP + e] = vy;
             VH[(hh * 3 + 2) * TP + e] = vz;

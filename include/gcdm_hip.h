@@ -37,7 +37,7 @@ extern "C" {
 #define GCDM_FLAG_NAN_VEL        0x1u  /* gcpnet.py:1213-1216: NaN seen in vel -> whole-batch vel zeroed   */
 #define GCDM_FLAG_MEAN_NOT_ZERO  0x2u  /* variational_diffusion.py:465-474 assert_mean_zero_with_mask fails  */
 #define GCDM_FLAG_COG_DRIFT      0x4u  /* variational_diffusion.py:1392-1402: CoG drift > 5e-2, re-projected  */
-#define GCDM_FLAG_F16_RANGE      0x8u  /* split-precision mode (GCDM_MFMA=f16x3): an activation exceeded 1.5e7 -> result invalid, re-run in fp32 mode */
+#define GCDM_FLAG_F16_RANGE      0x8u  /* split-precision mode (GCDM_MFMA=f16x3): an activation exceeded 1.2e8 -> result invalid, re-run in fp32 mode */
 
 typedef struct GcdmConfig {
     int32_t abi_version;       /* must be GCDM_ABI_VERSION */
@@ -174,8 +174,8 @@ int gcdm_debug_set_layer_limit(gcdm_handle* h, int32_t num_layers_to_run);
 
 /* Options.  "mfma_mode": 1 (default; env GCDM_MFMA=f16x3) evaluates the per-edge contractions with three f16 MFMAs per product
  * block on operands split as x = hi + 2^-11 lo' (fp32-equivalent accuracy; raises GCDM_FLAG_F16_RANGE if an
- * activation exceeds 1.5e7, in which case the caller must re-run with mode 0); 0 (env GCDM_MFMA=f32) uses fp32 MFMA throughout.
- * A model with a matrix weight of magnitude >= 255 (the split images hold 2^8 W in f16) runs in mode 0 whatever was requested
+ * activation exceeds 1.2e8, in which case the caller must re-run with mode 0); 0 (env GCDM_MFMA=f32) uses fp32 MFMA throughout.
+ * A model with a matrix weight of magnitude >= 31.9 (the split images hold 2^11 W in f16) runs in mode 0 whatever was requested
  * (gcdm_get_option reports the effective mode) and setting mode 1 on it fails.
  * "edge_tile": edges per workgroup of the edge-message kernels: 64 (one 8-wave workgroup per CU), 32 (two 4-wave workgroups per CU) or
  * 0 = automatic (default; env GCDM_EDGE_TILE): 32 for the split-precision kernel at the QM9 edge width (rows of <= 32 edges), else 64

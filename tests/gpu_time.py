@@ -39,8 +39,8 @@ torch.cuda.synchronize()
 nw = 4 if lib.gcdm_get_option(h, b"edge_tile") == 32 else 8
 ph = net.debug_read("phase").view(-1, 8, 24)[:, :nw]
 lib.gcdm_profile_enable(h, 0)
-names = {1: "P1 msg0 pre", 2: "barrier", 3: "PQ gather", 4: "GEMM0", 5: "silu", 6: "gate+PG", 7: "barrier", 8: "state+vec0+pre1", 9: "barrier",
-         10: "k1 acc init", 12: "k1 GEMM", 13: "k1 silu", 14: "k1 gate+PG", 15: "barrier", 16: "k1 state+vector", 17: "barrier",
+names = {1: "P1 msg0 pre", 2: "barrier", 3: "PQ add", 4: "GEMM0", 5: "silu", 6: "gate+PG", 7: "barrier", 8: "state store", 9: "barrier",
+         12: "k1 GEMM(+vec)+mid barrier", 13: "k1 silu", 14: "k1 gate+PG", 15: "barrier", 16: "k1 state store", 17: "barrier",
          18: "k2,k3 (all)", 19: "attention", 20: "aggregate"}
 mean = ph.mean(dim=(0, 1))
 print("phase breakdown (shader cycles, mean over tiles x waves; cumulative -> delta); per-wave deltas in brackets:")
@@ -50,5 +50,3 @@ for i in sorted(names):
     dw = pw[:, i] - prevw
     print(f"  {i:2d} {names[i]:<18s} delta={mean[i]-prev:10.0f}  cum={mean[i]:10.0f}   [" + " ".join(f"{x:7.0f}" for x in dw.tolist()) + "]")
     prev, prevw = mean[i], pw[:, i]
-print("  k1 vector phase on the vector waves: state store %s  finish %s  pre %s" % tuple(
-    " ".join(f"{x:6.0f}" for x in (pw[:, b] - pw[:, a_]).tolist()) for a_, b in ((15, 11), (11, 21), (21, 22))))
