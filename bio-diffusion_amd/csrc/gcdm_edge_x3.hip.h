@@ -613,6 +613,18 @@ __global__ __launch_bounds__(ET * 8) __attribute__((amdgpu_waves_per_eu(2, 2))) 
     const int mt0 = MT * wave;   // first M-tile (32 output channels each) of this wave
     X3Ring<MT, PD> ring;
     x3_prefetch<MT, PD>(ring, ax.w0H + (size_t)mt0 * KB0C * 64, ax.w0L + (size_t)mt0 * KB0C * 64, KB0C, lane);   // flies during P1
+    // per-edge constants of this thread's edge (streamed from HBM, independent of the edge list): requested first
+    constexpr int EPN = (SE / 4) / PARTS;                // e' float4 groups per thread (QM9 2, GEOM: parts 0..3 one each)
+    float fr[9];
+#pragma unroll
+    for (int r = 0; r < 9; ++r) fr[r] = a.FR[(size_t)r * E + eid];
+    v4f epv[EPN > 0 ? EPN : 1];
+#pragma unroll
+    for (int i = 0; i < (EPN > 0 ? EPN : 1); ++i) epv[i] = a.EP4[(size_t)min(part + PARTS * i, SE / 4 - 1) * E + eid];
+    float al[VE];
+#pragma unroll
+    for (int c = 0; c < VE; ++c) al[c] = a.AL[(size_t)c * E + eid];
+    const float u0 = a.U[eid], u1 = a.U[(size_t)E + eid], u2 = a.U[2 * (size_t)E + eid];
     // node-level halves of msg0 (PQ4 rows of this lane's GEMM-layout edges): requested now, consumed after P1
     v4f pqi[MT][NT][4], pqj[MT][NT][4];
     {
@@ -651,15 +663,15 @@ __global__ __launch_bounds__(ET * 8) __attribute__((amdgpu_waves_per_eu(2, 2))) 
     }
     // ---- P1: msg0 pre-phase ---------------------------------------------------------------------------------------------
     {
-        float fr[9];
-#pragma unroll
-        for (int r = 0; r < 9; ++r) fr[r] = a.FR[(size_t)r * E + eid];
         if (part == 0) {
 #pragma unroll
             for (int r = 0; r < 9; ++r) FR[r * ETP + e] = fr[r];
         }
-        for (int g = part; g < SEG; g += PARTS) {       // e' (fp32 in HBM) -> hi / lo' halves of an 8-group
-            const v4f v = a.EP4[(size_t)g * E + eid];
+#pragma unroll
+        for (int i = 0; i < (EPN > 0 ? EPN : 1); ++i) {       // e' (fp32 in HBM) -> hi / lo' halves of an 8-group
+            const int g = part + PARTS * i;
+            if (g >= SEG) break;
+            const v4f v = epv[i];
             h4 vh, vl;
 #pragma unroll
             for (int t = 0; t < 4; t += 2) {
@@ -673,10 +685,6 @@ __global__ __launch_bounds__(ET * 8) __attribute__((amdgpu_waves_per_eu(2, 2))) 
             *(h4*)(XH + off) = vh;
             *(h4*)(XL + off) = vl;
         }
-        float al[VE];
-#pragma unroll
-        for (int c = 0; c < VE; ++c) al[c] = a.AL[(size_t)c * E + eid];
-        const float u0 = a.U[eid], u1 = a.U[(size_t)E + eid], u2 = a.U[2 * (size_t)E + eid];
         constexpr int ROWS0 = H0 + 3, NH0 = (ROWS0 + PARTS - 1) / PARTS;
         float gi[NH0][3], gj[NH0][3], beta[NH0], beta2[NH0];
 #pragma unroll
