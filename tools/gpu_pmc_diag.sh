@@ -7,7 +7,7 @@ ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out
 export TMPDIR=/tmp
 cd /tmp
-B="python $ROOT/bench.py --workload $WL --lanes 1 --steps 4 --warmup 2 --no-cpu-baseline --no-fp32-timing"
+B="python $ROOT/bench.py --workload $WL --lanes 1 --steps 4 --warmup 2 --no-cpu-baseline --no-fp32-timing --no-other-configs"
 run() { local name=$1; shift; (timeout 280 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $OUT/${TAG}_$name -- $B > $OUT/${TAG}_$name.log 2>&1; echo "$name exit=$?"); }
 run sq1 SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM
 run sq2 SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_SALU SQ_INSTS_SMEM SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE
