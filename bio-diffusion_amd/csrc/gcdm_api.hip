@@ -59,11 +59,11 @@ struct gcdm_handle {
     // plan
     int B = 0, N = 0, max_n = 0;
     int64_t E = 0;
-    int *d_noff = nullptr, *d_erow = nullptr, *d_ecol = nullptr, *d_ncnt = nullptr;
+    int *d_noff = nullptr, *d_erow = nullptr, *d_ecol = nullptr, *d_ncnt = nullptr, *d_rowstart = nullptr;
     float* ws = nullptr;  // workspace pool
     size_t ws_floats = 0;
     float *X0 = nullptr, *XC = nullptr, *FBAR = nullptr, *CHI0 = nullptr, *HIN4 = nullptr, *H4 = nullptr, *CHI = nullptr, *PQ4 = nullptr,
-          *VDI = nullptr, *VDJ = nullptr, *AGG = nullptr, *VEL = nullptr, *EPS = nullptr, *TBUF = nullptr, *EP4 = nullptr, *AL = nullptr, *U = nullptr, *FR = nullptr, *PROF = nullptr, *ZK = nullptr, *ZU = nullptr;
+          *VDI = nullptr, *VDJ = nullptr, *AGG = nullptr, *PART = nullptr, *VEL = nullptr, *EPS = nullptr, *TBUF = nullptr, *EP4 = nullptr, *AL = nullptr, *U = nullptr, *FR = nullptr, *PROF = nullptr, *ZK = nullptr, *ZU = nullptr;
     uint32_t* d_flags = nullptr;
     float* d_gmean = nullptr;
     int flat_prev = 0, flat_next = 0;   // the plan is a slice of a larger flat batch (options "flat_prev" / "flat_next"; include/gcdm_hip.h)
@@ -72,10 +72,10 @@ struct gcdm_handle {
     int cog_fix = 1;                 // gcdm_sample_final re-projects drifting centres of gravity (off for chain frames, reference :1389)
     int layer_limit = -1;
     int edge_tile = 0;               // 64: one 8-wave workgroup per CU; 32: two 4-wave workgroups per CU; 0: automatic (env GCDM_EDGE_TILE)
-    // automatic choice, measured on MI355X: split-precision kernel at the QM9 edge width -> 32 (+3..5 %; +12 % on
-    // 100-molecule evaluation batches; QM9 molecules have <= 29 atoms, so a row is cut into at most 2 pieces and the result stays
-    // bit-reproducible), everything else 64 (GEOM: +-1 %, and rows of 44+ edges would be cut into >= 3 atomically added pieces)
-    int tile() const { return edge_tile ? edge_tile : ((use_x3() && Se == 64) ? 32 : 64); }
+    // automatic choice, measured on MI355X: split-precision kernels -> 32 (QM9 +-0 ... +2 %, GEOM +2 %, 100-molecule
+    // evaluation batches +12 ... 25 %: less round quantisation), fp32 kernels -> 64.  Rows cut by tile boundaries are summed from per-tile
+    // partials in tile order (AggSrc), so every choice is bit-reproducible for any molecule size.
+    int tile() const { return edge_tile ? edge_tile : (use_x3() ? 32 : 64); }
     bool x3_weights_ok = true;       // every GEMM weight fits the split-precision images (|W| < 31.9); else mfma_mode 1 is refused
     int mfma_x3 = 1;                 // requested mode -- 1: split-precision f16 x3 kernels (default; env GCDM_MFMA=f16x3|f32), 0: fp32 MFMA
     bool use_x3() const { return mfma_x3 && x3_weights_ok; }   // effective mode: models whose weights do not fit the split images run fp32 MFMA
@@ -396,8 +396,9 @@ void free_plan(gcdm_handle* h) {
     if (h->d_erow) (void)hipFree(h->d_erow);
     if (h->d_ecol) (void)hipFree(h->d_ecol);
     if (h->d_ncnt) (void)hipFree(h->d_ncnt);
+    if (h->d_rowstart) (void)hipFree(h->d_rowstart);
     if (h->ws) (void)hipFree(h->ws);
-    h->d_noff = h->d_erow = h->d_ecol = h->d_ncnt = nullptr;
+    h->d_noff = h->d_erow = h->d_ecol = h->d_ncnt = h->d_rowstart = nullptr;
     h->ws = nullptr;
     h->B = h->N = 0;
     h->E = 0;
@@ -696,12 +697,13 @@ int gcdm_plan_batch(gcdm_handle* h, int32_t B, const int32_t* nn) {
     // k_sample / k_prep stage one molecule in LDS (max_n * (3 + F) floats, 64 KB without an opt-in attribute)
     if (max_n > 4096 || (size_t)max_n * h->D * sizeof(float) > 65536) return fail(h, "gcdm_plan_batch: molecule too large (max_n * (3 + F) floats must fit 64 KB of LDS)");
     const int N = noff[B];
-    std::vector<int> erow(E), ecol(E), ncnt(N);
+    std::vector<int> erow(E), ecol(E), ncnt(N), rowstart(N);
     int64_t p = 0;
     for (int b = 0; b < B; ++b) {
         const int o = noff[b], n = nn[b];
         for (int i = 0; i < n; ++i) {
             ncnt[o + i] = n;
+            rowstart[o + i] = (int)p;
             for (int j = 0; j < n; ++j, ++p) { erow[p] = o + i; ecol[p] = o + j; }
         }
     }
@@ -709,6 +711,8 @@ int gcdm_plan_batch(gcdm_handle* h, int32_t B, const int32_t* nn) {
     HIP_OK(h, hipMalloc(&h->d_erow, E * sizeof(int)));
     HIP_OK(h, hipMalloc(&h->d_ecol, E * sizeof(int)));
     HIP_OK(h, hipMalloc(&h->d_ncnt, N * sizeof(int)));
+    HIP_OK(h, hipMalloc(&h->d_rowstart, N * sizeof(int)));
+    HIP_OK(h, hipMemcpy(h->d_rowstart, rowstart.data(), N * sizeof(int), hipMemcpyHostToDevice));
     HIP_OK(h, hipMemcpy(h->d_noff, noff.data(), (B + 1) * sizeof(int), hipMemcpyHostToDevice));
     HIP_OK(h, hipMemcpy(h->d_erow, erow.data(), E * sizeof(int), hipMemcpyHostToDevice));
     HIP_OK(h, hipMemcpy(h->d_ecol, ecol.data(), E * sizeof(int), hipMemcpyHostToDevice));
@@ -719,7 +723,7 @@ int gcdm_plan_batch(gcdm_handle* h, int32_t B, const int32_t* nn) {
     const size_t n = (size_t)N, e = (size_t)E;
     const size_t oX0 = take(3 * n), oXC = take(3 * n), oFB = take(9 * n), oC0 = take(12 * n), oHIN = take(4 * h->FinG * n), oH4 = take(GCDM_S * n),
                  oCHI = take(96 * n), oPQ = take(512 * n), oVDI = take((size_t)(h->H0 + 3) * 3 * n), oVDJ = take((size_t)(h->H0 + 3) * 3 * n),
-                 oAGG = take(GCDM_AGGW * n), oVEL = take(3 * n), oEPS = take((size_t)h->D * n), oT = take(n), oEP = take((size_t)h->Se * e),
+                 oAGG = take(GCDM_AGGW * n), oPART = take(((e + 31) / 32) * 2 * GCDM_AGGW), oVEL = take(3 * n), oEPS = take((size_t)h->D * n), oT = take(n), oEP = take((size_t)h->Se * e),
                  oAL = take((size_t)h->Ve * e), oU = take(3 * e), oFR = take(9 * e), oPROF = take(((e + 31) / 32) * 192),
                  oX0SC = take(h->sc ? 3 * n : 0), oBL = take(h->sc ? (size_t)h->Ve * e : 0), oUSC = take(h->sc ? 3 * e : 0),
                  oZK = take((size_t)h->D * n), oZU = take((size_t)h->D * n);
@@ -728,7 +732,7 @@ int gcdm_plan_batch(gcdm_handle* h, int32_t B, const int32_t* nn) {
     HIP_OK(h, hipMemset(h->ws, 0, off * sizeof(float)));
     float* w = h->ws;
     h->X0 = w + oX0; h->XC = w + oXC; h->FBAR = w + oFB; h->CHI0 = w + oC0; h->HIN4 = w + oHIN; h->H4 = w + oH4; h->CHI = w + oCHI;
-    h->PQ4 = w + oPQ; h->VDI = w + oVDI; h->VDJ = w + oVDJ; h->AGG = w + oAGG; h->VEL = w + oVEL; h->EPS = w + oEPS; h->TBUF = w + oT; h->EP4 = w + oEP;
+    h->PQ4 = w + oPQ; h->VDI = w + oVDI; h->VDJ = w + oVDJ; h->AGG = w + oAGG; h->PART = w + oPART; h->VEL = w + oVEL; h->EPS = w + oEPS; h->TBUF = w + oT; h->EP4 = w + oEP;
     h->AL = w + oAL; h->U = w + oU; h->FR = w + oFR; h->PROF = w + oPROF;
     h->ZK = w + oZK; h->ZU = w + oZU;
     h->X0SC = h->sc ? w + oX0SC : nullptr; h->BL = h->sc ? w + oBL : nullptr; h->USC = h->sc ? w + oUSC : nullptr;
@@ -787,7 +791,7 @@ int gcdm_forward_sc(gcdm_handle* h, const float* xh, const float* xh_sc, const f
     NodeArgs na{};
     na.N = N; na.F = h->F; na.C = h->C; na.FinG = h->FinG; na.Dout = h->D; na.pos_weight = h->cfg.node_positions_weight;
     na.HIN4 = (const v4f*)h->HIN4; na.CHI0 = h->CHI0; na.emb = h->emb;
-    na.AGG = h->AGG; na.H4 = (v4f*)h->H4; na.CHI = h->CHI; na.XC = h->XC; na.X0 = h->X0; na.FBAR = h->FBAR;
+    na.agg = AggSrc{h->AGG, h->PART, h->d_rowstart, h->d_ncnt, 0}; na.H4 = (v4f*)h->H4; na.CHI = h->CHI; na.XC = h->XC; na.X0 = h->X0; na.FBAR = h->FBAR;
     na.PQ4 = (v4f*)h->PQ4; na.VDI = h->VDI; na.VDJ = h->VDJ; na.H0 = h->H0;
     na.proj = h->proj; na.OUT = out; na.VEL = h->VEL; na.flags_dev = h->d_flags;
     auto set_next = [&](int l) {
@@ -826,13 +830,13 @@ int gcdm_forward_sc(gcdm_handle* h, const float* xh, const float* xh_sc, const f
     if (!node_kb_ok) return -1;
     const int ET = h->tile();
     const int tiles = (E + ET - 1) / ET;
+    na.agg.tile_shift = ET == 32 ? 5 : 6;
     for (int l = 0; l < L; ++l) {
         const LayerDev& d = h->layers[l];
-        HIP_OK(h, hipMemsetAsync(h->AGG, 0, (size_t)N * GCDM_AGGW * sizeof(float), st));
         EdgeMsgArgs ma{};
         ma.EP4 = (const v4f*)h->EP4; ma.AL = h->AL; ma.U = h->U; ma.FR = h->FR; ma.EROW = h->d_erow; ma.ECOL = h->d_ecol; ma.NCNT = h->d_ncnt;
         ma.BL = h->BL; ma.USC = h->USC;
-        ma.E = E; ma.N = N; ma.PQ4 = (const v4f*)h->PQ4; ma.VDI = h->VDI; ma.VDJ = h->VDJ; ma.AGG = h->AGG;
+        ma.E = E; ma.N = N; ma.PQ4 = (const v4f*)h->PQ4; ma.VDI = h->VDI; ma.VDJ = h->VDJ; ma.AGG = h->AGG; ma.PART = h->PART;
         ma.w0 = d.w0; ma.G0 = d.G0; ma.wddE = d.wddE; ma.wg0 = d.wg0; ma.bg0 = d.bg0; ma.wup0 = d.wup0;
         for (int k = 0; k < 3; ++k) ma.mk[k] = d.mk[k];
         ma.wa = d.wa; ma.ba = d.ba;
@@ -1139,7 +1143,31 @@ int64_t gcdm_debug_read(gcdm_handle* h, const char* name, float* host_out, int64
     else if (k == "chi") { p = h->CHI; cnt = 96 * n; }
     else if (k == "x") { p = h->XC; cnt = 3 * n; }
     else if (k == "x0") { p = h->X0; cnt = 3 * n; }
-    else if (k == "agg") { p = h->AGG; cnt = GCDM_AGGW * n; }
+    else if (k == "agg") {              // assembled on the host: whole rows from AGG, cut rows = their partial sums in tile order (AggSrc)
+        cnt = GCDM_AGGW * n;
+        if (!host_out) return cnt;
+        if (capacity < cnt) return fail(h, "gcdm_debug_read: capacity too small");
+        DeviceGuard guard(h->cfg.device);
+        const int ET = h->tile(), sh = ET == 32 ? 5 : 6;
+        const int64_t tiles = (e + ET - 1) / ET;
+        std::vector<float> part((size_t)tiles * 2 * GCDM_AGGW);
+        std::vector<int> rs(n), nc(n);
+        if (hipDeviceSynchronize() != hipSuccess || hipMemcpy(host_out, h->AGG, cnt * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess ||
+            hipMemcpy(part.data(), h->PART, part.size() * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess ||
+            hipMemcpy(rs.data(), h->d_rowstart, n * sizeof(int), hipMemcpyDeviceToHost) != hipSuccess ||
+            hipMemcpy(nc.data(), h->d_ncnt, n * sizeof(int), hipMemcpyDeviceToHost) != hipSuccess)
+            return fail(h, "gcdm_debug_read: copy failed");
+        for (int64_t i = 0; i < n; ++i) {
+            const int t0 = rs[i] >> sh, t1 = (rs[i] + nc[i] - 1) >> sh;
+            if (t0 == t1) continue;
+            float* dst = host_out + i * GCDM_AGGW;
+            const float* src = part.data() + ((size_t)t0 * 2 + ((rs[i] & (ET - 1)) ? 1 : 0)) * GCDM_AGGW;
+            for (int c = 0; c < GCDM_AGGW; ++c) dst[c] = src[c];
+            for (int t = t0 + 1; t <= t1; ++t)
+                for (int c = 0; c < GCDM_AGGW; ++c) dst[c] += part[((size_t)t * 2) * GCDM_AGGW + c];
+        }
+        return cnt;
+    }
     else if (k == "ep") { p = h->EP4; cnt = (int64_t)h->Se * e; }
     else if (k == "alpha") { p = h->AL; cnt = (int64_t)h->Ve * e; }
     else if (k == "u") { p = h->U; cnt = 3 * e; }

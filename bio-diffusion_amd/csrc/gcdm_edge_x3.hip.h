@@ -899,23 +899,17 @@ __global__ __launch_bounds__(ET * 8) __attribute__((amdgpu_waves_per_eu(2, 2))) 
             const int sb = m_seg[sg], en = m_seg[sg + 1];
             const int node = m_row[sb];
             const bool whole = (en - sb) == a.NCNT[node];
-            float* dst = a.AGG + (size_t)node * GCDM_AGGW;
+            float* dst = whole ? a.AGG + (size_t)node * GCDM_AGGW : a.PART + ((size_t)(e0 / ET) * 2 + (sb == 0 ? 0 : 1)) * GCDM_AGGW;
             if (un < GCDM_SG) {
                 v4f s = {0.f, 0.f, 0.f, 0.f};
                 for (int x = sb; x < en; ++x) s += XS4[un * ETP + x] * m_att[x];
-                if (whole) {
-                    *(v4f*)(dst + 4 * un) = s;
-                } else {
-#pragma unroll
-                    for (int t = 0; t < 4; ++t) atomicAdd(dst + 4 * un + t, s[t]);
-                }
+                *(v4f*)(dst + 4 * un) = s;
             } else {
                 const int r = un - GCDM_SG, c = r / 3, comp = r - 3 * c;      // AGG column S + 3c + comp (reference flatten layout)
                 const float* vp = (const float*)(VV4 + (comp * 8 + (c >> 2)) * ETP) + (c & 3);
                 float s = 0.f;
                 for (int x = sb; x < en; ++x) s += vp[4 * x];
-                if (whole) dst[GCDM_S + r] = s;
-                else atomicAdd(dst + GCDM_S + r, s);
+                dst[GCDM_S + r] = s;
             }
         }
     }

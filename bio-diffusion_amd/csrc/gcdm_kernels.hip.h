@@ -277,6 +277,52 @@ __device__ __forceinline__ void vec_finish(const float* PG, const float* __restr
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Aggregated messages, deterministic for any molecule size.  A node's row of n flat edges that lies inside ONE edge tile is summed
+// there and stored to AGG[node]; a row cut by tile boundaries leaves one partial sum per tile it touches in PART[tile][slot]
+// (slot 0: the piece touching the tile's first edge, slot 1: a piece that starts inside the tile and runs to its end), and the node
+// kernel adds the pieces in tile order.  No atomics, no zero-fill of AGG, bit-reproducible for rows spanning any number of tiles.
+// ------------------------------------------------------------------------------------------------
+struct AggSrc {
+    const float* AGG;      // [N][352] rows of nodes whose edge row lies inside one tile
+    const float* PART;     // [tiles][2][352] partial sums of cut rows
+    const int* ROWSTART;   // [N] flat index of the node's first edge
+    const int* NCNT;       // [N] row length (atoms of the node's molecule)
+    int tile_shift;        // log2(edges per tile) of the edge kernel that produced PART
+};
+
+struct AggRow {            // where to find node's aggregated row
+    const float* first;    // AGG row, or the first partial
+    const float* next;     // partial (slot 0) of tile t0 + 1
+    int extra;             // number of further tiles
+};
+
+__device__ __forceinline__ AggRow agg_row(const AggSrc& s, int node) {
+    const int rs = s.ROWSTART[node], n = s.NCNT[node];
+    const int t0 = rs >> s.tile_shift, t1 = (rs + n - 1) >> s.tile_shift;
+    AggRow r;
+    r.extra = t1 - t0;
+    if (r.extra == 0) {
+        r.first = s.AGG + (size_t)node * GCDM_AGGW;
+        r.next = r.first;
+    } else {
+        const int slot = (rs & ((1 << s.tile_shift) - 1)) ? 1 : 0;
+        r.first = s.PART + ((size_t)t0 * 2 + slot) * GCDM_AGGW;
+        r.next = s.PART + ((size_t)(t0 + 1) * 2) * GCDM_AGGW;
+    }
+    return r;
+}
+__device__ __forceinline__ v4f agg_load4(const AggRow& r, int col) {
+    v4f v = *(const v4f*)(r.first + col);
+    for (int t = 0; t < r.extra; ++t) v += *(const v4f*)(r.next + (size_t)t * 2 * GCDM_AGGW + col);
+    return v;
+}
+__device__ __forceinline__ float agg_load1(const AggRow& r, int col) {
+    float v = r.first[col];
+    for (int t = 0; t < r.extra; ++t) v += r.next[(size_t)t * 2 * GCDM_AGGW + col];
+    return v;
+}
+
 __device__ __forceinline__ void frame_of(float xi0, float xi1, float xi2, float xj0, float xj1, float xj2, float (&f)[9]) {
     // localize, components/__init__.py:122-171 (norm_x_diff=True)
     float d0 = xi0 - xj0, d1 = xi1 - xj1, d2 = xi2 - xj2;
@@ -500,7 +546,8 @@ struct EdgeMsgArgs {
     const v4f* PQ4;   // [128][N]: groups 0..63 = W_i h_i + b, groups 64..127 = W_j h_j  (msg0 scalar_out split)
     const float* VDI; // [(H0+3)*3][N] rows hh*3+x: [W_down;W_frames][:, 0:V] chi_i
     const float* VDJ; // same with the column block of chi_j
-    float* AGG;       // [N][352] (zeroed before launch; rows split across tiles are accumulated atomically)
+    float* AGG;       // [N][352] rows that lie inside one tile
+    float* PART;      // [tiles][2][352] partial sums of rows cut by tile boundaries (see AggSrc)
     // msg0
     const v4f* w0; int G0;       // packed [8][G0][64]; K' = [e'(Se) | n(H0 pad 4) | q(9 pad 12)] padded to 8
     const float* wddE;           // [(H0+3)][Ve]: columns V..V+Ve of [W_down; W_frames]
@@ -765,22 +812,16 @@ __global__ __launch_bounds__(EdgeGeo<ET>::THREADS) void k_edge_msg(EdgeMsgArgs a
             const int st = m_seg[sg], en = m_seg[sg + 1];
             const int node = m_row[st];
             const bool whole = (en - st) == a.NCNT[node];
-            float* dst = a.AGG + (size_t)node * GCDM_AGGW;
+            float* dst = whole ? a.AGG + (size_t)node * GCDM_AGGW : a.PART + ((size_t)blockIdx.x * 2 + (st == 0 ? 0 : 1)) * GCDM_AGGW;
             if (un < GCDM_SG) {
                 v4f s = {0.f, 0.f, 0.f, 0.f};
                 for (int x = st; x < en; ++x) s += XS4[un * ETP + x] * m_att[x];
-                if (whole) {
-                    *(v4f*)(dst + 4 * un) = s;
-                } else {
-#pragma unroll
-                    for (int t = 0; t < 4; ++t) atomicAdd(dst + 4 * un + t, s[t]);
-                }
+                *(v4f*)(dst + 4 * un) = s;
             } else {
                 const int r = un - GCDM_SG;
                 float s = 0.f;
                 for (int x = st; x < en; ++x) s += VV[r * ETP + x];
-                if (whole) dst[GCDM_S + r] = s;
-                else atomicAdd(dst + GCDM_S + r, s);
+                dst[GCDM_S + r] = s;
             }
         }
     }
@@ -801,7 +842,7 @@ struct NodeArgs {
     const v4f* HIN4; const float* CHI0;
     GcpW emb;
     // layer inputs
-    const float* AGG;
+    AggSrc agg;
     GcpW ff; GcpW pos;
     // shared state
     v4f* H4;        // [64][N]
@@ -886,10 +927,10 @@ __global__ __launch_bounds__(256) void k_node(NodeArgs a) {
         // agg (node-major rows of 352 floats): one wave reads a node's 64 scalar groups + 96 vector floats coalesced
         for (int x = wave; x < NT_; x += 4) {
             const int nd = min(n0 + x, N - 1);
-            const float* src = a.AGG + (size_t)nd * GCDM_AGGW;
-            XS4[lane * NTP + x] = *(const v4f*)(src + 4 * lane);
-            VV[lane * NTP + x] = src[GCDM_S + lane];
-            if (lane < 32) VV[(64 + lane) * NTP + x] = src[GCDM_S + 64 + lane];
+            const AggRow src = agg_row(a.agg, nd);
+            XS4[lane * NTP + x] = agg_load4(src, 4 * lane);
+            VV[lane * NTP + x] = agg_load1(src, GCDM_S + lane);
+            if (lane < 32) VV[(64 + lane) * NTP + x] = agg_load1(src, GCDM_S + 64 + lane);
         }
         for (int g = part; g < GCDM_SG; g += 8) XS4[(HB + g) * NTP + e] = a.H4[(size_t)g * N + nid];
         for (int r = part; r < 96; r += 8) VV[(CB * 3 + r) * NTP + e] = a.CHI[(size_t)r * N + nid];

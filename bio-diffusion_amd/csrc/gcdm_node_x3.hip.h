@@ -189,11 +189,11 @@ __global__ __launch_bounds__(NX_THREADS) void k_node_x3(NodeX3Args ax) {
     } else {
         // agg.s -> images (8-groups 0..31), agg.v -> VV channels 0..31, h -> registers + images (8-groups 32..63), chi -> VV channels 32..63
         {
-            const float* src = a.AGG + (size_t)nidl * GCDM_AGGW + 32 * wave + 4 * half;
+            const AggRow src = agg_row(a.agg, nidl);
             f32x16 t;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const v4f v = *(const v4f*)(src + 8 * q);
+                const v4f v = agg_load4(src, 32 * wave + 4 * half + 8 * q);
 #pragma unroll
                 for (int k = 0; k < 4; ++k) t[4 * q + k] = v[k];
             }
@@ -208,9 +208,9 @@ __global__ __launch_bounds__(NX_THREADS) void k_node_x3(NodeX3Args ax) {
         }
         for (int x = wave; x < NT_; x += 8) {
             const int nd = min(n0 + x, N - 1);
-            const float* src = a.AGG + (size_t)nd * GCDM_AGGW + GCDM_S;
-            VV[lane * NTP + x] = src[lane];
-            if (lane < 32) VV[(64 + lane) * NTP + x] = src[64 + lane];
+            const AggRow src = agg_row(a.agg, nd);
+            VV[lane * NTP + x] = agg_load1(src, GCDM_S + lane);
+            if (lane < 32) VV[(64 + lane) * NTP + x] = agg_load1(src, GCDM_S + 64 + lane);
         }
         for (int r = part; r < 96; r += PARTS) VV[(CB * 3 + r) * NTP + e] = a.CHI[(size_t)r * N + nid];
         __syncthreads();
