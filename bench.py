@@ -366,6 +366,29 @@ def main():
     edge_ms = mode_ms[x3_mode][1]
     fallback_ms = mode_ms[0][0] if 0 in mode_ms and x3_mode == 1 else None
 
+    # plug point 1: what the reference's UNCHANGED mol_gen_sample loop costs after the one-line registry swap -- per step one
+    # reference-signature sample_p_zs_given_zt (torch algebra on the device + GCPNetDynamics.forward, deferred range guard: no host sync)
+    plug1_ms = None
+    if world == 1 and args.streams == 1:
+        ddpm.to(dev)                                   # the reference-signature method does its schedule algebra with torch ops on the device
+        bidx = torch.repeat_interleave(torch.arange(B, device=dev), num_nodes.to(dev).long())
+        nmask = torch.ones(N, dtype=torch.bool, device=dev)
+        ctx_b1 = None if ctx is None else ctx
+        zz = z.clone()
+        def plug_step(si):
+            sa = torch.full((B, 1), si / T, device=dev)
+            ta = torch.full((B, 1), (si + 1) / T, device=dev)
+            return ddpm.sample_p_zs_given_zt(s=sa, t=ta, z=zz, batch_index=bidx, node_mask=nmask, context=ctx_b1)
+        for i in range(3):
+            zz = plug_step(900 - i)
+        torch.cuda.synchronize(dev)
+        tp = time.perf_counter()
+        for i in range(12):
+            zz = plug_step(890 - i)
+        torch.cuda.synchronize(dev)
+        plug1_ms = (time.perf_counter() - tp) / 12 * 1e3
+        dyn.check_deferred_flags()
+
     # finish the sample properly once (decode) so the path is exercised end to end, and gather like a real run would
     native.check(lib, h, lib.gcdm_sample_final(h, zp, cptr, None, seed, C.c_void_p(out.data_ptr()), fp, stream), "gcdm_sample_final")
     torch.cuda.synchronize(dev)
@@ -437,6 +460,9 @@ def main():
         # both matrix modes, measured the same way (whole batch, one handle); quote them together
         res["modes"] = {("f16x3" if m else "f32"): mode_entry(m) for m in sorted(mode_ms, reverse=True)}
         res["modes"]["measured_on"] = "whole batch on one handle, 8 steps wall clock after 3 settling steps; the headline ms_per_step runs the default mode as config.slices_of_the_batch slices"
+        res["plug_point_1"] = {"ms_per_step": plug1_ms, "value": None if plug1_ms is None else world * B / (plug1_ms * 1e-3 * NET_EVALS_PER_SAMPLE), "unit": "molecules/s",
+                               "what": "reference-signature sample_p_zs_given_zt per step (torch algebra + GCPNetDynamics.forward on one handle, no per-call host sync): "
+                                       "the cost of the reference's unchanged sampling loop after the dynamics_networks registry swap"}
         res["roofline"]["pmc_stale"] = pmc.get("stale")
         res["roofline"]["pmc_collected_at_commit"] = pmc.get("collected_at_commit")
         if args.workload == "qm9" and world == 1 and not args.no_other_configs and args.streams == 1:

@@ -11,10 +11,11 @@ The directory name contains a hyphen; import it with ``importlib.import_module("
 through the alias module ``bio_diffusion_amd`` at the repository root.
 """
 from .config import AttrDict, default_cfgs, load_cfg_tree, dataset_info          # noqa: F401
-from .gcpnet import GCP2, GCPNetDynamics                                        # noqa: F401
+from .gcpnet import GCP2, GCPNetDynamics, F16RangeError                                        # noqa: F401
 from .variational_diffusion import EquivariantVariationalDiffusion, PredefinedNoiseSchedule, NumNodesDistribution  # noqa: F401
 from .mol_gen_ddpm import QM9MoleculeGenerationDDPM, GEOMMoleculeGenerationDDPM, sample_sweep_conditionally  # noqa: F401
-from . import _native, stability, xyz                                           # noqa: F401
+from . import _native, stability, xyz, sdf                                      # noqa: F401
+from .sdf import write_sdf_file, build_molecules, bond_order_matrices, Molecule  # noqa: F401
 from .xyz import save_xyz_file, write_xyz_file                                  # noqa: F401
 from .stability import check_molecular_stability, check_molecular_stability_batch, get_bond_length_arrays, CategoricalDistribution  # noqa: F401
 
@@ -23,5 +24,5 @@ __all__ = [
     "EquivariantVariationalDiffusion", "PredefinedNoiseSchedule", "NumNodesDistribution",
     "QM9MoleculeGenerationDDPM", "GEOMMoleculeGenerationDDPM",
     "check_molecular_stability", "check_molecular_stability_batch", "get_bond_length_arrays", "CategoricalDistribution",
-    "save_xyz_file", "write_xyz_file",
+    "save_xyz_file", "write_xyz_file", "write_sdf_file", "build_molecules", "bond_order_matrices", "Molecule", "F16RangeError",
 ]

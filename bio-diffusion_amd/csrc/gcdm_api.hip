@@ -746,7 +746,17 @@ int gcdm_check_stability(const GcdmBondTables* tables, const float* x, int64_t x
     if (num_molecules == 0) return 0;
     if (!x || !atom_types || !mol_offsets || !out) return -1;
     hipLaunchKernelGGL(k_stability, dim3(num_molecules), dim3(64), 0, (hipStream_t)stream, *tables, x, (long)x_row_stride, atom_types,
-                       mol_offsets, out);
+                       mol_offsets, out, (const int64_t*)nullptr, (uint8_t*)nullptr);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+int gcdm_bond_orders(const GcdmBondTables* tables, const float* x, int64_t x_row_stride, const int32_t* atom_types, const int32_t* mol_offsets,
+                     int32_t num_molecules, const int64_t* pair_offsets, uint8_t* orders, void* stream) {
+    if (!tables || tables->num_types < 1 || tables->num_types > GCDM_STABILITY_MAX_TYPES || num_molecules < 0 || x_row_stride < 3) return -1;
+    if (num_molecules == 0) return 0;
+    if (!x || !atom_types || !mol_offsets || !pair_offsets || !orders) return -1;
+    hipLaunchKernelGGL(k_stability, dim3(num_molecules), dim3(64), 0, (hipStream_t)stream, *tables, x, (long)x_row_stride, atom_types,
+                       mol_offsets, (int32_t*)nullptr, pair_offsets, orders);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 

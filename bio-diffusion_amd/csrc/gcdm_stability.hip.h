@@ -17,7 +17,8 @@ constexpr int STAB_LDS_ATOMS = 1024;
 
 __global__ __launch_bounds__(64) void k_stability(GcdmBondTables tb, const float* __restrict__ x, long stride,
                                                   const int32_t* __restrict__ types, const int32_t* __restrict__ off,
-                                                  int32_t* __restrict__ out) {
+                                                  int32_t* __restrict__ out, const int64_t* __restrict__ pair_off = nullptr,
+                                                  uint8_t* __restrict__ orders = nullptr) {
     __shared__ float sx[STAB_LDS_ATOMS], sy[STAB_LDS_ATOMS], sz[STAB_LDS_ATOMS];
     __shared__ int st[STAB_LDS_ATOMS];
     const int m = blockIdx.x, lane = threadIdx.x;
@@ -49,13 +50,14 @@ __global__ __launch_bounds__(64) void k_stability(GcdmBondTables tb, const float
             o = d < tb.thr2[k] ? 2 : o;
             o = d < tb.thr3[k] ? 3 : o;
             if (tb.limit_bonds_to_one && o > 1) o = 1;
+            if (orders) orders[pair_off[m] + (int64_t)i * n + j] = (uint8_t)((j == i) ? 0 : o);     // n x n bond-order matrix (get_bond_order_batch, :61-87)
             nb += (j == i) ? 0 : o;
         }
         stable += (nb < 32 && ((tb.allowed_mask[ti] >> nb) & 1u)) ? 1 : 0;
     }
 #pragma unroll
     for (int s = 32; s > 0; s >>= 1) stable += __shfl_xor(stable, s);
-    if (lane == 0) {
+    if (lane == 0 && out) {
         out[3 * m + 0] = (stable == n) ? 1 : 0;
         out[3 * m + 1] = stable;
         out[3 * m + 2] = n;

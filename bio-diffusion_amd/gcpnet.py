@@ -130,6 +130,10 @@ class GCPInteractions(nn.Module):
         _fused_only("GCPInteractions")
 
 
+class F16RangeError(RuntimeError):
+    """An activation left the range of the split-precision images (deferred range guard of GCPNetDynamics.forward)."""
+
+
 class GCPNetDynamics(nn.Module):
     """Drop-in for the reference ``dynamics_networks["gcpnet"]`` (src/models/qm9_mol_gen_ddpm.py:101-131).
 
@@ -177,7 +181,14 @@ class GCPNetDynamics(nn.Module):
         self._weights_version = None
         self._plan_key = None
         self._flags = None
-        self.check_f16_range = True
+        # Range guard of the split-precision mode on the module-level call (plug point 1):
+        #   "deferred" (default): no host sync per call -- the device flag word of call k is copied to pinned host memory asynchronously and
+        #                         looked at when call k+1 (or read_flags / check_deferred_flags) comes; an activation beyond the f16 images
+        #                         (|x| > 1.2e8; trained models stay below 1e3) then raises F16RangeError and the handle falls back to fp32 MFMA;
+        #   True: one host sync per call, the call recomputes itself with fp32 MFMA (self-healing);   False: no check.
+        self.check_f16_range = "deferred"
+        self._flags_host = None
+        self._flags_event = None
 
     # ------------------------------------------------------------------------------------------
     def _native_config(self, device_index: int) -> "_native.GcdmConfig":
@@ -268,10 +279,19 @@ class GCPNetDynamics(nn.Module):
         self.sync_weights()
         self._plan_from_batch_index(cfg_get(batch, "batch"), cfg_get(batch, "mask"))
         ctx = cfg_get(batch, "props_context") if self.condition_on_context else None
+        if self.check_f16_range == "deferred":
+            self.check_deferred_flags(wait=False)          # the previous call's flag word, if it has arrived
         out = self.native_forward(xh, t, ctx, xh_self_cond=sc)
-        if self.mfma_mode == 1 and self.check_f16_range:
-            # split-precision mode: one host sync to make the module-level call self-healing (the fused sampler loop reads
-            # the flag once per run instead); an activation beyond the f16 range -> recompute this call with fp32 MFMA
+        if self.mfma_mode == 1 and self.check_f16_range == "deferred":
+            if self._flags_host is None:
+                self._flags_host = torch.zeros(1, dtype=torch.int32).pin_memory()
+                self._flags_event = torch.cuda.Event()
+            self._flags_host.copy_(self._flags, non_blocking=True)
+            self._flags_event.record(torch.cuda.current_stream(xh.device))
+            self._flags_pending = True
+        elif self.mfma_mode == 1 and self.check_f16_range:
+            # one host sync to make the module-level call self-healing (the fused sampler loop reads the flag once per run instead):
+            # an activation beyond the f16 range -> recompute this call with fp32 MFMA
             if self.read_flags() & _native.FLAG_F16_RANGE:
                 self.set_mfma_mode(0)
                 try:
@@ -279,6 +299,24 @@ class GCPNetDynamics(nn.Module):
                 finally:
                     self.set_mfma_mode(1)
         return batch, out
+
+    def check_deferred_flags(self, wait: bool = True) -> int:
+        """Looks at the asynchronously copied flag word of the last module-level call (deferred range guard).  Raises F16RangeError -- after
+        switching the handle to fp32 MFMA, so that a re-run is correct -- if an activation left the range of the split-precision images."""
+        if not getattr(self, "_flags_pending", False) or self._flags_event is None:
+            return 0
+        if not wait and not self._flags_event.query():
+            return 0
+        self._flags_event.synchronize()
+        self._flags_pending = False
+        v = int(self._flags_host.item())
+        if v & _native.FLAG_F16_RANGE:
+            self._flags.zero_()
+            self.set_mfma_mode(0)
+            raise F16RangeError("an activation exceeded the range of the split-precision (f16x3) images in an earlier forward call; its output "
+                                "was invalid.  The handle now runs fp32 MFMA: re-run the computation (or set check_f16_range=True for a "
+                                "self-healing, host-synchronising call)")
+        return v
 
     @property
     def mfma_mode(self) -> int:
@@ -324,6 +362,7 @@ class GCPNetDynamics(nn.Module):
     # ------------------------------------------------------------------------------------------
     def read_flags(self, reset: bool = True) -> int:
         """Device-side check word (host sync): bit 0 NaN in vel, bit 2 CoG drift re-projected."""
+        self._flags_pending = False
         v = int(self._flags.item()) if self._flags is not None else 0
         if reset and self._flags is not None:
             self._flags.zero_()

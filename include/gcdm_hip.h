@@ -229,6 +229,13 @@ typedef struct GcdmBondTables {
 int gcdm_check_stability(const GcdmBondTables* tables, const float* x, int64_t x_row_stride, const int32_t* atom_types,
                          const int32_t* mol_offsets, int32_t num_molecules, int32_t* out, void* stream);
 
+/* Bond orders of every atom pair (get_bond_order_batch, src/datamodules/components/edm/__init__.py:61-87; what make_mol_edm,
+ * rdkit_functions.py:276-320, builds its molecules from): for molecule m an n x n uint8 matrix at orders[pair_offsets[m] ..], entry
+ * (i, j) = 0 / 1 / 2 / 3, diagonal 0.  Same arguments as gcdm_check_stability; pair_offsets device int64 [num_molecules], orders device
+ * uint8 [sum n^2].  Feeds the SDF / molfile writer (write_sdf_file, src/models/components/__init__.py:372-378) without RDKit. */
+int gcdm_bond_orders(const GcdmBondTables* tables, const float* x, int64_t x_row_stride, const int32_t* atom_types,
+                     const int32_t* mol_offsets, int32_t num_molecules, const int64_t* pair_offsets, uint8_t* orders, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -314,6 +314,14 @@ def test_f16_range_flag_and_fp32_fallback():
     assert net.mfma_mode == 1
     assert torch.equal(got, want) or (got - want).abs().max().item() <= 1e-6 * scale
     del raw
+    # deferred guard (the default of the module-level call): no host sync per call, the flag surfaces at the next look and the handle falls back
+    net.check_f16_range = "deferred"
+    _fwd(net, xh, t, bi)
+    with pytest.raises(pkg.F16RangeError):
+        net.check_deferred_flags()
+    assert net.mfma_mode == 0
+    net.set_mfma_mode(1)
+    net.read_flags()
 
 
 def test_weights_outside_split_range_use_fp32_mfma():

@@ -325,3 +325,66 @@ def test_lanes_follow_weight_updates():
     assert (b2[:, :3] - b1[:, :3]).abs().max().item() <= 1e-4 * scale          # new weights in the lanes ...
     assert (b2[:, :3] - a2[:, :3]).abs().max().item() > 3e-4 * scale           # ... and they do differ from the old ones
     ddpm.release_lanes()
+
+
+def test_sdf_records_round_trip(tmp_path):
+    """V2000 records of the SDF writer (mirror of write_sdf_file, src/models/components/__init__.py:372-378): layout and round trip (host only)."""
+    sdf = pkg.sdf
+    mols = [sdf.Molecule(["C", "O", "H", "H"], np.array([[0.0, 0.0, 0.0], [1.2, 0.0, 0.0], [-0.55, 0.94, 0.0], [-0.55, -0.94, 0.0001]]),
+                         [(1, 0, 2), (2, 0, 1), (3, 0, 1)]),
+            None,
+            sdf.Molecule(["N", "H", "H", "H", "H"], np.random.default_rng(0).normal(size=(5, 3)), [(1, 0, 1), (2, 0, 1), (3, 0, 1), (4, 0, 1)],
+                         np.array([1, 0, 0, 0, 0]))]
+    path = tmp_path / "m.sdf"
+    sdf.write_sdf_file(path, mols)
+    text = open(path).read()
+    recs = text.split("$$$$\n")
+    assert len(recs) == 3 and recs[2] == ""                       # None is skipped, every record ends with $$$$
+    l = recs[0].split("\n")
+    assert l[0] == "" and l[1] == "     RDKit          3D" and l[2] == "" and l[3] == "  4  3  0  0  0  0  0  0  0  0999 V2000"
+    assert l[4] == "    0.0000    0.0000    0.0000 C   0  0  0  0  0  0  0  0  0  0  0  0" and len(l[4]) == 69
+    assert l[8] == "  2  1  2  0" and l[11] == "M  END"
+    assert "M  CHG  1   1   1" in recs[1]
+    back = sdf.read_sdf_file(path)
+    assert len(back) == 2
+    for m, b in zip([mols[0], mols[2]], back):
+        assert b.symbols == m.symbols and b.bonds == m.bonds
+        np.testing.assert_allclose(b.positions, m.positions, atol=5e-5)
+        assert (b.charges is None and m.charges is None) or list(b.charges) == list(m.charges)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ds", ["qm9", "geom"])
+def test_sdf_bond_tables_from_the_device_match_the_oracle(ds, tmp_path):
+    """Bond orders of every pair from the device kernel (gcdm_bond_orders) == the oracle's get_bond_order_batch on the golden molecules
+    (incl. the matrix the reference itself produced for molecule 6), and the SDF written from them parses back to the same connection tables."""
+    info = pkg.dataset_info(ds)
+    bonds = so.bond_length_arrays(TABLES, info["atom_encoder"])
+    sizes = torch.from_numpy(G[f"{ds}_sizes"].astype(np.int64))
+    x = torch.from_numpy(G[f"{ds}_x"]).cuda()
+    t = torch.from_numpy(G[f"{ds}_types"]).cuda()
+    limit = ds == "geom"                                               # make_mol_edm: limit_bonds_to_one = "GEOM" in dataset_info["name"]
+    E = pkg.bond_order_matrices(x, t, sizes, info)
+    for m, (xm, tm) in enumerate(molecules(ds)):
+        n = len(tm)
+        if so.threshold_gap(xm, tm, bonds, TABLES["margins"]) < 1e-3:
+            continue                                                   # a distance within 1e-3 pm of a threshold: cdist's last bits decide
+        a1, a2 = np.meshgrid(tm.astype(np.int64), tm.astype(np.int64), indexing="xy")
+        want = so.bond_order_batch(a1.reshape(-1), a2.reshape(-1), so.pair_distances(xm).reshape(-1), bonds, TABLES["margins"], limit).reshape(n, n)
+        np.fill_diagonal(want, 0)
+        np.testing.assert_array_equal(E[m].astype(np.int64), want)
+    ref6 = G[f"{ds}_order1_mol6" if limit else f"{ds}_order_mol6"].reshape(E[6].shape).copy()
+    np.fill_diagonal(ref6, 0)
+    np.testing.assert_array_equal(E[6].astype(np.int64), ref6)
+    mols = pkg.build_molecules(x, t, sizes, info)
+    path = tmp_path / f"{ds}.sdf"
+    pkg.write_sdf_file(path, [m for m in mols if len(m.symbols) <= 999 and len(m.bonds) <= 999])
+    back = pkg.sdf.read_sdf_file(path)
+    k = 0
+    for m, e in zip(mols, E):
+        if len(m.symbols) > 999 or len(m.bonds) > 999:
+            continue
+        tri = np.tril(e, -1)
+        assert back[k].bonds == [(int(i), int(j), int(tri[i, j])) for i, j in zip(*np.nonzero(tri))]
+        assert back[k].symbols == m.symbols
+        k += 1
