@@ -32,6 +32,7 @@ struct LayerDev {
     // split-precision (f16 x3) images of the edge-kernel GEMM weights
     const h8 *w0H, *w0L, *wg0H, *wg0L, *wH[3], *wL[3], *wgH[3], *wgL[3];
     const h8 *vpH[3], *vpL[3], *vf1[3], *vf2[3], *vf0H, *vf0L;   // vector path on the matrix pipe (gcdm_edge_x3.hip.h)
+    const h8 *vdH, *vdL;
     int KB0, KB;
     GcpX3 ffx, posx;
     const h8 *wpqH, *wpqL;
@@ -243,6 +244,23 @@ void pack_vec_fin(const WU& wu, std::vector<float>& out1, std::vector<float>& ou
     out2 = f16_words(A2);
 }
 
+// generic small-M matrix W [R][K] as 16x16x32 A operands in natural K order: packed [ceil(R/16)][K/32][64 lanes] x 8 f16
+// (node kernels: vecmat_mfma, gcdm_node_x3.hip.h)
+void pack_vecmat(const std::vector<float>& W, int R, int K, std::vector<float>& outH, std::vector<float>& outL) {
+    const int MT = (R + 15) / 16, KBn = K / 32;
+    std::vector<uint16_t> H((size_t)MT * KBn * 64 * 8, 0), L(H.size(), 0);
+    for (int m = 0; m < MT; ++m)
+        for (int kb = 0; kb < KBn; ++kb)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int j = 0; j < 8; ++j) {
+                    const int r = 16 * m + (lane & 15), c = 32 * kb + 8 * (lane >> 4) + j;
+                    const size_t o = (((size_t)m * KBn + kb) * 64 + lane) * 8 + j;
+                    split_f16(r < R ? W[(size_t)r * K + c] : 0.f, H[o], L[o]);
+                }
+    outH = f16_words(H);
+    outL = f16_words(L);
+}
+
 // vector_up of msg0 [32][H0], k = hidden channel (H0 <= 32)
 template <typename WU>
 void pack_vec_fin0(const WU& wu, int H0, std::vector<float>& outH, std::vector<float>& outL) {
@@ -286,6 +304,7 @@ struct GcpOff {
     bool has_w2 = false, has_gate = false;
     int G = 0, H = 0, V_in = 0, V_out = 0;
     size_t xwH = 0, xwL = 0, xw2H = 0, xw2L = 0, xwgH = 0, xwgL = 0;   // split-precision images
+    size_t xvmH = 0, xvmL = 0; bool has_vm = false;
     int KB = 0;
 };
 
@@ -326,6 +345,11 @@ bool build_gcp(gcdm_handle* h, Pool& pool, const std::string& pre, int s_in, int
     for (int r = 0; r < H; ++r) for (int c = 0; c < v_in; ++c) dd[(size_t)r * v_in + c] = wd.at(r, c);
     for (int r = 0; r < 3; ++r) for (int c = 0; c < v_in; ++c) dd[(size_t)(H + r) * v_in + c] = wdf.at(r, c);
     o.wdd = pool.add(dd);
+    if (v_in % 32 == 0) {            // vector pre-phase on the matrix pipe (node kernels)
+        std::vector<float> a, b;
+        pack_vecmat(dd, H + 3, v_in, a, b);
+        o.xvmH = pool.add(a); o.xvmL = pool.add(b); o.has_vm = true;
+    }
     if (ff) {
         WView w2, b2;
         if (!get_w(h, pre + "scalar_out.2.weight", s_out, s_out, w2) || !get_w(h, pre + "scalar_out.2.bias", 1, s_out, b2)) return false;
@@ -377,6 +401,7 @@ GcpX3 resolve_x3(const GcpOff& o, const float* base) {
     g.wH = (const h8*)(base + o.xwH); g.wL = (const h8*)(base + o.xwL); g.KB = o.KB;
     g.w2H = o.has_w2 ? (const h8*)(base + o.xw2H) : nullptr; g.w2L = o.has_w2 ? (const h8*)(base + o.xw2L) : nullptr;
     g.wgH = o.has_gate ? (const h8*)(base + o.xwgH) : nullptr; g.wgL = o.has_gate ? (const h8*)(base + o.xwgL) : nullptr;
+    g.vmH = o.has_vm ? (const h8*)(base + o.xvmH) : nullptr; g.vmL = o.has_vm ? (const h8*)(base + o.xvmL) : nullptr;
     return g;
 }
 
@@ -386,7 +411,7 @@ struct LayerOff {
     float ba;
     GcpOff mk[3], ff, pos;
     size_t w0H, w0L, wg0H, wg0L, wH[3], wL[3], wgH[3], wgL[3];
-    size_t vpH[3], vpL[3], vf1[3], vf2[3], vf0H, vf0L;
+    size_t vpH[3], vpL[3], vf1[3], vf2[3], vf0H, vf0L, vdH, vdL;
     size_t wpqH, wpqL;
     int KB0, KB;
 };
@@ -555,6 +580,13 @@ int gcdm_finalize_weights(gcdm_handle* h) {
                 for (int c = 0; c < V; ++c) dJ[(size_t)r * V + c] = src.at(rr, V + Ve + c);
             }
             o.wddI = pool.add(dI); o.wddJ = pool.add(dJ); o.wddE = pool.add(dE);
+            {   // [wddI; wddJ] (2 x (H0 + 3) rows x 32) for the node kernel's matrix-pipe evaluation of VDI / VDJ
+                std::vector<float> dIJ(dI);
+                dIJ.insert(dIJ.end(), dJ.begin(), dJ.end());
+                std::vector<float> a, b;
+                pack_vecmat(dIJ, 2 * (H0 + 3), V, a, b);
+                o.vdH = pool.add(a); o.vdL = pool.add(b);
+            }
             Dense Wg(32, S);
             for (int m = 0; m < V; ++m) for (int k = 0; k < S; ++k) Wg.at(m, k) = wg.at(m, k);
             o.wg0 = pool.add(pack_mfma(Wg));
@@ -655,6 +687,7 @@ int gcdm_finalize_weights(gcdm_handle* h) {
         d.wpqH = (const h8*)(base + o.wpqH); d.wpqL = (const h8*)(base + o.wpqL);
         d.wg0H = (const h8*)(base + o.wg0H); d.wg0L = (const h8*)(base + o.wg0L);
         d.vf0H = (const h8*)(base + o.vf0H); d.vf0L = (const h8*)(base + o.vf0L);
+        d.vdH = (const h8*)(base + o.vdH); d.vdL = (const h8*)(base + o.vdL);
         for (int k = 0; k < 3; ++k) {
             d.wH[k] = (const h8*)(base + o.wH[k]); d.wL[k] = (const h8*)(base + o.wL[k]);
             d.wgH[k] = (const h8*)(base + o.wgH[k]); d.wgL[k] = (const h8*)(base + o.wgL[k]);
@@ -825,7 +858,7 @@ int gcdm_forward_sc(gcdm_handle* h, const float* xh, const float* xh_sc, const f
                 node_kb_ok = false;
                 return;
             }
-            if (next_layer < h->L) { nx.wpqH = h->layers[next_layer].wpqH; nx.wpqL = h->layers[next_layer].wpqL; }
+            if (next_layer < h->L) { nx.wpqH = h->layers[next_layer].wpqH; nx.wpqL = h->layers[next_layer].wpqL; nx.vdH = h->layers[next_layer].vdH; nx.vdL = h->layers[next_layer].vdL; }
             if (embed && h->sc) hipLaunchKernelGGL((k_node_x3<true, 4>), dim3(ngrid), dim3(NX_THREADS), NK_LDS_BYTES, st, nx);
             else if (embed) hipLaunchKernelGGL(k_node_x3<true>, dim3(ngrid), dim3(NX_THREADS), NK_LDS_BYTES, st, nx);
             else hipLaunchKernelGGL(k_node_x3<false>, dim3(ngrid), dim3(NX_THREADS), NK_LDS_BYTES, st, nx);

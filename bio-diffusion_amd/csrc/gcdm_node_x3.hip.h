@@ -12,12 +12,14 @@ struct GcpX3 {
     const h8 *wH, *wL; int KB;     // scalar_out (first Linear) packed [M'/32][KB][64]
     const h8 *w2H, *w2L;           // feed-forward second Linear packed [8][16][64] (or null)
     const h8 *wgH, *wgL;           // vector gate packed [8][2][64] (or null)
+    const h8 *vmH, *vmL;           // [W_down; W_frames] as 16x16x32 A operands, packed [M-tiles][K-blocks][64] (pack_vecmat, gcdm_api.hip)
 };
 
 struct NodeX3Args {
     NodeArgs base;
     GcpX3 emb, ff, pos, proj;
     const h8 *wpqH, *wpqL;         // next layer's msg0 node halves, packed [16][16][64]
+    const h8 *vdH, *vdL;           // next layer's msg0 vector halves [wddI; wddJ] (2 x (H0+3) rows x 32) as 16x16x32 A operands, [3][1][64]
 };
 
 // generic GCP2 pre-phase writing the extended-K rows as hi / lo' images (rows of [W_down; W_frames] split over the PARTS threads of an entity)
@@ -77,6 +79,78 @@ __device__ __forceinline__ bool gcp2_pre_x3g(const float* __restrict__ wdd, cons
     return over;
 }
 
+// ---- small-M vector contractions of the node kernels on the matrix pipe --------------------------------------------------------
+// OUT[r][x][node] = sum_c W[r][c] * V[c][x][node]  (r < 16 MT rows, c < 32 KB channels; V = fp32 rows VV[(vch0 + c) * 3 + x][node]).
+// One wave per (component x, group of 16 nodes): waves 0..5 of the 8 (v_mfma_f32_16x16x32_f16, split precision; lane l: q = l >> 4,
+// n = l & 15 -- A[row n][k = 8q + j], B[k = 8q + j][col n], D[row 4q + i][col n]).  `store(row, x, node_in_tile, value)` receives
+// the results.  As VALU FMAs (16 threads per node, every thread re-reading all vector components) the same contractions cost
+// 700 (feed-forward pre-phase) and 670 (next layer's msg0 halves) instructions per thread.
+template <int MT, int KB, int TP, typename StoreFn>
+__device__ __forceinline__ void vecmat_mfma(const h8* __restrict__ wH, const h8* __restrict__ wL, const float* VV, int vch0, int wave, int lane,
+                                            float& amax, StoreFn store) {
+    if (wave >= 6) return;
+    const int x = wave % 3, g = wave / 3, q = lane >> 4, n = lane & 15;
+    f32x4 am[MT], al[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) { am[m] = (f32x4){0.f, 0.f, 0.f, 0.f}; al[m] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb) {
+        float v0[4], v1[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            v0[j] = VV[((vch0 + 32 * kb + 8 * q + j) * 3 + x) * TP + 16 * g + n];
+            v1[j] = VV[((vch0 + 32 * kb + 8 * q + 4 + j) * 3 + x) * TP + 16 * g + n];
+        }
+        h4 h0, l0, h1, l1;
+        split4(v0, h0, l0, amax);
+        split4(v1, h1, l1, amax);
+        const h8 bh = cat44(h0, h1), bl = cat44(l0, l1);
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            const h8 aH = wH[(m * KB + kb) * 64 + lane], aL = wL[(m * KB + kb) * 64 + lane];
+            am[m] = MFMA1632(aH, bh, am[m]);
+            al[m] = MFMA1632(aH, bl, al[m]);
+            al[m] = MFMA1632(aL, bh, al[m]);
+        }
+    }
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) store(16 * m + 4 * q + i, x, 16 * g + n, am[m][i] + al[m][i] * X3_INV_SCALE);
+}
+
+// second half of a GCP2 pre-phase: hidden vectors VH[(h*3 + x)][node] (rows 0..H-1) and frame vectors (rows H..H+2) -> norms and frame
+// scalars as hi / lo' images of the extended-K rows (gcpnet.py:442-459, scalarize: components/__init__.py:174-219)
+template <int T, int H, int NTHR>
+__device__ __forceinline__ bool gcp2_pre_tail_x3(const float* VH, const float* FR, char* XH, char* XL, int gN8, int gQ8, int gEnd8, int tid) {
+    constexpr int TP = T + 1, ROWS = H + 3;
+    bool over = false;
+    for (int it = tid; it < ROWS * T; it += NTHR) {
+        const int hh = it / T, e = it - hh * T;
+        const float vx = VH[(hh * 3 + 0) * TP + e], vy = VH[(hh * 3 + 1) * TP + e], vz = VH[(hh * 3 + 2) * TP + e];
+        if (hh < H) {
+            over |= put16(XH, XL, TP, gN8 + (hh >> 3), hh & 7, e, fast_sqrt(vx * vx + vy * vy + vz * vz + 1e-8f) + 1e-8f);
+        } else {
+            const int k = hh - H;
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+                const int idx = 3 * k + r;
+                over |= put16(XH, XL, TP, gQ8 + (idx >> 3), idx & 7, e, FR[(3 * r) * TP + e] * vx + FR[(3 * r + 1) * TP + e] * vy + FR[(3 * r + 2) * TP + e] * vz);
+            }
+        }
+    }
+    for (int it = tid; it < T; it += NTHR) {           // zero the padding slots (weights there are zero, LDS is not)
+        const int e = it;
+        for (int hh = H; hh < 8 * (gQ8 - gN8); ++hh) put16(XH, XL, TP, gN8 + (hh >> 3), hh & 7, e, 0.f);
+        for (int idx = 9; idx < 16; ++idx) put16(XH, XL, TP, gQ8 + (idx >> 3), idx & 7, e, 0.f);
+        for (int g = gQ8 + 2; g < gEnd8; ++g) {
+            *(v4f*)(XH + (g * TP + e) * 16) = (v4f){0.f, 0.f, 0.f, 0.f};
+            *(v4f*)(XL + (g * TP + e) * 16) = (v4f){0.f, 0.f, 0.f, 0.f};
+        }
+    }
+    return over;
+}
+
 // hi / lo' images of a C-layout register block (one M-tile, one N-tile) -> 8-groups gbase8 .. gbase8+3
 __device__ __forceinline__ bool store_block_x3(char* XH, char* XL, int gbase8, const f32x16& v, int TP, int lane) {
     f32x16 t[1][1] = {{v}};
@@ -112,8 +186,12 @@ __global__ __launch_bounds__(NX_THREADS) void k_node_x3(NodeX3Args ax) {
     const bool validl = (n0 + l31) < N;
     constexpr int HB8 = 32;   // 8-group base of h inside XH8/XL8 (LAYER: groups 0..31 hold agg.s, then the ff hidden activations)
     constexpr int CB = 32;    // channel base of chi inside VV
-    constexpr int PD = 2;
+#ifndef GCDM_NODE_PD
+#define GCDM_NODE_PD 2
+#endif
+    constexpr int PD = GCDM_NODE_PD;
     bool over = false;
+    float amax = 0.f;
 
     for (int r = part; r < 9; r += PARTS) FR[r * NTP + e] = a.FBAR[(size_t)r * N + nid];
     if (part < 3) XP[part * NTP + e] = a.XC[(size_t)part * N + nid];
@@ -217,7 +295,12 @@ __global__ __launch_bounds__(NX_THREADS) void k_node_x3(NodeX3Args ax) {
         // ---- feed-forward GCP2 ------------------------------------------------------------------------------------------------
         {
             const GcpW& w = a.ff;
-            over |= gcp2_pre_x3g<NT_, 16, 2 * GCDM_V, NX_THREADS>(w.wdd, VV, 0, FR, XH, XL, 64, 66, 2 * ax.ff.KB, VH, e, part);
+            // pre-phase: [W_down (16); W_frames (3)] x 64 input vectors on the matrix pipe -> VH, then norms / frame scalars
+            vecmat_mfma<2, 2, NTP>(ax.ff.vmH, ax.ff.vmL, VV, 0, wave, lane, amax, [&](int row, int x, int nd, float v) {
+                if (row < 19) VH[(row * 3 + x) * NTP + nd] = v;
+            });
+            __syncthreads();
+            over |= gcp2_pre_tail_x3<NT_, 16, NX_THREADS>(VH, FR, XH, XL, 64, 66, 2 * ax.ff.KB, tid);
             __syncthreads();
             acc_bias(w.b);
             gemm(integral_constant<int, 34>{}, ax.ff.wH, ax.ff.wL, ax.ff.KB, 0);        // K' = 512 + 16 + 16
@@ -245,7 +328,11 @@ __global__ __launch_bounds__(NX_THREADS) void k_node_x3(NodeX3Args ax) {
         // ---- position update GCP2 -------------------------------------------------------------------------------------------------
         {
             const GcpW& w = a.pos;
-            over |= gcp2_pre_x3g<NT_, 8, GCDM_V, NX_THREADS>(w.wdd, VV, CB, FR, XH, XL, 64, 65, HB8 + 2 * ax.pos.KB, VH, e, part);
+            vecmat_mfma<1, 1, NTP>(ax.pos.vmH, ax.pos.vmL, VV, CB, wave, lane, amax, [&](int row, int x, int nd, float v) {
+                if (row < 11) VH[(row * 3 + x) * NTP + nd] = v;
+            });
+            __syncthreads();
+            over |= gcp2_pre_tail_x3<NT_, 8, NX_THREADS>(VH, FR, XH, XL, 64, 65, HB8 + 2 * ax.pos.KB, tid);
             __syncthreads();
             acc_bias(w.b);
             gemm(integral_constant<int, 18>{}, ax.pos.wH, ax.pos.wL, ax.pos.KB, HB8);    // K' = 256 + 8 + 16 -> 288
@@ -296,22 +383,15 @@ __global__ __launch_bounds__(NX_THREADS) void k_node_x3(NodeX3Args ax) {
                 }
             }
         }
-        if (valid) {
+        // vector halves of the next layer's msg0: [W_down; W_frames][:, block] . chi for the row (I) and col (J) block -- 2 x (H0 + 3) rows
+        {
             const int rows = a.H0 + 3;
-            for (int it = part; it < 2 * rows; it += PARTS) {
-                const int side = it >= rows, hh = side ? it - rows : it;
-                const float* w = (side ? a.wddJ : a.wddI) + hh * GCDM_V;
-                const float* vp = VV + (CB * 3) * NTP + e;
-                float vx = 0.f, vy = 0.f, vz = 0.f;
-#pragma unroll 8
-                for (int c = 0; c < GCDM_V; ++c) {
-                    const float wc = w[c];
-                    vx += wc * vp[0]; vy += wc * vp[NTP]; vz += wc * vp[2 * NTP];
-                    vp += 3 * NTP;
+            vecmat_mfma<3, 1, NTP>(ax.vdH, ax.vdL, VV, CB, wave, lane, amax, [&](int row, int x, int nd, float v) {
+                if (row < 2 * rows && n0 + nd < N) {
+                    const int side = row >= rows, hh = side ? row - rows : row;
+                    (side ? a.VDJ : a.VDI)[(size_t)(hh * 3 + x) * N + n0 + nd] = v;
                 }
-                float* dst = (side ? a.VDJ : a.VDI) + (size_t)(hh * 3) * N + nid;
-                dst[0] = vx; dst[N] = vy; dst[2 * (size_t)N] = vz;
-            }
+            });
         }
     } else {
         // ---- scalar projection GCP2 (S, V) -> (F+1+C, 0), bottleneck 1, no activation (gcpnet.py:1191-1197) -----------------------
@@ -336,5 +416,6 @@ __global__ __launch_bounds__(NX_THREADS) void k_node_x3(NodeX3Args ax) {
             if (v != v) atomicOr(a.flags_dev, 1u);
         }
     }
+    over |= amax > X3_RANGE;
     if (__any(over) && lane == 0) atomicOr(a.flags_dev, GCDM_FLAG_F16_RANGE_BIT);
 }
