@@ -52,6 +52,7 @@ struct gcdm_handle {
     float *X0SC = nullptr, *BL = nullptr, *USC = nullptr;
     // device weights
     float* wpool = nullptr;
+    size_t wpool_bytes = 0;
     std::vector<LayerDev> layers;
     GcpW emb{}, proj{};
     GcpX3 embx{}, projx{};
@@ -664,6 +665,8 @@ int gcdm_finalize_weights(gcdm_handle* h) {
     h->wpool = nullptr;
     HIP_OK(h, hipMalloc(&h->wpool, pool.host.size() * sizeof(float)));
     HIP_OK(h, hipMemcpy(h->wpool, pool.host.data(), pool.host.size() * sizeof(float), hipMemcpyHostToDevice));
+    h->wpool_bytes = pool.host.size() * sizeof(float);
+    if (h->wpool_bytes >= ((size_t)1 << 32)) return fail(h, "gcdm_finalize_weights: weight pool exceeds 4 GB");
     const float* base = h->wpool;
     h->ee_ws = base + o_ws; h->ee_bs = base + o_bs; h->ee_wd = base + o_wd; h->ee_wdf = base + o_wdf;
     h->ee_kappa = base + o_kap; h->ee_wg = base + o_wg; h->ee_bg = base + o_bg;
@@ -892,6 +895,7 @@ int gcdm_forward_sc(gcdm_handle* h, const float* xh, const float* xh_sc, const f
             for (int k = 0; k < 3; ++k) { xa.wH[k] = d.wH[k]; xa.wL[k] = d.wL[k]; xa.wgH[k] = d.wgH[k]; xa.wgL[k] = d.wgL[k]; }
             for (int k = 0; k < 3; ++k) { xa.vpH[k] = d.vpH[k]; xa.vpL[k] = d.vpL[k]; xa.vf1[k] = d.vf1[k]; xa.vf2[k] = d.vf2[k]; }
             xa.vf0H = d.vf0H; xa.vf0L = d.vf0L;
+            xa.wpool = h->wpool; xa.wpool_bytes = (uint32_t)h->wpool_bytes;
             xa.flags_dev = h->d_flags;
             if (d.KB != 18 || d.KB0 != (h->Se == 64 ? 7 : 4)) return fail(h, "internal: k-block counts differ from the kernel's compile-time constants");
             if (ET == 64) {

@@ -64,6 +64,39 @@ struct X3Ring {
     h8 ah[PD + 1][MT], alo[PD + 1][MT];
 };
 
+// Weight stream through buffer loads: one resource descriptor for the whole weight pool (SGPRs), per-lane offset lane * 16 (one VGPR for
+// the whole kernel), and the array / M-tile / k-block offset as a scalar -- the address arithmetic of the stream is SALU only (global
+// loads cost the compiler a 64-bit VALU add per 4 KB of immediate-offset reach and stream).  Out-of-range reads return 0.
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+struct WPool {
+    __amdgpu_buffer_rsrc_t rsrc;
+    uint32_t voff;                 // lane * 16
+    const char* base;
+    __device__ __forceinline__ uint32_t off(const void* p) const { return (uint32_t)((const char*)p - base); }      // uniform
+    __device__ __forceinline__ h8 ld(uint32_t soff) const {
+        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, soff, 0);
+        h8 r;
+        __builtin_memcpy(&r, &v, 16);
+        return r;
+    }
+};
+__device__ __forceinline__ WPool make_wpool(const void* pool, uint32_t bytes, int lane) {
+    WPool w;
+    w.rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(pool), 0, bytes, 0x00020000);
+    w.voff = (uint32_t)lane * 16u;
+    w.base = (const char*)pool;
+    return w;
+}
+
+template <int MT, int PD>
+__device__ __forceinline__ void x3_prefetch_b(X3Ring<MT, PD>& ring, const WPool& wp, uint32_t oH, uint32_t oL, int KB) {
+    const uint32_t wstride = KB * 64 * 16;
+#pragma unroll
+    for (int r = 0; r < PD; ++r)
+#pragma unroll
+        for (int m = 0; m < MT; ++m) { ring.ah[r][m] = wp.ld(oH + m * wstride + r * 1024); ring.alo[r][m] = wp.ld(oL + m * wstride + r * 1024); }
+}
+
 // NOTE: the prefetches run PD k-blocks (A) / one k-block (B) past the end of the contraction without clamping: the packed weight
 // arrays carry X3_TAIL_BLOCKS zero blocks of padding behind the last M-tile, and the LDS reads stay inside the XH8|XL8|VV allocation.
 #define X3_TAIL_BLOCKS 4
@@ -144,12 +177,11 @@ __device__ __forceinline__ void static_for(F&& f) {
 }
 
 template <int MT, int NT, int PD, int KB, bool ZAM, bool ZAL>
-__device__ __forceinline__ void tile_gemm_x3z(f32x16 (&am)[MT][NT], f32x16 (&al)[MT][NT], X3Ring<MT, PD>& ring, const h8* __restrict__ wH,
-                                              const h8* __restrict__ wL, const h8* xh8, const h8* xl8, int TP, int lane) {
+__device__ __forceinline__ void tile_gemm_x3z(f32x16 (&am)[MT][NT], f32x16 (&al)[MT][NT], X3Ring<MT, PD>& ring, const WPool& wp, uint32_t wH,
+                                              uint32_t wL, const h8* xh8, const h8* xl8, int TP, int lane) {
     constexpr int R = PD + 1;
     constexpr int wstride = KB * 64;
-    const h8* wh = wH + lane + PD * 64;
-    const h8* wl = wL + lane + PD * 64;
+    // weights: uniform base (SGPR) + compile-time block offset + lane -- no per-block 64-bit VALU pointer arithmetic
     const int boff = (lane >> 5) * TP + (lane & 31);
     const h8* sh = xh8 + boff;
     const h8* sl = xl8 + boff;
@@ -160,13 +192,12 @@ __device__ __forceinline__ void tile_gemm_x3z(f32x16 (&am)[MT][NT], f32x16 (&al)
     static_for<0, KB>([&](auto rc) {
         constexpr int r = decltype(rc)::value;
 #pragma unroll
-        for (int m = 0; m < MT; ++m) { ring.ah[(r + PD) % R][m] = wh[m * wstride]; ring.alo[(r + PD) % R][m] = wl[m * wstride]; }
-        wh += 64;
-        wl += 64;
-        sh += 2 * TP;
-        sl += 2 * TP;
+        for (int m = 0; m < MT; ++m) {
+            ring.ah[(r + PD) % R][m] = wp.ld(wH + ((r + PD) * 64 + m * wstride) * 16);
+            ring.alo[(r + PD) % R][m] = wp.ld(wL + ((r + PD) * 64 + m * wstride) * 16);
+        }
 #pragma unroll
-        for (int n = 0; n < NT; ++n) { bh[(r + 1) & 1][n] = sh[n * 32]; bl[(r + 1) & 1][n] = sl[n * 32]; }
+        for (int n = 0; n < NT; ++n) { bh[(r + 1) & 1][n] = sh[(r + 1) * 2 * TP + n * 32]; bl[(r + 1) & 1][n] = sl[(r + 1) * 2 * TP + n * 32]; }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int m = 0; m < MT; ++m)
@@ -494,12 +525,10 @@ struct VecStage {
 // Scalar GEMM of a residual GCP2 with the vector stages in its shadow: k-blocks [0, SPLIT) carry hook(stage r) between their MFMAs
 // (vector waves; the others pass a no-op), then a workgroup barrier (the extended-K rows are complete), then k-blocks [SPLIT, KB).
 template <int MT, int NT, int PD, int KB, int SPLIT, bool HOOKED, class Hook>
-__device__ __forceinline__ void tile_gemm_x3s(f32x16 (&am)[MT][NT], f32x16 (&al)[MT][NT], X3Ring<MT, PD>& ring, const h8* __restrict__ wH,
-                                              const h8* __restrict__ wL, const h8* xh8, const h8* xl8, int TP, int lane, Hook&& hook) {
+__device__ __forceinline__ void tile_gemm_x3s(f32x16 (&am)[MT][NT], f32x16 (&al)[MT][NT], X3Ring<MT, PD>& ring, const WPool& wp, uint32_t wH,
+                                              uint32_t wL, const h8* xh8, const h8* xl8, int TP, int lane, Hook&& hook) {
     constexpr int R = PD + 1;
     constexpr int wstride = KB * 64;
-    const h8* wh = wH + lane + PD * 64;
-    const h8* wl = wL + lane + PD * 64;
     const int boff = (lane >> 5) * TP + (lane & 31);
     const h8* sh = xh8 + boff;
     const h8* sl = xl8 + boff;
@@ -511,14 +540,13 @@ __device__ __forceinline__ void tile_gemm_x3s(f32x16 (&am)[MT][NT], f32x16 (&al)
         constexpr int r = decltype(rc)::value;
         constexpr bool HK = decltype(hooked)::value;
 #pragma unroll
-        for (int m = 0; m < MT; ++m) { ring.ah[(r + PD) % R][m] = wh[m * wstride]; ring.alo[(r + PD) % R][m] = wl[m * wstride]; }
-        wh += 64;
-        wl += 64;
-        sh += 2 * TP;
-        sl += 2 * TP;
+        for (int m = 0; m < MT; ++m) {          // uniform base + compile-time block offset + lane: no per-block VALU pointer arithmetic
+            ring.ah[(r + PD) % R][m] = wp.ld(wH + ((r + PD) * 64 + m * wstride) * 16);
+            ring.alo[(r + PD) % R][m] = wp.ld(wL + ((r + PD) * 64 + m * wstride) * 16);
+        }
         if constexpr (r + 1 != SPLIT) {          // the block behind the barrier is read after the barrier
 #pragma unroll
-            for (int n = 0; n < NT; ++n) { bh[(r + 1) & 1][n] = sh[n * 32]; bl[(r + 1) & 1][n] = sl[n * 32]; }
+            for (int n = 0; n < NT; ++n) { bh[(r + 1) & 1][n] = sh[(r + 1) * 2 * TP + n * 32]; bl[(r + 1) & 1][n] = sl[(r + 1) * 2 * TP + n * 32]; }
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -535,18 +563,20 @@ __device__ __forceinline__ void tile_gemm_x3s(f32x16 (&am)[MT][NT], f32x16 (&al)
             for (int n = 0; n < NT; ++n) al[m][n] = MFMA16(ring.alo[r % R][m], bh[r & 1][n], al[m][n]);
         if constexpr (HK) {
             hook(rc);
+#if GCDM_VEC_PER_MFMA > 0
 #pragma unroll
             for (int i = 0; i < 3 * MT * NT; ++i) {      // one MFMA, then up to GCDM_VEC_PER_MFMA other instructions of the stage, ...
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
                 __builtin_amdgcn_sched_group_barrier(0x002 | 0x004 | 0x080 | 0x400 | 0x020, GCDM_VEC_PER_MFMA, 0);
             }
+#endif
         }
         __builtin_amdgcn_sched_barrier(0);
     };
     static_for<0, SPLIT>([&](auto rc) { body(rc, std::integral_constant<bool, HOOKED>{}); });
     __syncthreads();
 #pragma unroll
-    for (int n = 0; n < NT; ++n) { bh[SPLIT & 1][n] = sh[n * 32]; bl[SPLIT & 1][n] = sl[n * 32]; }
+    for (int n = 0; n < NT; ++n) { bh[SPLIT & 1][n] = sh[SPLIT * 2 * TP + n * 32]; bl[SPLIT & 1][n] = sl[SPLIT * 2 * TP + n * 32]; }
     static_for<SPLIT, KB>([&](auto rc) { body(rc, std::false_type{}); });
 }
 
@@ -561,6 +591,7 @@ struct EdgeMsgX3Args {
     const h8* vpH[3]; const h8* vpL[3];             // msg1..3 [W_down; W_frames] (11 x 32 -> 16 x 32), K permuted to the VV4 lane ownership
     const h8* vf1[3]; const h8* vf2[3];             // msg1..3 vector_up [32 x 8] as two M-tiles: A1 = [W_hi | 0], A2 = [W_lo' | W_hi]
     const h8* vf0H; const h8* vf0L;                 // msg0 vector_up [32 x H0] as two M-tiles, K = hidden channel
+    const void* wpool; uint32_t wpool_bytes;        // the whole weight pool (every packed array above lies inside): base of the buffer-load stream
 };
 
 #define GCDM_FLAG_F16_RANGE_BIT 8u
@@ -612,7 +643,9 @@ __global__ __launch_bounds__(ET * 8) __attribute__((amdgpu_waves_per_eu(2, 2))) 
     constexpr int PD = GCDM_X3_PD;
     const int mt0 = MT * wave;   // first M-tile (32 output channels each) of this wave
     X3Ring<MT, PD> ring;
-    x3_prefetch<MT, PD>(ring, ax.w0H + (size_t)mt0 * KB0C * 64, ax.w0L + (size_t)mt0 * KB0C * 64, KB0C, lane);   // flies during P1
+    const WPool wp = make_wpool(ax.wpool, ax.wpool_bytes, lane);
+    const uint32_t o0H = wp.off(ax.w0H + (size_t)mt0 * KB0C * 64), o0L = wp.off(ax.w0L + (size_t)mt0 * KB0C * 64);
+    x3_prefetch_b<MT, PD>(ring, wp, o0H, o0L, KB0C);   // flies during P1
     // per-edge constants of this thread's edge (streamed from HBM, independent of the edge list): requested first
     constexpr int EPN = (SE / 4) / PARTS;                // e' float4 groups per thread (QM9 2, GEOM: parts 0..3 one each)
     float fr[9];
@@ -779,8 +812,8 @@ __global__ __launch_bounds__(ET * 8) __attribute__((amdgpu_waves_per_eu(2, 2))) 
 #pragma unroll
                     for (int t = 0; t < 4; ++t) am[m][n][4 * q + t] = pqi[m][n][q][t] + pqj[m][n][q][t];
         STAMP(3);
-        tile_gemm_x3z<MT, NT, PD, KB0C, false, true>(am, al2, ring, ax.w0H + (size_t)mt0 * KB0C * 64, ax.w0L + (size_t)mt0 * KB0C * 64, xh8, xl8, ETP, lane);
-        x3_prefetch<MT, PD>(ring, ax.wH[0] + (size_t)mt0 * 18 * 64, ax.wL[0] + (size_t)mt0 * 18 * 64, 18, lane);
+        tile_gemm_x3z<MT, NT, PD, KB0C, false, true>(am, al2, ring, wp, o0H, o0L, xh8, xl8, ETP, lane);
+        x3_prefetch_b<MT, PD>(ring, wp, wp.off(ax.wH[0] + (size_t)mt0 * 18 * 64), wp.off(ax.wL[0] + (size_t)mt0 * 18 * 64), 18);
         STAMP(4);
 #pragma unroll
         for (int m = 0; m < MT; ++m)
@@ -811,8 +844,7 @@ __global__ __launch_bounds__(ET * 8) __attribute__((amdgpu_waves_per_eu(2, 2))) 
     static_for<0, 3>([&](auto kc) {
         constexpr int k = decltype(kc)::value;
         const GcpW& w = a.mk[k];
-        const h8* gwH = ax.wH[k] + (size_t)mt0 * 18 * 64;
-        const h8* gwL = ax.wL[k] + (size_t)mt0 * 18 * 64;
+        const uint32_t gwH = wp.off(ax.wH[k] + (size_t)mt0 * 18 * 64), gwL = wp.off(ax.wL[k] + (size_t)mt0 * 18 * 64);
         if (k == 0) STAMP(10);
         if (vhalf == (k & 1)) {
             VecStage<ET, H0, k == 0> vs;
@@ -820,12 +852,12 @@ __global__ __launch_bounds__(ET * 8) __attribute__((amdgpu_waves_per_eu(2, 2))) 
             vs.fA = k == 0 ? ax.vf0H : ax.vf1[k == 0 ? 0 : k - 1]; vs.fB = k == 0 ? ax.vf0L : ax.vf2[k == 0 ? 0 : k - 1];
             vs.pH = ax.vpH[k]; vs.pL = ax.vpL[k];
             vs.ve = ve; vs.vq = vq; vs.lane = lane;
-            tile_gemm_x3s<MT, NT, PD, 18, 16, true>(am, al2, ring, gwH, gwL, xh8, xl8, ETP, lane, [&](auto rc) { vs.template run<decltype(rc)::value>(); });
+            tile_gemm_x3s<MT, NT, PD, 18, 16, true>(am, al2, ring, wp, gwH, gwL, xh8, xl8, ETP, lane, [&](auto rc) { vs.template run<decltype(rc)::value>(); });
             amax = fmaxf(amax, vs.amax);
         } else {
-            tile_gemm_x3s<MT, NT, PD, 18, 16, false>(am, al2, ring, gwH, gwL, xh8, xl8, ETP, lane, [](auto) {});
+            tile_gemm_x3s<MT, NT, PD, 18, 16, false>(am, al2, ring, wp, gwH, gwL, xh8, xl8, ETP, lane, [](auto) {});
         }
-        if (k < 2) x3_prefetch<MT, PD>(ring, ax.wH[k < 2 ? k + 1 : 2] + (size_t)mt0 * 18 * 64, ax.wL[k < 2 ? k + 1 : 2] + (size_t)mt0 * 18 * 64, 18, lane);
+        if (k < 2) x3_prefetch_b<MT, PD>(ring, wp, wp.off(ax.wH[k < 2 ? k + 1 : 2] + (size_t)mt0 * 18 * 64), wp.off(ax.wL[k < 2 ? k + 1 : 2] + (size_t)mt0 * 18 * 64), 18);
         if (k == 0) STAMP(12);
 #pragma unroll
         for (int m = 0; m < MT; ++m)
