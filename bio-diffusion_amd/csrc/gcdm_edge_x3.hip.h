@@ -28,6 +28,18 @@ typedef _Float16 h4 __attribute__((ext_vector_type(4)));
 #define X3_PRE (1.0f / 2048.0f)          // every image holds x * 2^-11, the packed weights carry the 2^11 (gcdm_api.hip: split_f16); with
                                          // PRE = 1 / SCALE the lo' image is f16(x - hi * 2^11): one mixed FMA, no extra multiply
 #define X3_RANGE (6.0e4f * 2048.0f)      // bound on the un-scaled activation
+// Range guard.  An activation beyond the images' range becomes inf in its hi image, every product with it is inf / NaN, and -- all state
+// updates of the network being residual -- the non-finite value reaches the network output: the LAST node kernel raises
+// GCDM_FLAG_F16_RANGE when vel or a projected feature is not finite (the caller then re-runs in fp32 mode, which also decides whether a
+// NaN was the model's own).  Per-element |x| tracking in every split cost ~10 % of the edge kernel's VALU instructions; compile with
+// -DGCDM_X3_TRACK_RANGE to get it back (debugging).
+#ifdef GCDM_X3_TRACK_RANGE
+#define X3_TRACK(amax, x0, x1) (amax) = fmaxf((amax), fmaxf(fabsf(x0), fabsf(x1)))
+#define X3_OVER(expr) (expr)
+#else
+#define X3_TRACK(amax, x0, x1) ((void)0)
+#define X3_OVER(expr) false
+#endif
 
 __device__ __forceinline__ void split16(float x, _Float16& hi, _Float16& lo) {
     hi = (_Float16)(x * X3_PRE);
@@ -297,7 +309,7 @@ __device__ __forceinline__ void store_state_x3(char* XH, char* XL, int gbase8, c
 #pragma unroll
                 for (int t = 0; t < 4; t += 2) {
                     const float x0 = st[m][n][4 * q + t], x1 = st[m][n][4 * q + t + 1];
-                    amax = fmaxf(amax, fmaxf(fabsf(x0), fabsf(x1)));
+                    X3_TRACK(amax, x0, x1);
                     h2 hi, lo;
                     split16x2(x0, x1, hi, lo);
                     vh[t] = hi[0]; vh[t + 1] = hi[1];
@@ -322,7 +334,7 @@ __device__ __forceinline__ bool put16(char* XH, char* XL, int TP, int g8, int sl
     const int off = (g8 * TP + e) * 16 + 2 * slot;
     *(_Float16*)(XH + off) = hi;
     *(_Float16*)(XL + off) = lo;
-    return fabsf(x) > X3_RANGE;
+    return X3_OVER(fabsf(x) > X3_RANGE);
 }
 
 // ---- the vector path of the message GCP2s on the matrix pipe ----------------------------------------------------------------
@@ -356,7 +368,7 @@ __device__ __forceinline__ void split4(const float (&x)[4], h4& hi, h4& lo, floa
         split16x2(x[s], x[s + 1], a, b);
         hi[s] = a[0]; hi[s + 1] = a[1];
         lo[s] = b[0]; lo[s + 1] = b[1];
-        amax = fmaxf(amax, fmaxf(fabsf(x[s]), fabsf(x[s + 1])));
+        X3_TRACK(amax, x[s], x[s + 1]);
     }
 }
 
@@ -712,7 +724,7 @@ __global__ __launch_bounds__(ET * 8) __attribute__((amdgpu_waves_per_eu(2, 2))) 
                 split16x2(v[t], v[t + 1], hi, lo);
                 vh[t] = hi[0]; vh[t + 1] = hi[1];
                 vl[t] = lo[0]; vl[t + 1] = lo[1];
-                over |= fmaxf(fabsf(v[t]), fabsf(v[t + 1])) > X3_RANGE;
+                over |= X3_OVER(fmaxf(fabsf(v[t]), fabsf(v[t + 1])) > X3_RANGE);
             }
             const int off = ((g >> 1) * ETP + e) * 16 + 8 * (g & 1);
             *(h4*)(XH + off) = vh;

@@ -239,7 +239,7 @@ __global__ __launch_bounds__(NX_THREADS) void k_node_x3(NodeX3Args ax) {
                 split16x2(v[t], v[t + 1], hi, lo);
                 vh[t] = hi[0]; vh[t + 1] = hi[1];
                 vl[t] = lo[0]; vl[t + 1] = lo[1];
-                over |= fmaxf(fabsf(v[t]), fabsf(v[t + 1])) > X3_RANGE;
+                over |= X3_OVER(fmaxf(fabsf(v[t]), fabsf(v[t + 1])) > X3_RANGE);
             }
             const int off = ((g >> 1) * NTP + e) * 16 + 8 * (g & 1);
             *(h4*)(XH + off) = vh;
@@ -406,7 +406,11 @@ __global__ __launch_bounds__(NX_THREADS) void k_node_x3(NodeX3Args ax) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int c = (r & 3) + 8 * (r >> 2) + 4 * half;
-                    if (c < a.F) dst[c] = am[0][0][r] + al[0][0][r] * X3_INV_SCALE;
+                    if (c < a.F) {
+                        const float hv = am[0][0][r] + al[0][0][r] * X3_INV_SCALE;
+                        dst[c] = hv;
+                        over |= !(fabsf(hv) <= 3.0e38f);          // range guard: a non-finite network output (see X3_RANGE)
+                    }
                 }
             }
         }
@@ -414,6 +418,7 @@ __global__ __launch_bounds__(NX_THREADS) void k_node_x3(NodeX3Args ax) {
             const float v = XP[part * NTP + e] - a.X0[(size_t)part * N + nid];
             a.VEL[(size_t)part * N + nid] = v;
             if (v != v) atomicOr(a.flags_dev, 1u);
+            over |= !(fabsf(v) <= 3.0e38f);
         }
     }
     over |= amax > X3_RANGE;
