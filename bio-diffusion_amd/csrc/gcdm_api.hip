@@ -764,6 +764,7 @@ int gcdm_plan_batch(gcdm_handle* h, int32_t B, const int32_t* nn) {
                  oX0SC = take(h->sc ? 3 * n : 0), oBL = take(h->sc ? (size_t)h->Ve * e : 0), oUSC = take(h->sc ? 3 * e : 0),
                  oZK = take((size_t)h->D * n), oZU = take((size_t)h->D * n);
     h->ws_floats = off;
+    if (off * sizeof(float) >= ((size_t)1 << 32)) return fail(h, "gcdm_plan_batch: workspace exceeds 4 GB (buffer-addressed); split the batch");
     HIP_OK(h, hipMalloc(&h->ws, off * sizeof(float)));
     HIP_OK(h, hipMemset(h->ws, 0, off * sizeof(float)));
     float* w = h->ws;
@@ -896,6 +897,7 @@ int gcdm_forward_sc(gcdm_handle* h, const float* xh, const float* xh_sc, const f
             for (int k = 0; k < 3; ++k) { xa.vpH[k] = d.vpH[k]; xa.vpL[k] = d.vpL[k]; xa.vf1[k] = d.vf1[k]; xa.vf2[k] = d.vf2[k]; }
             xa.vf0H = d.vf0H; xa.vf0L = d.vf0L;
             xa.wpool = h->wpool; xa.wpool_bytes = (uint32_t)h->wpool_bytes;
+            xa.wspool = h->ws; xa.wspool_bytes = (uint32_t)(h->ws_floats * sizeof(float));
             xa.flags_dev = h->d_flags;
             if (d.KB != 18 || d.KB0 != (h->Se == 64 ? 7 : 4)) return fail(h, "internal: k-block counts differ from the kernel's compile-time constants");
             if (ET == 64) {

@@ -100,6 +100,25 @@ __device__ __forceinline__ WPool make_wpool(const void* pool, uint32_t bytes, in
     return w;
 }
 
+// the same for the per-edge / per-node fp32 arrays of the workspace pool: per-lane byte offset (an edge or node index, computed once) in
+// the VGPR, array base + row * stride as the scalar offset
+struct BufView {
+    __amdgpu_buffer_rsrc_t rsrc;
+    const char* base;
+    __device__ __forceinline__ uint32_t off(const void* p) const { return (uint32_t)((const char*)p - base); }
+    __device__ __forceinline__ float ld1(uint32_t voff, uint32_t soff) const { return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, voff, soff, 0)); }
+    __device__ __forceinline__ v4f ld4(uint32_t voff, uint32_t soff) const {
+        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, soff, 0);
+        return __builtin_bit_cast(v4f, v);
+    }
+};
+__device__ __forceinline__ BufView make_view(const void* pool, uint32_t bytes) {
+    BufView b;
+    b.rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(pool), 0, bytes, 0x00020000);
+    b.base = (const char*)pool;
+    return b;
+}
+
 template <int MT, int PD>
 __device__ __forceinline__ void x3_prefetch_b(X3Ring<MT, PD>& ring, const WPool& wp, uint32_t oH, uint32_t oL, int KB) {
     const uint32_t wstride = KB * 64 * 16;
@@ -604,6 +623,7 @@ struct EdgeMsgX3Args {
     const h8* vf1[3]; const h8* vf2[3];             // msg1..3 vector_up [32 x 8] as two M-tiles: A1 = [W_hi | 0], A2 = [W_lo' | W_hi]
     const h8* vf0H; const h8* vf0L;                 // msg0 vector_up [32 x H0] as two M-tiles, K = hidden channel
     const void* wpool; uint32_t wpool_bytes;        // the whole weight pool (every packed array above lies inside): base of the buffer-load stream
+    const void* wspool; uint32_t wspool_bytes;      // the workspace pool (EP4, AL, U, FR, PQ4, VDI, VDJ lie inside)
 };
 
 #define GCDM_FLAG_F16_RANGE_BIT 8u
@@ -658,33 +678,50 @@ __global__ __launch_bounds__(ET * 8) __attribute__((amdgpu_waves_per_eu(2, 2))) 
     const WPool wp = make_wpool(ax.wpool, ax.wpool_bytes, lane);
     const uint32_t o0H = wp.off(ax.w0H + (size_t)mt0 * KB0C * 64), o0L = wp.off(ax.w0L + (size_t)mt0 * KB0C * 64);
     x3_prefetch_b<MT, PD>(ring, wp, o0H, o0L, KB0C);   // flies during P1
-    // per-edge constants of this thread's edge (streamed from HBM, independent of the edge list): requested first
+    // per-edge constants of this thread's edge (streamed from HBM, independent of the edge list): requested first.  Buffer loads: the
+    // per-lane offset is the edge (node) index, array base and row stride are scalars -- no 64-bit VALU address arithmetic per load
+    const BufView ws = make_view(ax.wspool, ax.wspool_bytes);
+    const BufView wv = make_view(ax.wpool, ax.wpool_bytes);
     constexpr int EPN = (SE / 4) / PARTS;                // e' float4 groups per thread (QM9 2, GEOM: parts 0..3 one each)
+    const uint32_t ve4 = (uint32_t)eid * 4u, ve16 = (uint32_t)eid * 16u, rowE = (uint32_t)E * 4u, rowN = (uint32_t)N * 4u;
     float fr[9];
+    {
+        const uint32_t o = ws.off(a.FR);
 #pragma unroll
-    for (int r = 0; r < 9; ++r) fr[r] = a.FR[(size_t)r * E + eid];
+        for (int r = 0; r < 9; ++r) fr[r] = ws.ld1(ve4, o + r * rowE);
+    }
     v4f epv[EPN > 0 ? EPN : 1];
+    {
+        const uint32_t o = ws.off(a.EP4);
 #pragma unroll
-    for (int i = 0; i < (EPN > 0 ? EPN : 1); ++i) epv[i] = a.EP4[(size_t)min(part + PARTS * i, SE / 4 - 1) * E + eid];
+        for (int i = 0; i < (EPN > 0 ? EPN : 1); ++i)
+            epv[i] = ws.ld4(ve16 + (uint32_t)min(part + PARTS * i, SE / 4 - 1) * (rowE * 4u), o);          // the group index depends on the lane's part
+    }
     float al[VE];
+    {
+        const uint32_t o = ws.off(a.AL);
 #pragma unroll
-    for (int c = 0; c < VE; ++c) al[c] = a.AL[(size_t)c * E + eid];
-    const float u0 = a.U[eid], u1 = a.U[(size_t)E + eid], u2 = a.U[2 * (size_t)E + eid];
+        for (int c = 0; c < VE; ++c) al[c] = ws.ld1(ve4, o + c * rowE);
+    }
+    const uint32_t oU = ws.off(a.U);
+    const float u0 = ws.ld1(ve4, oU), u1 = ws.ld1(ve4, oU + rowE), u2 = ws.ld1(ve4, oU + 2 * rowE);
     // node-level halves of msg0 (PQ4 rows of this lane's GEMM-layout edges): requested now, consumed after P1
     v4f pqi[MT][NT][4], pqj[MT][NT][4];
     {
         const int half_ = lane >> 5, l31_ = lane & 31;
+        const uint32_t oP = ws.off(a.PQ4), rowP = (uint32_t)N * 16u;
 #pragma unroll
         for (int n = 0; n < NT; ++n) {
             const int eg = min(e0 + 32 * n + l31_, E - 1);
             const int ri = a.EROW[eg], cj = a.ECOL[eg];
+            const uint32_t vi = ((uint32_t)half_ * N + ri) * 16u, vj = ((uint32_t)half_ * N + cj) * 16u;     // group 2q + half: the half rides in the lane offset
 #pragma unroll
             for (int m = 0; m < MT; ++m)
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    const int g = 8 * (mt0 + m) + 2 * q + half_;
-                    pqi[m][n][q] = a.PQ4[(size_t)g * N + ri];
-                    pqj[m][n][q] = a.PQ4[(size_t)(64 + g) * N + cj];
+                    const int g = 8 * (mt0 + m) + 2 * q;
+                    pqi[m][n][q] = ws.ld4(vi, oP + (uint32_t)g * rowP);
+                    pqj[m][n][q] = ws.ld4(vj, oP + (uint32_t)(64 + g) * rowP);
                 }
         }
     }
@@ -732,19 +769,20 @@ __global__ __launch_bounds__(ET * 8) __attribute__((amdgpu_waves_per_eu(2, 2))) 
         }
         constexpr int ROWS0 = H0 + 3, NH0 = (ROWS0 + PARTS - 1) / PARTS;
         float gi[NH0][3], gj[NH0][3], beta[NH0], beta2[NH0];
+        const uint32_t oI = ws.off(a.VDI), oJ = ws.off(a.VDJ), oW = wv.off(a.wddE);
 #pragma unroll
         for (int i = 0; i < NH0; ++i) {
             const int hh = min(part + PARTS * i, ROWS0 - 1);
-            const size_t r0 = (size_t)(hh * 3) * N;
+            const uint32_t vI = ((uint32_t)(hh * 3) * N + ni) * 4u, vJ = ((uint32_t)(hh * 3) * N + nj) * 4u;   // the row depends on the lane's part
 #pragma unroll
             for (int x = 0; x < 3; ++x) {
-                gi[i][x] = a.VDI[r0 + (size_t)x * N + ni];
-                gj[i][x] = a.VDJ[r0 + (size_t)x * N + nj];
+                gi[i][x] = ws.ld1(vI, oI + x * rowN);
+                gj[i][x] = ws.ld1(vJ, oJ + x * rowN);
             }
-            const float* w = a.wddE + hh * VE;
+            const uint32_t vW = (uint32_t)(hh * VE) * 4u;
             float bsum = 0.f;
 #pragma unroll
-            for (int c = 0; c < VE; ++c) bsum += w[c] * al[c];
+            for (int c = 0; c < VE; ++c) bsum += wv.ld1(vW, oW + c * 4) * al[c];
             beta[i] = bsum;
             beta2[i] = 0.f;
         }
