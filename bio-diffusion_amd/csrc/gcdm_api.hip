@@ -33,6 +33,7 @@ struct LayerDev {
     const h8 *w0H, *w0L, *wg0H, *wg0L, *wH[3], *wL[3], *wgH[3], *wgL[3];
     const h8 *vpH[3], *vpL[3], *vf1[3], *vf2[3], *vf0H, *vf0L;   // vector path on the matrix pipe (gcdm_edge_x3.hip.h)
     const h8 *vdH, *vdL;
+    const float *bpqx, *wax;       // scaled units of the split-precision edge kernel: c * bias of the msg0 node halves, attention weights / c
     int KB0, KB;
     GcpX3 ffx, posx;
     const h8 *wpqH, *wpqL;
@@ -199,6 +200,11 @@ struct WView {
     int rows, cols;
     float at(int r, int c) const { return (*v)[(size_t)r * cols + c]; }
 };
+
+// Scaled units of the split-precision edge kernel (gcdm_edge_x3.hip.h): the message scalars live as c * m.s with c = -log2(e), so that
+// SiLU(x) * c = x' / (1 + exp2(x')) for x' = c * x -- one multiply less per element.  Host side: scalar_out weights acting on true-unit
+// inputs (and biases) carry c, weights acting on the scaled message scalars whose output is in true units carry 1 / c.
+// (the constant itself: X3_C in gcdm_edge_x3.hip.h)
 
 // ---- A operands of the vector path (v_mfma_f32_16x16x32_f16: lane l holds row l & 15, k = 8 (l >> 4) + j), see gcdm_edge_x3.hip.h ----
 std::vector<float> f16_words(const std::vector<uint16_t>& v) {
@@ -407,7 +413,7 @@ GcpX3 resolve_x3(const GcpOff& o, const float* base) {
 }
 
 struct LayerOff {
-    size_t w0, wddE, wg0, bg0, wup0, wa, wpq, bpq, wddI, wddJ;
+    size_t w0, wddE, wg0, bg0, wup0, wa, wpq, bpq, wddI, wddJ, bpqx, wax;
     int G0;
     float ba;
     GcpOff mk[3], ff, pos;
@@ -567,10 +573,15 @@ int gcdm_finalize_weights(gcdm_handle* h) {
                 }
             o.wpq = pool.add(pack_mfma(PQ));
             o.bpq = pool.add(padded(bs, 2 * S));
-            {
+            {   // split-precision path: the node kernel writes c * (P | Q) (scaled units of the edge kernel)
+                Dense PQc(2 * S, S);
+                for (size_t i = 0; i < PQc.a.size(); ++i) PQc.a[i] = PQ.a[i] * X3_C;
                 std::vector<float> xh, xl;
-                pack_x3(PQ, xh, xl);
+                pack_x3(PQc, xh, xl);
                 o.wpqH = pool.add(xh); o.wpqL = pool.add(xl);
+                std::vector<float> bc = padded(bs, 2 * S);
+                for (auto& v : bc) v *= X3_C;
+                o.bpqx = pool.add(bc);
             }
             std::vector<float> dI((size_t)(H0 + 3) * V), dJ((size_t)(H0 + 3) * V), dE((size_t)(H0 + 3) * Ve);
             for (int r = 0; r < H0 + 3; ++r) {
@@ -602,10 +613,15 @@ int gcdm_finalize_weights(gcdm_handle* h) {
                 for (int k = 0; k < H0; ++k) W0x.at(m, 8 * N8 + k) = ws.at(m, 2 * S + Se + k);
                 for (int k = 0; k < 9; ++k) W0x.at(m, 8 * Q8 + k) = ws.at(m, 2 * S + Se + H0 + k);
             }
+            for (auto& v : W0x.a) v *= X3_C;                    // true-unit inputs -> scaled pre-activation
             std::vector<float> xh, xl;
             pack_x3(W0x, xh, xl);
             o.w0H = pool.add(xh); o.w0L = pool.add(xl); o.KB0 = Kx / 16;
-            pack_gate_x3(Wg, xh, xl);
+            {
+                Dense Wgc(32, S);
+                for (size_t i = 0; i < Wgc.a.size(); ++i) Wgc.a[i] = Wg.a[i] / X3_C;   // acts on the scaled SiLU output
+                pack_gate_x3(Wgc, xh, xl);
+            }
             o.wg0H = pool.add(xh); o.wg0L = pool.add(xl);
             pack_vec_fin0(wu, H0, xh, xl);
             o.vf0H = pool.add(xh); o.vf0L = pool.add(xl);
@@ -624,17 +640,17 @@ int gcdm_finalize_weights(gcdm_handle* h) {
             for (int m = 0; m < S; ++m) {
                 for (int kk = 0; kk < S; ++kk) Wx.at(m, kk) = ws.at(m, kk);
                 for (int g = 0; g < 3; ++g)
-                    for (int t = 0; t < 3; ++t) {
-                        if (3 * g + t < 8) Wx.at(m, S + 8 * g + t) = ws.at(m, S + 3 * g + t);          // norms of the hidden vectors
-                        Wx.at(m, S + 8 * g + 3 + t) = ws.at(m, S + 8 + 3 * g + t);                     // frame scalars q[3g + t]
+                    for (int t = 0; t < 3; ++t) {          // true-unit inputs: weights carry c (the message scalars are already scaled)
+                        if (3 * g + t < 8) Wx.at(m, S + 8 * g + t) = X3_C * ws.at(m, S + 3 * g + t);          // norms of the hidden vectors
+                        Wx.at(m, S + 8 * g + 3 + t) = X3_C * ws.at(m, S + 8 + 3 * g + t);                     // frame scalars q[3g + t]
                     }
-                Wx.at(m, 287) = wb.at(0, m);
+                Wx.at(m, 287) = X3_C * wb.at(0, m);
             }
             std::vector<float> xh, xl;
             pack_x3(Wx, xh, xl);
             o.wH[k - 1] = pool.add(xh); o.wL[k - 1] = pool.add(xl); o.KB = 18;
             Dense Wgd(32, S);
-            for (int m = 0; m < V; ++m) for (int kk = 0; kk < S; ++kk) Wgd.at(m, kk) = wg.at(m, kk);
+            for (int m = 0; m < V; ++m) for (int kk = 0; kk < S; ++kk) Wgd.at(m, kk) = wg.at(m, kk) / X3_C;
             pack_gate_x3(Wgd, xh, xl);
             o.wgH[k - 1] = pool.add(xh); o.wgL[k - 1] = pool.add(xl);
             {   // vector path on the matrix pipe: vector_down / vector_down_frames and vector_up as 16x16x32 A operands
@@ -656,6 +672,9 @@ int gcdm_finalize_weights(gcdm_handle* h) {
                 return -1;
             o.wa = pool.add(*wa.v);
             o.ba = ba.at(0, 0);
+            std::vector<float> wac(*wa.v);
+            for (auto& v : wac) v /= X3_C;
+            o.wax = pool.add(wac);
         }
         if (!build_gcp(h, pool, lp + "feedforward_network.0.", 2 * S, 2 * V, S, V, 4, true, o.ff)) return -1;
         if (!build_gcp(h, pool, lp + "node_position_update_gcp.", S, V, S, 1, 4, false, o.pos)) return -1;
@@ -691,6 +710,7 @@ int gcdm_finalize_weights(gcdm_handle* h) {
         d.wg0H = (const h8*)(base + o.wg0H); d.wg0L = (const h8*)(base + o.wg0L);
         d.vf0H = (const h8*)(base + o.vf0H); d.vf0L = (const h8*)(base + o.vf0L);
         d.vdH = (const h8*)(base + o.vdH); d.vdL = (const h8*)(base + o.vdL);
+        d.bpqx = base + o.bpqx; d.wax = base + o.wax;
         for (int k = 0; k < 3; ++k) {
             d.wH[k] = (const h8*)(base + o.wH[k]); d.wL[k] = (const h8*)(base + o.wL[k]);
             d.wgH[k] = (const h8*)(base + o.wgH[k]); d.wgL[k] = (const h8*)(base + o.wgL[k]);
@@ -862,7 +882,7 @@ int gcdm_forward_sc(gcdm_handle* h, const float* xh, const float* xh_sc, const f
                 node_kb_ok = false;
                 return;
             }
-            if (next_layer < h->L) { nx.wpqH = h->layers[next_layer].wpqH; nx.wpqL = h->layers[next_layer].wpqL; nx.vdH = h->layers[next_layer].vdH; nx.vdL = h->layers[next_layer].vdL; }
+            if (next_layer < h->L) { nx.wpqH = h->layers[next_layer].wpqH; nx.wpqL = h->layers[next_layer].wpqL; nx.vdH = h->layers[next_layer].vdH; nx.vdL = h->layers[next_layer].vdL; nx.bpqx = h->layers[next_layer].bpqx; }
             if (embed && h->sc) hipLaunchKernelGGL((k_node_x3<true, 4>), dim3(ngrid), dim3(NX_THREADS), NK_LDS_BYTES, st, nx);
             else if (embed) hipLaunchKernelGGL(k_node_x3<true>, dim3(ngrid), dim3(NX_THREADS), NK_LDS_BYTES, st, nx);
             else hipLaunchKernelGGL(k_node_x3<false>, dim3(ngrid), dim3(NX_THREADS), NK_LDS_BYTES, st, nx);
@@ -896,6 +916,7 @@ int gcdm_forward_sc(gcdm_handle* h, const float* xh, const float* xh_sc, const f
             for (int k = 0; k < 3; ++k) { xa.wH[k] = d.wH[k]; xa.wL[k] = d.wL[k]; xa.wgH[k] = d.wgH[k]; xa.wgL[k] = d.wgL[k]; }
             for (int k = 0; k < 3; ++k) { xa.vpH[k] = d.vpH[k]; xa.vpL[k] = d.vpL[k]; xa.vf1[k] = d.vf1[k]; xa.vf2[k] = d.vf2[k]; }
             xa.vf0H = d.vf0H; xa.vf0L = d.vf0L;
+            xa.wax = d.wax;
             xa.wpool = h->wpool; xa.wpool_bytes = (uint32_t)h->wpool_bytes;
             xa.wspool = h->ws; xa.wspool_bytes = (uint32_t)(h->ws_floats * sizeof(float));
             xa.flags_dev = h->d_flags;

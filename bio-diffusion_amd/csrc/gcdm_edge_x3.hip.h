@@ -16,6 +16,11 @@
 #include "gcdm_kernels.hip.h"
 #include <type_traits>
 
+// SiLU in the scaled units of this kernel: the message scalars are kept as c * m.s with c = -log2(e) (the host folds c into the weights, gcdm_api.hip
+// X3_C), so for x' = c * x:  c * SiLU(x) = x' / (1 + exp2(x'))  -- exp2, add, rcp, mul: one multiply less than x * sigmoid(x)
+#define X3_C (-1.4426950408889634f)
+__device__ __forceinline__ float silu_scaled(float xs) { return xs * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(xs)); }
+
 // v_sqrt_f32 (1 ulp) instead of the ~20-instruction correctly rounded expansion: the argument is >= 1e-8, never denormal
 __device__ __forceinline__ float fast_sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
 
@@ -622,6 +627,7 @@ struct EdgeMsgX3Args {
     const h8* vpH[3]; const h8* vpL[3];             // msg1..3 [W_down; W_frames] (11 x 32 -> 16 x 32), K permuted to the VV4 lane ownership
     const h8* vf1[3]; const h8* vf2[3];             // msg1..3 vector_up [32 x 8] as two M-tiles: A1 = [W_hi | 0], A2 = [W_lo' | W_hi]
     const h8* vf0H; const h8* vf0L;                 // msg0 vector_up [32 x H0] as two M-tiles, K = hidden channel
+    const float* wax;                               // scalar_message_attention weights / c
     const void* wpool; uint32_t wpool_bytes;        // the whole weight pool (every packed array above lies inside): base of the buffer-load stream
     const void* wspool; uint32_t wspool_bytes;      // the workspace pool (EP4, AL, U, FR, PQ4, VDI, VDJ lie inside)
 };
@@ -870,7 +876,7 @@ __global__ __launch_bounds__(ET * 8) __attribute__((amdgpu_waves_per_eu(2, 2))) 
 #pragma unroll
             for (int n = 0; n < NT; ++n)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) st[m][n][r] = fast_silu(am[m][n][r] + al2[m][n][r] * X3_INV_SCALE);
+                for (int r = 0; r < 16; ++r) st[m][n][r] = silu_scaled(am[m][n][r] + al2[m][n][r] * X3_INV_SCALE);
         STAMP(5);
         gate_partial_x3<MT, NT, true>(gm, gl, st, ax.wg0H, ax.wg0L, mt0, lane);
         if (NW == 4) {               // four partials = the four slots the vector waves sum: no fold needed
@@ -914,7 +920,7 @@ __global__ __launch_bounds__(ET * 8) __attribute__((amdgpu_waves_per_eu(2, 2))) 
 #pragma unroll
             for (int n = 0; n < NT; ++n)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) am[m][n][r] = fast_silu(am[m][n][r] + al2[m][n][r] * X3_INV_SCALE);
+                for (int r = 0; r < 16; ++r) am[m][n][r] = silu_scaled(am[m][n][r] + al2[m][n][r] * X3_INV_SCALE);
         if (k == 0) STAMP(13);
         gate_partial_x3<MT, NT, true>(gm, gl, am, ax.wgH[k], ax.wgL[k], mt0, lane);
         if (NW == 4) {
@@ -958,7 +964,7 @@ __global__ __launch_bounds__(ET * 8) __attribute__((amdgpu_waves_per_eu(2, 2))) 
         float s = 0.f;
         constexpr int GPP = GCDM_SG / PARTS;
         for (int g = part * GPP; g < part * GPP + GPP; ++g) {
-            const v4f wv = *(const v4f*)(a.wa + 4 * g);
+            const v4f wv = *(const v4f*)(ax.wax + 4 * g);          // attention weights / c: the image holds c * m.s
             const v4f x = XS4[g * ETP + e];
             s += wv[0] * x[0] + wv[1] * x[1] + wv[2] * x[2] + wv[3] * x[3];
         }
@@ -985,7 +991,7 @@ __global__ __launch_bounds__(ET * 8) __attribute__((amdgpu_waves_per_eu(2, 2))) 
             if (un < GCDM_SG) {
                 v4f s = {0.f, 0.f, 0.f, 0.f};
                 for (int x = sb; x < en; ++x) s += XS4[un * ETP + x] * m_att[x];
-                *(v4f*)(dst + 4 * un) = s;
+                *(v4f*)(dst + 4 * un) = s * (1.0f / X3_C);           // back to true units
             } else {
                 const int r = un - GCDM_SG, c = r / 3, comp = r - 3 * c;      // AGG column S + 3c + comp (reference flatten layout)
                 const float* vp = (const float*)(VV4 + (comp * 8 + (c >> 2)) * ETP) + (c & 3);

@@ -19,6 +19,7 @@ struct NodeX3Args {
     NodeArgs base;
     GcpX3 emb, ff, pos, proj;
     const h8 *wpqH, *wpqL;         // next layer's msg0 node halves, packed [16][16][64]
+    const float* bpqx;             // c * bias of the next layer's msg0 node halves (scaled units of the edge kernel, X3_C)
     const h8 *vdH, *vdL;           // next layer's msg0 vector halves [wddI; wddJ] (2 x (H0+3) rows x 32) as 16x16x32 A operands, [3][1][64]
 };
 
@@ -365,7 +366,7 @@ __global__ __launch_bounds__(NX_THREADS) void k_node_x3(NodeX3Args ax) {
 #pragma unroll
         for (int m = 0; m < 2; ++m) {
             const int mt = wave + 8 * m;
-            acc_init_bias<1, 1>(am, a.bpq, mt, lane);
+            acc_init_bias<1, 1>(am, ax.bpqx, mt, lane);
 #pragma unroll
             for (int r = 0; r < 16; ++r) al[0][0][r] = 0.f;
             const h8* wh = ax.wpqH + (size_t)mt * 16 * 64;
