@@ -292,6 +292,22 @@ def test_ragged_geom_is_bit_reproducible(mode, tile):
     assert lib.gcdm_set_option(h, b"edge_tile", 0) == 0
 
 
+@pytest.mark.parametrize("tile", [32, 64])
+def test_repeat_launch_bit_identity_full_batch(tile):
+    """Run-to-run bit reproducibility of the split-precision kernels with co-resident workgroups (32-edge tiles: two per CU) over many
+    launches of the benchmark batch: a regression of the packed-fp32 code-generation hazard (the library is built with
+    -target-feature -packed-fp32-ops) or any hidden LDS / VMEM race shows up as a differing hash."""
+    d = _dims("qm9")
+    net, W, _ = _net("qm9", seed=51, scale=0.5, mode=1)
+    lib, h = net._lib, net._handle
+    assert lib.gcdm_set_option(h, b"edge_tile", tile) == 0
+    xh, t, bi, nn_, _ = synth.make_inputs([19] * 1024, synth.dims_feat(d), seed=77, t_value=0.41)
+    first = _fwd(net, xh, t, bi)
+    for _ in range(12):
+        assert torch.equal(_fwd(net, xh, t, bi), first)
+    assert lib.gcdm_set_option(h, b"edge_tile", 0) == 0
+
+
 def test_f16_range_flag_and_fp32_fallback():
     """Activations beyond the f16 range: the split-precision kernel raises GCDM_FLAG_F16_RANGE and the module-level call
     transparently recomputes with fp32 MFMA (bit-identical to fp32 mode)."""
