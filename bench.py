@@ -142,7 +142,7 @@ def load_pmc_summary(workload, x3):
     return {}
 
 
-def quick_config(pkg, name, dev, rank, lanes=2, steps=24, warmup=10):
+def quick_config(pkg, name, dev, rank, lanes=2, steps=40, warmup=25):
     """ms/step of another BASELINE.json config on this GPU (same code path as the headline: the batch as `lanes` slices, Philox noise);
     a short run, reported as extra fields of the one JSON line (configs[2] = qm9cond, configs[3] = geom)."""
     import synth
