@@ -13,8 +13,13 @@ are gathered with one all_gather outside the timed region.
 
 Prints ONE JSON line (rank 0).  ``value`` = molecules/s of a full 1000-step sample = molecules / (1001 network
 evaluations x measured s/step) over all ranks.  ``roofline`` is for the dominant kernel (fused edge-message kernel,
-one launch per interaction layer) timed with HIP events inside the library on the launch stream.
-``cpu_baseline`` times the CPU oracle (torch, all host cores) on a bounded sample of the same workload.
+one launch per interaction layer) timed with HIP events inside the library on the launch stream; its ``traffic`` /
+``mfma_busy_frac_pmc`` come from the committed PMC summary of the same command (profiles/) and are nulled when the kernels
+have changed since (``pmc_stale``).  ``cpu_baseline`` times the CPU oracle (torch, 32 threads) on the BASELINE.json
+configs[0] shape (64 molecules x 19 atoms, >= 10 steps).  Extra fields at N=1: ``modes`` (both matrix modes -- the default
+f16x3 split precision and exact fp32 MFMA -- measured the same way, each with its roofline), ``other_configs``
+(configs[2] alpha-conditional QM9 and configs[3] GEOM-Drugs, short runs), ``plug_point_1`` (the reference's unchanged
+per-step method on top of GCPNetDynamics.forward).
 """
 from __future__ import annotations
 
@@ -332,6 +337,13 @@ def main():
         sliced = None
     else:
         sliced_flags, sliced_finite = 0, True
+    # BASELINE.json configs[2] / configs[3] as extra fields of the one JSON line: short runs right after the timed region (before the
+    # fp32-mode steps, whose power draw leaves the chip at a lower clock for a while)
+    other_configs = None
+    if args.workload == "qm9" and world == 1 and not args.no_other_configs and args.streams == 1:
+        log("other configs ...")
+        other_configs = {"configs[2] qm9cond": quick_config(pkg, "qm9cond", dev, rank), "configs[3] geom": quick_config(pkg, "geom", dev, rank)}
+
     # Both matrix modes on the same footing: whole batch on ONE handle, wall clock over 8 steps + the dominant kernel's launch time from
     # HIP events recorded by the library on the launch stream (separate un-timed steps).  f16x3 = the default (split-precision MFMA
     # operands, fp32-equivalent accuracy), f32 = exact fp32 MFMA (also what the automatic re-run costs if an activation leaves the f16 range).
@@ -465,9 +477,8 @@ def main():
                                        "the cost of the reference's unchanged sampling loop after the dynamics_networks registry swap"}
         res["roofline"]["pmc_stale"] = pmc.get("stale")
         res["roofline"]["pmc_collected_at_commit"] = pmc.get("collected_at_commit")
-        if args.workload == "qm9" and world == 1 and not args.no_other_configs and args.streams == 1:
-            log("other configs ...")
-            res["other_configs"] = {"configs[2] qm9cond": quick_config(pkg, "qm9cond", dev, rank), "configs[3] geom": quick_config(pkg, "geom", dev, rank)}
+        if other_configs is not None:
+            res["other_configs"] = other_configs
         if not args.no_cpu_baseline and world == 1:
             log("cpu baseline ...")
             res["cpu_baseline"] = cpu_baseline(wl["dataset"], wl["cond"], dims)
