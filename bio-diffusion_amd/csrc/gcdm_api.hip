@@ -1264,11 +1264,15 @@ int64_t gcdm_debug_read(gcdm_handle* h, const char* name, float* host_out, int64
 
 double gcdm_forward_flops_executed(const gcdm_handle* h) {
     if (!h || !h->N) return 0.0;
-    // MFMA + VALU multiply-adds actually issued per forward (x2), see DESIGN.md section 4
+    // multiply-adds actually issued per forward (x2; a split-precision product block counts once, padded MFMA rows / columns count), see DESIGN.md section 4
     const double N = h->N, E = (double)h->E, S = GCDM_S, V = GCDM_V, Se = h->Se, Ve = h->Ve, H0 = h->H0;
     const double G0 = h->layers.empty() ? 0 : h->layers[0].G0;
-    const double msg0 = 8.0 * G0 * S + 32.0 * S + (H0 + 3) * (Ve + 2) * 1.0 + 3.0 * V * H0;
-    const double msgk = 280.0 * S + 32.0 * S + 11.0 * 3 * V + 3.0 * V * 8;
+    const bool x3 = h->use_x3();
+    // fp32 kernels: extended-K GEMM + gate + VALU vector products; split-precision kernels: 16-deep k-blocks, vector path on 16x16x32 MFMA tiles
+    const double msg0 = x3 ? 16.0 * (h->layers.empty() ? 0 : h->layers[0].KB0) * S + 32.0 * S + (H0 + 3) * Ve + 3.0 * V * 32
+                           : 8.0 * G0 * S + 32.0 * S + (H0 + 3) * (Ve + 2) * 1.0 + 3.0 * V * H0;
+    const double msgk = x3 ? 288.0 * S + 32.0 * S + 16.0 * 32 * 3 + 32.0 * 32 * 3
+                           : 280.0 * S + 32.0 * S + 11.0 * 3 * V + 3.0 * V * 8;
     const double edge = msg0 + 3 * msgk + S;
     const double node = 544.0 * S + S * S + 32.0 * S + 19.0 * 3 * 2 * V + 3.0 * V * 16      // ff
                         + 280.0 * S + 32.0 * S + 11.0 * 3 * V + 3.0 * 8                       // pos
