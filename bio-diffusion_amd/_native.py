@@ -46,7 +46,7 @@ EXPORTS = [
     "gcdm_plan_batch", "gcdm_forward", "gcdm_sample_step", "gcdm_sample_final", "gcdm_sample_init", "gcdm_debug_read",
     "gcdm_debug_set_layer_limit", "gcdm_num_nodes", "gcdm_num_edges", "gcdm_forward_flops_executed",
     "gcdm_profile_enable", "gcdm_profile_edge_kernel_ms", "gcdm_set_option", "gcdm_get_option", "gcdm_check_stability", "gcdm_encode_samples", "gcdm_unnormalize_z", "gcdm_sample_step_to", "gcdm_forward_sc", "gcdm_sample_step_sc", "gcdm_sample_final_sc",
-    "gcdm_inpaint_center", "gcdm_inpaint_step", "gcdm_inpaint_jump", "gcdm_timestep_index", "gcdm_bond_orders",
+    "gcdm_inpaint_center", "gcdm_inpaint_step", "gcdm_inpaint_jump", "gcdm_timestep_index", "gcdm_bond_orders", "gcdm_plan_batch_masked",
 ]
 
 _lib: Optional[C.CDLL] = None
@@ -91,6 +91,7 @@ def load() -> C.CDLL:
     lib.gcdm_finalize_weights.argtypes = [H]
     lib.gcdm_set_gamma.argtypes = [H, C.c_void_p, C.c_int64]
     lib.gcdm_plan_batch.argtypes = [H, C.c_int32, C.c_void_p]
+    lib.gcdm_plan_batch_masked.argtypes = [H, C.c_int32, C.c_void_p, C.c_void_p]
     lib.gcdm_forward.argtypes = [H, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.gcdm_forward_sc.argtypes = [H, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.gcdm_sample_step.argtypes = [H, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]

@@ -63,6 +63,7 @@ struct gcdm_handle {
     int B = 0, N = 0, max_n = 0;
     int64_t E = 0;
     int *d_noff = nullptr, *d_erow = nullptr, *d_ecol = nullptr, *d_ncnt = nullptr, *d_rowstart = nullptr;
+    float* d_mask = nullptr;         // 1 / 0 per node when the plan has masked nodes (gcdm_plan_batch_masked), else null
     float* ws = nullptr;  // workspace pool
     size_t ws_floats = 0;
     float *X0 = nullptr, *XC = nullptr, *FBAR = nullptr, *CHI0 = nullptr, *HIN4 = nullptr, *H4 = nullptr, *CHI = nullptr, *PQ4 = nullptr,
@@ -429,6 +430,8 @@ void free_plan(gcdm_handle* h) {
     if (h->d_ecol) (void)hipFree(h->d_ecol);
     if (h->d_ncnt) (void)hipFree(h->d_ncnt);
     if (h->d_rowstart) (void)hipFree(h->d_rowstart);
+    if (h->d_mask) (void)hipFree(h->d_mask);
+    h->d_mask = nullptr;
     if (h->ws) (void)hipFree(h->ws);
     h->d_noff = h->d_erow = h->d_ecol = h->d_ncnt = h->d_rowstart = nullptr;
     h->ws = nullptr;
@@ -736,32 +739,54 @@ int gcdm_finalize_weights(gcdm_handle* h) {
     return 0;
 }
 
-int gcdm_plan_batch(gcdm_handle* h, int32_t B, const int32_t* nn) {
+int gcdm_plan_batch(gcdm_handle* h, int32_t B, const int32_t* nn) { return gcdm_plan_batch_masked(h, B, nn, nullptr); }
+
+int gcdm_plan_batch_masked(gcdm_handle* h, int32_t B, const int32_t* nn, const uint8_t* node_mask) {
     if (!h || B <= 0 || !nn) return fail(h, "gcdm_plan_batch: bad argument");
     DeviceGuard guard(h->cfg.device);
-    free_plan(h);
     std::vector<int> noff(B + 1, 0);
     int64_t E = 0;
     int max_n = 0;
+    bool masked = false;
     for (int b = 0; b < B; ++b) {
         if (nn[b] <= 0) return fail(h, "gcdm_plan_batch: every molecule needs >= 1 atom");
         noff[b + 1] = noff[b] + nn[b];
-        E += (int64_t)nn[b] * nn[b];
+        int64_t m = nn[b];
+        if (node_mask) {            // edges only between unmasked atoms of a molecule (get_fully_connected_edge_index, gcpnet.py:1062-1065)
+            m = 0;
+            for (int i = 0; i < nn[b]; ++i) m += node_mask[noff[b] + i] ? 1 : 0;
+            if (m == 0) return fail(h, "gcdm_plan_batch_masked: every molecule needs >= 1 unmasked atom (the reference's centroid is 0 / 0 otherwise)");
+            masked |= m != nn[b];
+        }
+        E += m * m;
         max_n = std::max(max_n, (int)nn[b]);
     }
+    if (!masked) node_mask = nullptr;
     if (E >= (int64_t)1 << 31) return fail(h, "gcdm_plan_batch: too many edges");
     // k_sample / k_prep stage one molecule in LDS (max_n * (3 + F) floats, 64 KB without an opt-in attribute)
     if (max_n > 4096 || (size_t)max_n * h->D * sizeof(float) > 65536) return fail(h, "gcdm_plan_batch: molecule too large (max_n * (3 + F) floats must fit 64 KB of LDS)");
+    free_plan(h);                 // only now: a rejected request leaves the previous plan in place
     const int N = noff[B];
     std::vector<int> erow(E), ecol(E), ncnt(N), rowstart(N);
     int64_t p = 0;
     for (int b = 0; b < B; ++b) {
         const int o = noff[b], n = nn[b];
+        int m = n;
+        if (node_mask) { m = 0; for (int i = 0; i < n; ++i) m += node_mask[o + i] ? 1 : 0; }
         for (int i = 0; i < n; ++i) {
-            ncnt[o + i] = n;
+            const bool on = !node_mask || node_mask[o + i];
+            ncnt[o + i] = on ? m : 0;           // a masked node has no edges: its aggregated row is zero (AggRow)
             rowstart[o + i] = (int)p;
-            for (int j = 0; j < n; ++j, ++p) { erow[p] = o + i; ecol[p] = o + j; }
+            if (!on) continue;
+            for (int j = 0; j < n; ++j)
+                if (!node_mask || node_mask[o + j]) { erow[p] = o + i; ecol[p] = o + j; ++p; }
         }
+    }
+    if (node_mask) {
+        std::vector<float> mf(N);
+        for (int i = 0; i < N; ++i) mf[i] = node_mask[i] ? 1.f : 0.f;
+        HIP_OK(h, hipMalloc(&h->d_mask, N * sizeof(float)));
+        HIP_OK(h, hipMemcpy(h->d_mask, mf.data(), N * sizeof(float), hipMemcpyHostToDevice));
     }
     HIP_OK(h, hipMalloc(&h->d_noff, (B + 1) * sizeof(int)));
     HIP_OK(h, hipMalloc(&h->d_erow, E * sizeof(int)));
@@ -844,7 +869,7 @@ int gcdm_forward_sc(gcdm_handle* h, const float* xh, const float* xh_sc, const f
     const int E = (int)h->E;
     HIP_OK(h, hipMemsetAsync(h->d_flags, 0, sizeof(uint32_t), st));
     PrepArgs pa{xh, t, context, h->d_noff, N, h->F, h->C, h->FinG, h->X0, h->XC, h->FBAR, h->CHI0, (v4f*)h->HIN4, h->flat_prev, h->flat_next,
-                h->sc, xh_sc, h->X0SC};
+                h->sc, xh_sc, h->X0SC, h->d_mask};
     hipLaunchKernelGGL(k_prep, dim3(B), dim3(64), 3 * h->max_n * sizeof(float), st, pa);
     EdgeEmbedArgs ea{h->X0, h->XC, N, h->d_erow, h->d_ecol, E, h->ee_ws, h->ee_bs, h->ee_wd, h->ee_wdf, h->ee_kappa, h->ee_wg, h->ee_bg,
                      (v4f*)h->EP4, h->AL, h->U, h->FR,
@@ -860,7 +885,7 @@ int gcdm_forward_sc(gcdm_handle* h, const float* xh, const float* xh_sc, const f
     na.HIN4 = (const v4f*)h->HIN4; na.CHI0 = h->CHI0; na.emb = h->emb;
     na.agg = AggSrc{h->AGG, h->PART, h->d_rowstart, h->d_ncnt, 0}; na.H4 = (v4f*)h->H4; na.CHI = h->CHI; na.XC = h->XC; na.X0 = h->X0; na.FBAR = h->FBAR;
     na.PQ4 = (v4f*)h->PQ4; na.VDI = h->VDI; na.VDJ = h->VDJ; na.H0 = h->H0;
-    na.proj = h->proj; na.OUT = out; na.VEL = h->VEL; na.flags_dev = h->d_flags;
+    na.proj = h->proj; na.OUT = out; na.VEL = h->VEL; na.flags_dev = h->d_flags; na.mask = h->d_mask;
     auto set_next = [&](int l) {
         if (l < h->L) {
             const LayerDev& d = h->layers[l];
@@ -941,7 +966,7 @@ int gcdm_forward_sc(gcdm_handle* h, const float* xh, const float* xh_sc, const f
         launch_node(false, l + 1, &d);
     }
     if (!truncated) {
-        FinishArgs fa{h->VEL, h->d_noff, N, h->D, out, h->d_flags, flags};
+        FinishArgs fa{h->VEL, h->d_noff, N, h->D, out, h->d_flags, flags, h->d_mask};
         hipLaunchKernelGGL(k_finish, dim3(B), dim3(64), 0, st, fa);
     }
     HIP_OK(h, hipGetLastError());
@@ -965,6 +990,7 @@ int32_t gcdm_timestep_index(float t, int32_t num_timesteps) {
 static float gamma_lookup(const gcdm_handle* h, float t) { return h->gamma[gcdm_timestep_index(t, h->cfg.num_timesteps)]; }
 
 static int launch_sample(gcdm_handle* h, StepArgs& sa, hipStream_t st) {
+    if (h->d_mask) return fail(h, "the sampler entry points need an all-True node mask (plan with gcdm_plan_batch); masked plans serve gcdm_forward only");
     DeviceGuard guard(h->cfg.device);
     sa.noff = h->d_noff; sa.N = h->N; sa.D = h->D; sa.node_base = h->node_base;
     if (h->fix_noise) {                 // pre-pass: mean of this draw over all nodes (deterministic order)

@@ -294,7 +294,7 @@ struct AggSrc {
 struct AggRow {            // where to find node's aggregated row
     const float* first;    // AGG row, or the first partial
     const float* next;     // partial (slot 0) of tile t0 + 1
-    int extra;             // number of further tiles
+    int extra;             // number of further tiles; -1: the node has no edges (a masked node): the row is zero
 };
 
 __device__ __forceinline__ AggRow agg_row(const AggSrc& s, int node) {
@@ -302,7 +302,10 @@ __device__ __forceinline__ AggRow agg_row(const AggSrc& s, int node) {
     const int t0 = rs >> s.tile_shift, t1 = (rs + n - 1) >> s.tile_shift;
     AggRow r;
     r.extra = t1 - t0;
-    if (r.extra == 0) {
+    if (n == 0) {
+        r.extra = -1;
+        r.first = r.next = s.AGG;
+    } else if (r.extra == 0) {
         r.first = s.AGG + (size_t)node * GCDM_AGGW;
         r.next = r.first;
     } else {
@@ -313,11 +316,13 @@ __device__ __forceinline__ AggRow agg_row(const AggSrc& s, int node) {
     return r;
 }
 __device__ __forceinline__ v4f agg_load4(const AggRow& r, int col) {
+    if (r.extra < 0) return (v4f){0.f, 0.f, 0.f, 0.f};
     v4f v = *(const v4f*)(r.first + col);
     for (int t = 0; t < r.extra; ++t) v += *(const v4f*)(r.next + (size_t)t * 2 * GCDM_AGGW + col);
     return v;
 }
 __device__ __forceinline__ float agg_load1(const AggRow& r, int col) {
+    if (r.extra < 0) return 0.f;
     float v = r.first[col];
     for (int t = 0; t < r.extra; ++t) v += r.next[(size_t)t * 2 * GCDM_AGGW + col];
     return v;
@@ -354,35 +359,43 @@ struct PrepArgs {
     // self-conditioning (gcpnet.py:1112-1139): h_in = [h0 | h_sc | t | context], CHI0 gets the orientations of x_sc as vectors 2, 3,
     // X0SC the un-centralised x_sc for the second edge scalar / vector.  xh_sc may be null (= zeros)
     int sc; const float* xh_sc; float* X0SC;
+    // masked nodes (batch.mask with False entries; gcpnet.py:1081, 1094-1099, components/__init__.py:53-92): 1 / 0 per node, or null (all True).
+    // Masked nodes enter with zero positions and features, have no edges, are left out of the centroid and keep time / context inputs.
+    const float* mask;
 };
 
 __global__ __launch_bounds__(64) void k_prep(PrepArgs a) {
     extern __shared__ __attribute__((aligned(16))) float xs[];  // [3][n] centralised
     const int b = blockIdx.x, o = a.noff[b], n = a.noff[b + 1] - o, D = 3 + a.F;
-    float m0 = 0.f, m1 = 0.f, m2 = 0.f;
+    float m0 = 0.f, m1 = 0.f, m2 = 0.f, cnt = 0.f;
     for (int i = 0; i < n; ++i) {  // same summation order as scatter(sum) over a sorted index
         const float* p = a.xh + (size_t)(o + i) * D;
-        m0 += p[0]; m1 += p[1]; m2 += p[2];
+        const float mk = a.mask ? a.mask[o + i] : 1.f;
+        m0 += p[0] * mk; m1 += p[1] * mk; m2 += p[2] * mk;
+        cnt += mk;
     }
-    m0 /= (float)n; m1 /= (float)n; m2 /= (float)n;
+    m0 /= cnt; m1 /= cnt; m2 /= cnt;
     for (int i = threadIdx.x; i < n; i += 64) {
         const int g = o + i;
         const float* p = a.xh + (size_t)g * D;
-        const float x0 = p[0], x1 = p[1], x2 = p[2];
+        const float mk = a.mask ? a.mask[g] : 1.f;
+        const float x0 = p[0] * mk, x1 = p[1] * mk, x2 = p[2] * mk;
         a.X0[g] = x0; a.X0[a.N + g] = x1; a.X0[2 * a.N + g] = x2;
-        const float c0 = x0 - m0, c1 = x1 - m1, c2 = x2 - m2;
+        const float c0 = x0 - m0 * mk, c1 = x1 - m1 * mk, c2 = x2 - m2 * mk;
         a.XC[g] = c0; a.XC[a.N + g] = c1; a.XC[2 * a.N + g] = c2;
         xs[i] = c0; xs[n + i] = c1; xs[2 * n + i] = c2;
         // orientations (protein_graph_dataset.py:217-225): flat neighbours, zero padded at the global ends
         float fw[3] = {0.f, 0.f, 0.f}, bw[3] = {0.f, 0.f, 0.f};
         if (g + 1 < a.N || a.has_next) {
             const float* q = p + D;
-            const float e0 = q[0] - x0, e1 = q[1] - x1, e2 = q[2] - x2, nr = sqrtf(e0 * e0 + e1 * e1 + e2 * e2);
+            const float mq = (a.mask && g + 1 < a.N) ? a.mask[g + 1] : 1.f;
+            const float e0 = q[0] * mq - x0, e1 = q[1] * mq - x1, e2 = q[2] * mq - x2, nr = sqrtf(e0 * e0 + e1 * e1 + e2 * e2);
             if (nr > 0.f) { fw[0] = e0 / nr; fw[1] = e1 / nr; fw[2] = e2 / nr; }
         }
         if (g > 0 || a.has_prev) {
             const float* q = p - D;
-            const float e0 = q[0] - x0, e1 = q[1] - x1, e2 = q[2] - x2, nr = sqrtf(e0 * e0 + e1 * e1 + e2 * e2);
+            const float mq = (a.mask && g > 0) ? a.mask[g - 1] : 1.f;
+            const float e0 = q[0] * mq - x0, e1 = q[1] * mq - x1, e2 = q[2] * mq - x2, nr = sqrtf(e0 * e0 + e1 * e1 + e2 * e2);
             if (nr > 0.f) { bw[0] = e0 / nr; bw[1] = e1 / nr; bw[2] = e2 / nr; }
         }
 #pragma unroll
@@ -414,7 +427,7 @@ __global__ __launch_bounds__(64) void k_prep(PrepArgs a) {
             for (int k = 0; k < 4; ++k) {
                 const int c = 4 * gg + k;
                 float val = 0.f;
-                if (c < a.F) val = p[3 + c];
+                if (c < a.F) val = p[3 + c] * mk;
                 else if (c < a.F + Fsc) val = a.xh_sc ? a.xh_sc[(size_t)g * D + 3 + (c - a.F)] : 0.f;
                 else if (c == a.F + Fsc) val = a.t[g];
                 else if (c < Fin) val = a.ctx[(size_t)g * a.C + (c - a.F - Fsc - 1)];
@@ -427,13 +440,15 @@ __global__ __launch_bounds__(64) void k_prep(PrepArgs a) {
     for (int i = threadIdx.x; i < n; i += 64) {
         float s[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, f[9];
         const float xi0 = xs[i], xi1 = xs[n + i], xi2 = xs[2 * n + i];
+        const float mi = a.mask ? a.mask[o + i] : 1.f;
         for (int j = 0; j < n; ++j) {
+            if (a.mask && (mi == 0.f || a.mask[o + j] == 0.f)) continue;       // no edge (i, j)
             frame_of(xi0, xi1, xi2, xs[j], xs[n + j], xs[2 * n + j], f);
 #pragma unroll
             for (int r = 0; r < 9; ++r) s[r] += f[r];
         }
 #pragma unroll
-        for (int r = 0; r < 9; ++r) a.FBAR[r * a.N + o + i] = s[r] / (float)n;
+        for (int r = 0; r < 9; ++r) a.FBAR[r * a.N + o + i] = mi != 0.f ? s[r] / cnt : 0.f;
     }
 }
 
@@ -860,6 +875,7 @@ struct NodeArgs {
     float* OUT;     // [N][Dout] : columns 3.. get h_final
     float* VEL;     // [3][N]
     uint32_t* flags_dev;
+    const float* mask;   // masked nodes (or null): h, chi and x of a masked node are zeroed after every interaction layer (gcpnet.py:914-928)
 };
 
 constexpr int NT_ = 32, NTP = 33;
@@ -954,12 +970,17 @@ __global__ __launch_bounds__(256) void k_node(NodeArgs a) {
             store_gate_partial<1>(PG, gacc, NTP, wave, lane);
             __syncthreads();
             store_state<2, 1, true>(XS4, HB, acc, NTP, mt0, lane);  // h <- h + ff.s (gcpnet.py:907)
+            const float me = a.mask ? a.mask[nid] : 1.f;            // masked nodes: h, chi, x <- 0 after the layer (gcpnet.py:914-928)
             vec_finish<NT_, 16>(PG, w.bg, w.wup, GCDM_V, VH, e, part, [&](int c, float ox, float oy, float oz) {
-                VV[((CB + c) * 3 + 0) * NTP + e] += ox;
-                VV[((CB + c) * 3 + 1) * NTP + e] += oy;
-                VV[((CB + c) * 3 + 2) * NTP + e] += oz;
+                VV[((CB + c) * 3 + 0) * NTP + e] = (VV[((CB + c) * 3 + 0) * NTP + e] + ox) * me;
+                VV[((CB + c) * 3 + 1) * NTP + e] = (VV[((CB + c) * 3 + 1) * NTP + e] + oy) * me;
+                VV[((CB + c) * 3 + 2) * NTP + e] = (VV[((CB + c) * 3 + 2) * NTP + e] + oz) * me;
             });
             __syncthreads();
+            if (a.mask) {
+                for (int g = part; g < GCDM_SG; g += 8) XS4[(HB + g) * NTP + e] *= me;
+                __syncthreads();
+            }
         }
         // ---- position update GCP2: (h, chi) -> (S, 1); x += v[0] * weight (gcpnet.py:834-857, 922-928)
         {
@@ -974,10 +995,11 @@ __global__ __launch_bounds__(256) void k_node(NodeArgs a) {
             gate_partial<2, 1>(gacc, acc, w.wg, mt0, lane);
             store_gate_partial<1>(PG, gacc, NTP, wave, lane);
             __syncthreads();
+            const float me = a.mask ? a.mask[nid] : 1.f;
             vec_finish<NT_, 8>(PG, w.bg, w.wup, 1, VH, e, part, [&](int c, float ox, float oy, float oz) {
-                XP[0 * NTP + e] += ox * a.pos_weight;
-                XP[1 * NTP + e] += oy * a.pos_weight;
-                XP[2 * NTP + e] += oz * a.pos_weight;
+                XP[0 * NTP + e] = (XP[0 * NTP + e] + ox * a.pos_weight) * me;
+                XP[1 * NTP + e] = (XP[1 * NTP + e] + oy * a.pos_weight) * me;
+                XP[2 * NTP + e] = (XP[2 * NTP + e] + oz * a.pos_weight) * me;
             });
             __syncthreads();
             if (part < 3 && valid) a.XC[(size_t)part * N + nid] = XP[part * NTP + e];
@@ -1056,6 +1078,7 @@ __global__ __launch_bounds__(256) void k_node(NodeArgs a) {
 // ================================================================================================
 struct FinishArgs {
     const float* VEL; const int* noff; int N, Dout; float* OUT; const uint32_t* flags_dev; uint32_t* user_flags;
+    const float* mask;      // masked nodes (or null): vel is zero there and they are left out of the centroid (components/__init__.py:53-92)
 };
 
 __global__ __launch_bounds__(64) void k_finish(FinishArgs a) {
@@ -1065,14 +1088,20 @@ __global__ __launch_bounds__(64) void k_finish(FinishArgs a) {
     if (fl && a.user_flags && b == 0 && threadIdx.x == 0) atomicOr(a.user_flags, fl);   // NaN-vel / f16-range bits
     float m0 = 0.f, m1 = 0.f, m2 = 0.f;
     if (!nan) {
-        for (int i = 0; i < n; ++i) { m0 += a.VEL[o + i]; m1 += a.VEL[a.N + o + i]; m2 += a.VEL[2 * (size_t)a.N + o + i]; }
-        m0 /= (float)n; m1 /= (float)n; m2 /= (float)n;
+        float cnt = 0.f;
+        for (int i = 0; i < n; ++i) {
+            const float mk = a.mask ? a.mask[o + i] : 1.f;
+            m0 += a.VEL[o + i] * mk; m1 += a.VEL[a.N + o + i] * mk; m2 += a.VEL[2 * (size_t)a.N + o + i] * mk;
+            cnt += mk;
+        }
+        m0 /= cnt; m1 /= cnt; m2 /= cnt;
     }
     for (int i = threadIdx.x; i < n; i += 64) {
         float* dst = a.OUT + (size_t)(o + i) * a.Dout;
-        dst[0] = nan ? 0.f : a.VEL[o + i] - m0;
-        dst[1] = nan ? 0.f : a.VEL[a.N + o + i] - m1;
-        dst[2] = nan ? 0.f : a.VEL[2 * (size_t)a.N + o + i] - m2;
+        const float mk = a.mask ? a.mask[o + i] : 1.f;
+        dst[0] = nan ? 0.f : (a.VEL[o + i] - m0) * mk;
+        dst[1] = nan ? 0.f : (a.VEL[a.N + o + i] - m1) * mk;
+        dst[2] = nan ? 0.f : (a.VEL[2 * (size_t)a.N + o + i] - m2) * mk;
     }
 }
 

@@ -316,13 +316,14 @@ __global__ __launch_bounds__(NX_THREADS) void k_node_x3(NodeX3Args ax) {
             for (int r = 0; r < 16; ++r) am[0][0][r] += al[0][0][r] * X3_INV_SCALE;   // nonlinearities (None, None)
             fold_gate(ax.ff.wgH, ax.ff.wgL, am);
             __syncthreads();
+            const float ml = a.mask ? a.mask[nidl] : 1.f, me = a.mask ? a.mask[nid] : 1.f;     // masked nodes: h, chi, x <- 0 after the layer (gcpnet.py:914-928)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) hst[r] += am[0][0][r];     // h <- h + ff.s (gcpnet.py:907), fp32
+            for (int r = 0; r < 16; ++r) hst[r] = (hst[r] + am[0][0][r]) * ml;     // h <- h + ff.s (gcpnet.py:907), fp32
             over |= store_block_x3(XH, XL, HB8 + 4 * wave, hst, NTP, lane);
             vec_finish<NT_, 16, NX_THREADS>(PG, w.bg, w.wup, GCDM_V, VH, e, part, [&](int c, float ox, float oy, float oz) {
-                VV[((CB + c) * 3 + 0) * NTP + e] += ox;
-                VV[((CB + c) * 3 + 1) * NTP + e] += oy;
-                VV[((CB + c) * 3 + 2) * NTP + e] += oz;
+                VV[((CB + c) * 3 + 0) * NTP + e] = (VV[((CB + c) * 3 + 0) * NTP + e] + ox) * me;
+                VV[((CB + c) * 3 + 1) * NTP + e] = (VV[((CB + c) * 3 + 1) * NTP + e] + oy) * me;
+                VV[((CB + c) * 3 + 2) * NTP + e] = (VV[((CB + c) * 3 + 2) * NTP + e] + oz) * me;
             });
             __syncthreads();
         }
@@ -342,9 +343,10 @@ __global__ __launch_bounds__(NX_THREADS) void k_node_x3(NodeX3Args ax) {
             fold_gate(ax.pos.wgH, ax.pos.wgL, am);
             __syncthreads();
             vec_finish<NT_, 8, NX_THREADS>(PG, w.bg, w.wup, 1, VH, e, part, [&](int c, float ox, float oy, float oz) {
-                XP[0 * NTP + e] += ox * a.pos_weight;
-                XP[1 * NTP + e] += oy * a.pos_weight;
-                XP[2 * NTP + e] += oz * a.pos_weight;
+                const float mp = a.mask ? a.mask[nid] : 1.f;
+                XP[0 * NTP + e] = (XP[0 * NTP + e] + ox * a.pos_weight) * mp;
+                XP[1 * NTP + e] = (XP[1 * NTP + e] + oy * a.pos_weight) * mp;
+                XP[2 * NTP + e] = (XP[2 * NTP + e] + oz * a.pos_weight) * mp;
             });
             __syncthreads();
             if (part < 3 && valid) a.XC[(size_t)part * N + nid] = XP[part * NTP + e];

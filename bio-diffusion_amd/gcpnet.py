@@ -248,26 +248,33 @@ class GCPNetDynamics(nn.Module):
         _native.check(lib, h, lib.gcdm_finalize_weights(h), "gcdm_finalize_weights")
         self._weights_version = ver
 
-    def plan(self, num_nodes) -> None:
-        """Builds the batch topology (molecule sizes) once; constant over the sampling loop."""
+    def plan(self, num_nodes, node_mask: Optional[torch.Tensor] = None) -> None:
+        """Builds the batch topology (molecule sizes, optionally a node mask with False = masked atoms) once; constant over the sampling loop."""
         nn_ = torch.as_tensor(num_nodes, dtype=torch.int32, device="cpu").contiguous()
         key = tuple(nn_.tolist())
+        mk = None
+        if node_mask is not None and not bool(node_mask.all()):
+            mk = node_mask.detach().to("cpu", torch.uint8).contiguous()
+            key = key + (mk.numpy().tobytes(),)
         if key == self._plan_key:
             return
-        st = self._lib.gcdm_plan_batch(self._handle, len(key), C.c_void_p(nn_.data_ptr()))
+        if mk is None:
+            st = self._lib.gcdm_plan_batch(self._handle, len(nn_), C.c_void_p(nn_.data_ptr()))
+        else:
+            if mk.numel() != int(nn_.sum()):
+                raise ValueError("node_mask must have one entry per node")
+            st = self._lib.gcdm_plan_batch_masked(self._handle, len(nn_), C.c_void_p(nn_.data_ptr()), C.c_void_p(mk.data_ptr()))
         _native.check(self._lib, self._handle, st, "gcdm_plan_batch")
         self._plan_key = key
         self._plan_src = None
 
     def _plan_from_batch_index(self, batch_index: torch.Tensor, mask: Optional[torch.Tensor]):
-        src = (batch_index.data_ptr(), batch_index.shape[0], batch_index._version)
+        src = (batch_index.data_ptr(), batch_index.shape[0], batch_index._version,
+               None if mask is None else (mask.data_ptr(), mask._version))
         if getattr(self, "_plan_src", None) == src and self._plan_key is not None:
             return
-        if mask is not None and not bool(mask.all()):
-            raise NotImplementedError("node_mask with masked nodes is not built (sampling uses an all-True mask, "
-                                      "src/mol_gen_sample.py:160)")
         counts = torch.unique_consecutive(batch_index, return_counts=True)[1]
-        self.plan(counts.cpu())
+        self.plan(counts.cpu(), mask)              # masked nodes (batch.mask with False entries): gcdm_plan_batch_masked
         self._plan_src = src
 
     # ------------------------------------------------------------------------------------------

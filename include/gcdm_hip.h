@@ -82,6 +82,13 @@ int gcdm_set_gamma(gcdm_handle* h, const float* host_gamma, int64_t numel);
  * topology is constant over the 1000 steps.  Replaces get_fully_connected_edge_index (gcpnet.py:1054-1066). */
 int gcdm_plan_batch(gcdm_handle* h, int32_t num_molecules, const int32_t* host_num_nodes);
 
+/* The same with masked nodes (`batch.mask` with False entries, gcpnet.py:1081-1099, 1062-1065): node_mask host uint8 [sum num_nodes], 0 = masked
+ * (NULL = all True).  A masked node enters the network with zero position and features, has no edges, is left out of its molecule's
+ * centroid, and its h / chi / x are zeroed after every interaction layer; its output row is (0, 0, 0 | projection of the zero state).
+ * Every molecule needs at least one unmasked node.  Masked plans serve gcdm_forward / gcdm_forward_sc only: the sampler entry points return
+ * an error (the reference's sampling drivers always pass an all-True mask, src/mol_gen_sample.py:160). */
+int gcdm_plan_batch_masked(gcdm_handle* h, int32_t num_molecules, const int32_t* num_nodes, const uint8_t* node_mask);
+
 /* One epsilon prediction.  xh [N,3+F] device, t [N] device (the reference passes [N,1]), context [N,C] device or
  * NULL, out [N,3+F] device, flags: device uint32 (OR-ed into) or NULL.  node_mask is all-True (mol_gen_sample.py:160).
  * Replaces GCPNetDynamics.forward (gcpnet.py:1042-1052, 1069-1232). */

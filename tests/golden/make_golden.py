@@ -173,6 +173,48 @@ def dyn_full(case):
         x_l0=x0, h_last=hL, chi_last=chiL, x_last=xL)
 
 
+def dyn_full_masked(case):
+    """Full-width forward with masked nodes (`batch.mask` with False entries: gcpnet.py:1081-1099 zeroed inputs, :1062-1065 no edges,
+    components/__init__.py:53-92 masked centroid, gcpnet.py:914-928 re-masking after every layer), run by the REFERENCE in fp32 and fp64."""
+    ds, cond, cfgs = cfgs_for(case)
+    d = synth.DATASET_DIMS[case]
+    net = rh.build_reference_dynamics(cfgs, seed=0)
+    shapes = synth.dynamics_shapes(d["S"], d["V"], d["Se"], d["Ve"], d["L"], synth.dims_h_in(d))
+    net.load_state_dict(synth.make_weights(shapes, seed=19))
+    sizes = [5, 19, 3, 11, 40] if case != "geom" else [5, 44, 3, 70]
+    xh, t, bi, nn_, ctx = synth.make_inputs(sizes, synth.dims_feat(d), seed=11, n_ctx=d["n_ctx"])
+    g = torch.Generator().manual_seed(23)
+    mask = torch.rand(len(bi), generator=g) > 0.25
+    for b in range(len(nn_)):                        # every molecule keeps an unmasked atom; one molecule is fully unmasked, one has its last atoms masked
+        sel = (bi == b).nonzero().flatten()
+        mask[sel[0]] = True
+    mask[(bi == 1)] = True
+    mask[(bi == 3).nonzero().flatten()[-3:]] = False
+    # inputs as a caller provides them: masked rows arbitrary (the network zeroes them), unmasked positions CoM-free per molecule
+    for b in range(len(nn_)):
+        sel = (bi == b) & mask
+        xh[sel, :3] -= xh[sel, :3].mean(0, keepdim=True)
+    xin = xh.clone()
+    xin[~mask] = 0.0                                  # the reference asserts masked positions ~ 0 inside centralize(edm=True)
+
+    def run(dtype):
+        prev = torch.get_default_dtype()
+        torch.set_default_dtype(dtype)
+        try:
+            n2 = net.to(dtype)
+            with torch.no_grad():
+                batch = rh.make_batch(bi, mask, None if ctx is None else ctx.to(dtype))
+                _, out = n2(batch, xin.to(dtype), t.to(dtype))
+            return out
+        finally:
+            torch.set_default_dtype(prev)
+            net.to(prev)
+
+    out32 = run(torch.float32)
+    out64 = run(torch.float64)
+    npz(f"dyn_masked_{case}", num_nodes=nn_, xh=xin, t=t, ctx=ctx, mask=mask, weight_seed=19, out32=out32, out64=out64.float())
+
+
 def sampler_small(case):
     ds, cond, cfgs = cfgs_for(case)
     cfgs = rh.shrink_cfgs(cfgs)
@@ -220,8 +262,13 @@ def sampler_small(case):
 
 if __name__ == "__main__":
     assert rh.reference_available(), "reference checkout not found"
+    if len(sys.argv) > 1 and sys.argv[1] == "masked":          # only the masked-node fixtures (added in round 2)
+        for case in ("qm9", "qm9cond", "geom"):
+            dyn_full_masked(case)
+        sys.exit(0)
     function_level()
     for case in ("qm9", "qm9cond", "geom"):
         dyn_small(case)
         sampler_small(case)
         dyn_full(case)
+        dyn_full_masked(case)

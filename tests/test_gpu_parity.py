@@ -308,6 +308,41 @@ def test_repeat_launch_bit_identity_full_batch(tile):
     assert lib.gcdm_set_option(h, b"edge_tile", 0) == 0
 
 
+@pytest.mark.parametrize("mode", MODES)
+@pytest.mark.parametrize("case", ["qm9", "qm9cond", "geom"])
+def test_masked_nodes_match_reference_golden(case, mode, golden_dir):
+    """`batch.mask` with False entries (gcpnet.py:1062-1065, 1081-1099, 914-928; components/__init__.py:53-92): full-width forward against the
+    REFERENCE's own outputs (tests/golden/dyn_masked_*.npz: random masks, a fully unmasked molecule, masked tails), both matrix modes and both
+    tile sizes; masked rows of the input are arbitrary (the network zeroes them); masked plans are refused by the sampler entry points."""
+    g = np.load(os.path.join(golden_dir, f"dyn_masked_{case}.npz"))
+    net, W, _ = _net(case, seed=int(g["weight_seed"]), mode=mode)
+    lib, h = net._lib, net._handle
+    nn_ = torch.tensor(g["num_nodes"])
+    bi = O.num_nodes_to_batch_index(nn_)
+    mask = torch.tensor(g["mask"]).bool()
+    ctx = torch.tensor(g["ctx"]) if "ctx" in g.files else None
+    xh = torch.tensor(g["xh"]).clone()
+    xh[~mask] = 7.5                                     # garbage in the masked rows must not matter
+    dev = torch.device("cuda")
+    for tile in (32, 64):
+        assert lib.gcdm_set_option(h, b"edge_tile", tile) == 0
+        batch = dict(batch=bi.to(dev), mask=mask.to(dev), props_context=None if ctx is None else ctx.to(dev))
+        _, out = net(batch, xh.to(dev), torch.tensor(g["t"]).to(dev))
+        torch.cuda.synchronize()
+        out = out.cpu()
+        assert (out - torch.tensor(g["out32"])).abs().max().item() <= TOL
+        assert (out - torch.tensor(g["out64"])).abs().max().item() <= TOL
+        assert out[~mask][:, :3].abs().max().item() == 0.0
+    assert lib.gcdm_set_option(h, b"edge_tile", 0) == 0
+    assert net.read_flags() == 0
+    z = torch.zeros_like(xh).to(dev)
+    st = lib.gcdm_sample_init(h, C.c_void_p(z.data_ptr()), None, C.c_uint64(1), C.c_void_p(torch.cuda.current_stream().cuda_stream))
+    assert st < 0 and b"all-True" in lib.gcdm_last_error(h)
+    # back to an unmasked plan on the same handle
+    out2 = _fwd(net, torch.tensor(g["xh"]), torch.tensor(g["t"]), bi, ctx)
+    assert torch.isfinite(out2).all()
+
+
 def test_f16_range_flag_and_fp32_fallback():
     """Activations beyond the f16 range: the split-precision kernel raises GCDM_FLAG_F16_RANGE and the module-level call
     transparently recomputes with fp32 MFMA (bit-identical to fp32 mode)."""
@@ -374,9 +409,9 @@ def test_forward_input_validation():
     mask = torch.ones(len(bi), dtype=torch.bool, device=dev)
     with pytest.raises(ValueError):
         net(dict(batch=bi.to(dev), mask=mask), xh[:, :-1].to(dev), t.to(dev))
-    mask2 = mask.clone(); mask2[0] = False
+    mask2 = mask.clone(); mask2[:4] = False           # a molecule without an unmasked atom: the reference's centroid would be 0 / 0
     bi2 = bi.clone().to(dev)
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(pkg._native.NativeError, match="unmasked"):
         net(dict(batch=bi2, mask=mask2), xh.to(dev), t.to(dev))
     # without diffusion_cfg.self_condition the reference ignores a self-conditioning input (gcpnet.py:1112); so does the mirror
     _, o1 = net(dict(batch=bi.to(dev), mask=mask), xh.to(dev), t.to(dev), xh_self_cond=xh.to(dev))

@@ -286,3 +286,19 @@ def test_oracle_follows_long_horizon_golden_first_50_steps(golden_dir):
             r32, r64 = torch.tensor(g[f"z32_{s}"]).double(), torch.tensor(g[f"z64_{s}"])
             bound = 4.0 * (r32 - r64).abs().max().item() + 1e-4 * r64.abs().max().item()
             assert (z.double() - r32).abs().max().item() <= bound, s
+
+
+@pytest.mark.parametrize("case", ["qm9", "qm9cond", "geom"])
+def test_oracle_masked_nodes_match_reference_golden(case, golden_dir):
+    """Masked nodes (`batch.mask` with False entries): the oracle against the reference's own full-width outputs (dyn_masked_*.npz)."""
+    g = load(golden_dir, f"dyn_masked_{case}")
+    d = synth.DATASET_DIMS[case]
+    P = synth.make_weights(synth.dynamics_shapes(d["S"], d["V"], d["Se"], d["Ve"], d["L"], synth.dims_h_in(d)), seed=int(g["weight_seed"]))
+    cfg = cfg_for(case, d["L"])
+    bi = O.num_nodes_to_batch_index(g["num_nodes"])
+    mask = torch.as_tensor(g["mask"]).bool()
+    assert (~mask).sum() > 5 and mask.sum() > 5
+    out = O.dynamics_forward(P, cfg, g["xh"], g["t"], bi, mask, g.get("ctx"))
+    assert (out - g["out32"]).abs().max().item() <= 2e-5
+    assert (out - g["out64"]).abs().max().item() <= 1e-4
+    assert out[~mask][:, :3].abs().max().item() == 0.0
