@@ -5,10 +5,10 @@
 Prints one line: sha256 of a full-size forward output and of the latent after 3 Philox sampler steps (bit-identity check between
 variants), and the per-step time of 40 sampler steps on one handle (HIP events on the launch stream).  The forward output is also
 kept in /tmp/ab_<tag>_<case>.pt; with a third argument the line additionally carries max |out - out_of_that_tag| / max |out| (for
-variants that change the summation order, e.g. -DGCDM_X3_PRE_MFMA: expect ~1e-6, the parity bar is 1e-4).
+variants that change the summation order: expect ~1e-6, the parity bar is 1e-4).
 
 Typical call (libraries pre-built in the build container under build/ab/, which travels to the GPU box):
-    for v in base pre; do cp build/ab/libgcdm_$v.so bio-diffusion_amd/libgcdm_hip.so; python tools/ab_variant.py $v qm9 base; done
+    for v in base new; do cp build/ab/libgcdm_$v.so bio-diffusion_amd/libgcdm_hip.so; python tools/ab_variant.py $v qm9 base; done
 """
 import ctypes as C
 import hashlib

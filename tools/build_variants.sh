@@ -1,9 +1,9 @@
 #!/bin/bash
 # Builds kernel variants of libgcdm_hip.so for A/B runs (build container; hipcc cross-compiles gfx950 without a GPU):
-#     tools/build_variants.sh base: pre:-DGCDM_X3_PRE_MFMA
-# -> build/ab/libgcdm_base.so, build/ab/libgcdm_pre.so   (build/ is git-ignored but travels to the GPU box with gpurun)
+#     tools/build_variants.sh base: v3:-DGCDM_VEC_PER_MFMA=3
+# -> build/ab/libgcdm_base.so, build/ab/libgcdm_v3.so   (build/ is git-ignored but travels to the GPU box with gpurun)
 # then on the GPU box, same call, alternating:
-#     for v in base pre base pre; do cp build/ab/libgcdm_$v.so bio-diffusion_amd/libgcdm_hip.so; python tools/ab_variant.py $v qm9 base; done
+#     for v in base v3 base v3; do cp build/ab/libgcdm_$v.so bio-diffusion_amd/libgcdm_hip.so; python tools/ab_variant.py $v qm9 base; done
 set -e
 cd "$(dirname "$0")/.."
 mkdir -p build/ab
