@@ -67,7 +67,7 @@ struct gcdm_handle {
     float* ws = nullptr;  // workspace pool
     size_t ws_floats = 0;
     float *X0 = nullptr, *XC = nullptr, *FBAR = nullptr, *CHI0 = nullptr, *HIN4 = nullptr, *H4 = nullptr, *CHI = nullptr, *PQ4 = nullptr,
-          *VDI = nullptr, *VDJ = nullptr, *AGG = nullptr, *PART = nullptr, *VEL = nullptr, *EPS = nullptr, *TBUF = nullptr, *EP4 = nullptr, *AL = nullptr, *U = nullptr, *FR = nullptr, *PROF = nullptr, *ZK = nullptr, *ZU = nullptr;
+          *VDI = nullptr, *VDJ = nullptr, *AGG = nullptr, *PART = nullptr, *VEL = nullptr, *EPS = nullptr, *TBUF = nullptr, *EP4 = nullptr, *AL = nullptr, *U = nullptr, *FR = nullptr, *PROF = nullptr, *ZK = nullptr, *ZU = nullptr, *ZROW = nullptr;
     uint32_t* d_flags = nullptr;
     float* d_gmean = nullptr;
     int flat_prev = 0, flat_next = 0;   // the plan is a slice of a larger flat batch (options "flat_prev" / "flat_next"; include/gcdm_hip.h)
@@ -87,6 +87,7 @@ struct gcdm_handle {
     // profiling (HIP events around the k_edge_msg launches of one forward)
     bool profile = false;
     bool profile_phases = false;     // enable == 2: in-kernel phase time stamps (debug_read("phase"))
+    bool profile_node = false;       // enable == 3: phase time stamps of the layer node kernel (debug_read("phase_node"))
     std::vector<hipEvent_t> ev;      // 2 per layer
     int ev_used = 0;
 };
@@ -807,7 +808,7 @@ int gcdm_plan_batch_masked(gcdm_handle* h, int32_t B, const int32_t* nn, const u
                  oAGG = take(GCDM_AGGW * n), oPART = take(((e + 31) / 32) * 2 * GCDM_AGGW), oVEL = take(3 * n), oEPS = take((size_t)h->D * n), oT = take(n), oEP = take((size_t)h->Se * e),
                  oAL = take((size_t)h->Ve * e), oU = take(3 * e), oFR = take(9 * e), oPROF = take(((e + 31) / 32) * 192),
                  oX0SC = take(h->sc ? 3 * n : 0), oBL = take(h->sc ? (size_t)h->Ve * e : 0), oUSC = take(h->sc ? 3 * e : 0),
-                 oZK = take((size_t)h->D * n), oZU = take((size_t)h->D * n);
+                 oZK = take((size_t)h->D * n), oZU = take((size_t)h->D * n), oZROW = take(GCDM_AGGW);
     h->ws_floats = off;
     if (off * sizeof(float) >= ((size_t)1 << 32)) return fail(h, "gcdm_plan_batch: workspace exceeds 4 GB (buffer-addressed); split the batch");
     HIP_OK(h, hipMalloc(&h->ws, off * sizeof(float)));
@@ -816,7 +817,7 @@ int gcdm_plan_batch_masked(gcdm_handle* h, int32_t B, const int32_t* nn, const u
     h->X0 = w + oX0; h->XC = w + oXC; h->FBAR = w + oFB; h->CHI0 = w + oC0; h->HIN4 = w + oHIN; h->H4 = w + oH4; h->CHI = w + oCHI;
     h->PQ4 = w + oPQ; h->VDI = w + oVDI; h->VDJ = w + oVDJ; h->AGG = w + oAGG; h->PART = w + oPART; h->VEL = w + oVEL; h->EPS = w + oEPS; h->TBUF = w + oT; h->EP4 = w + oEP;
     h->AL = w + oAL; h->U = w + oU; h->FR = w + oFR; h->PROF = w + oPROF;
-    h->ZK = w + oZK; h->ZU = w + oZU;
+    h->ZK = w + oZK; h->ZU = w + oZU; h->ZROW = w + oZROW;     // ZROW is never written: the workspace starts zeroed
     h->X0SC = h->sc ? w + oX0SC : nullptr; h->BL = h->sc ? w + oBL : nullptr; h->USC = h->sc ? w + oUSC : nullptr;
     h->B = B; h->N = N; h->E = E; h->max_n = max_n;
     return 0;
@@ -883,7 +884,7 @@ int gcdm_forward_sc(gcdm_handle* h, const float* xh, const float* xh_sc, const f
     NodeArgs na{};
     na.N = N; na.F = h->F; na.C = h->C; na.FinG = h->FinG; na.Dout = h->D; na.pos_weight = h->cfg.node_positions_weight;
     na.HIN4 = (const v4f*)h->HIN4; na.CHI0 = h->CHI0; na.emb = h->emb;
-    na.agg = AggSrc{h->AGG, h->PART, h->d_rowstart, h->d_ncnt, 0}; na.H4 = (v4f*)h->H4; na.CHI = h->CHI; na.XC = h->XC; na.X0 = h->X0; na.FBAR = h->FBAR;
+    na.agg = AggSrc{h->AGG, h->PART, h->d_rowstart, h->d_ncnt, 0, h->ZROW}; na.H4 = (v4f*)h->H4; na.CHI = h->CHI; na.XC = h->XC; na.X0 = h->X0; na.FBAR = h->FBAR;
     na.PQ4 = (v4f*)h->PQ4; na.VDI = h->VDI; na.VDJ = h->VDJ; na.H0 = h->H0;
     na.proj = h->proj; na.OUT = out; na.VEL = h->VEL; na.flags_dev = h->d_flags; na.mask = h->d_mask;
     auto set_next = [&](int l) {
@@ -907,6 +908,7 @@ int gcdm_forward_sc(gcdm_handle* h, const float* xh, const float* xh_sc, const f
                 node_kb_ok = false;
                 return;
             }
+            nx.prof = (h->profile_node && cur && next_layer < h->L) ? h->PROF : nullptr;
             if (next_layer < h->L) { nx.wpqH = h->layers[next_layer].wpqH; nx.wpqL = h->layers[next_layer].wpqL; nx.vdH = h->layers[next_layer].vdH; nx.vdL = h->layers[next_layer].vdL; nx.bpqx = h->layers[next_layer].bpqx; }
             if (embed && h->sc) hipLaunchKernelGGL((k_node_x3<true, 4>), dim3(ngrid), dim3(NX_THREADS), NK_LDS_BYTES, st, nx);
             else if (embed) hipLaunchKernelGGL(k_node_x3<true>, dim3(ngrid), dim3(NX_THREADS), NK_LDS_BYTES, st, nx);
@@ -1211,6 +1213,7 @@ int gcdm_profile_enable(gcdm_handle* h, int32_t enable) {
     }
     h->profile = enable != 0;
     h->profile_phases = enable == 2;
+    h->profile_node = enable == 3;
     h->ev_used = 0;
     return 0;
 }
@@ -1278,6 +1281,7 @@ int64_t gcdm_debug_read(gcdm_handle* h, const char* name, float* host_out, int64
     else if (k == "erow") { p = (const float*)h->d_erow; cnt = e; }        // int32 bit patterns (edge list of the plan: row / col node per flat edge)
     else if (k == "ecol") { p = (const float*)h->d_ecol; cnt = e; }
     else if (k == "phase") { p = h->PROF; cnt = ((e + h->tile() - 1) / h->tile()) * 192; }
+    else if (k == "phase_node") { p = h->PROF; cnt = ((n + NT_ - 1) / NT_) * 192; }
     else return fail(h, "gcdm_debug_read: unknown buffer " + k);
     if (!host_out) return cnt;
     if (capacity < cnt) return fail(h, "gcdm_debug_read: capacity too small");

@@ -289,6 +289,7 @@ struct AggSrc {
     const int* ROWSTART;   // [N] flat index of the node's first edge
     const int* NCNT;       // [N] row length (atoms of the node's molecule)
     int tile_shift;        // log2(edges per tile) of the edge kernel that produced PART
+    const float* ZROW;     // 352 zeros (the branch-free form below adds them where a row has no second piece)
 };
 
 struct AggRow {            // where to find node's aggregated row
@@ -321,6 +322,24 @@ __device__ __forceinline__ v4f agg_load4(const AggRow& r, int col) {
     for (int t = 0; t < r.extra; ++t) v += *(const v4f*)(r.next + (size_t)t * 2 * GCDM_AGGW + col);
     return v;
 }
+// Branch-free form for kernels that want all their loads in flight at once: row = first + next (+ `more` further partials, rare: only rows
+// longer than one tile).  Same summation order as agg_load4 / agg_load1 (adding the zero row changes no bits but the sign of a zero).
+struct AggRow2 {
+    const float* first;
+    const float* next;
+    int more;
+};
+__device__ __forceinline__ AggRow2 agg_row2(const AggSrc& s, int node, int rs, int n) {
+    const int t0 = rs >> s.tile_shift, t1 = (rs + n - 1) >> s.tile_shift;
+    const bool none = n == 0, whole = t1 == t0;
+    const int slot = (rs & ((1 << s.tile_shift) - 1)) ? 1 : 0;
+    AggRow2 r;
+    r.first = none ? s.ZROW : whole ? s.AGG + (size_t)node * GCDM_AGGW : s.PART + ((size_t)t0 * 2 + slot) * GCDM_AGGW;
+    r.next = (none || whole) ? s.ZROW : s.PART + ((size_t)(t0 + 1) * 2) * GCDM_AGGW;
+    r.more = (none || whole) ? 0 : t1 - t0 - 1;
+    return r;
+}
+
 __device__ __forceinline__ float agg_load1(const AggRow& r, int col) {
     if (r.extra < 0) return 0.f;
     float v = r.first[col];

@@ -21,7 +21,13 @@ struct NodeX3Args {
     const h8 *wpqH, *wpqL;         // next layer's msg0 node halves, packed [16][16][64]
     const float* bpqx;             // c * bias of the next layer's msg0 node halves (scaled units of the edge kernel, X3_C)
     const h8 *vdH, *vdL;           // next layer's msg0 vector halves [wddI; wddJ] (2 x (H0+3) rows x 32) as 16x16x32 A operands, [3][1][64]
+    float* prof;                   // optional [tiles][8 waves][24] phase time stamps (gcdm_profile_enable(h, 3))
 };
+
+#define NSTAMP(i)                                                                                       \
+    do {                                                                                                \
+        if (ax.prof && lane == 0) ax.prof[((size_t)blockIdx.x * 8 + wave) * 24 + (i)] = (float)(__builtin_amdgcn_s_memtime() - t_start); \
+    } while (0)
 
 // generic GCP2 pre-phase writing the extended-K rows as hi / lo' images (rows of [W_down; W_frames] split over the PARTS threads of an entity)
 template <int T, int H, int V_IN, int NTHR>
@@ -193,6 +199,7 @@ __global__ __launch_bounds__(NX_THREADS) void k_node_x3(NodeX3Args ax) {
     constexpr int PD = GCDM_NODE_PD;
     bool over = false;
     float amax = 0.f;
+    const uint64_t t_start = ax.prof ? __builtin_amdgcn_s_memtime() : 0;
 
     for (int r = part; r < 9; r += PARTS) FR[r * NTP + e] = a.FBAR[(size_t)r * N + nid];
     if (part < 3) XP[part * NTP + e] = a.XC[(size_t)part * N + nid];
@@ -266,33 +273,76 @@ __global__ __launch_bounds__(NX_THREADS) void k_node_x3(NodeX3Args ax) {
         });
         __syncthreads();
     } else {
-        // agg.s -> images (8-groups 0..31), agg.v -> VV channels 0..31, h -> registers + images (8-groups 32..63), chi -> VV channels 32..63
+        // agg.s -> images (8-groups 0..31), agg.v -> VV channels 0..31, h -> registers + images (8-groups 32..63), chi -> VV channels 32..63.
+        // Every global load of the phase is requested before the first one is consumed (row descriptors, then all row pieces, h and chi
+        // at once): three dependent round trips instead of one per piece.
         {
-            const AggRow src = agg_row(a.agg, nidl);
+            const AggSrc& sg = a.agg;
+            const int rs_l = sg.ROWSTART[nidl], n_l = sg.NCNT[nidl];
+            int ndx[4], rsx[4], ncx[4];                        // the 4 nodes whose vector rows this wave fetches (lane = channel)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                ndx[i] = min(n0 + wave + 8 * i, N - 1);
+                rsx[i] = sg.ROWSTART[ndx[i]];
+                ncx[i] = sg.NCNT[ndx[i]];
+            }
+            v4f hv[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) hv[q] = a.H4[(size_t)(8 * wave + 2 * q + half) * N + nidl];
+            static_assert(96 % PARTS == 0, "chi rows per thread");
+            float cv[96 / PARTS];
+#pragma unroll
+            for (int k = 0; k < 96 / PARTS; ++k) cv[k] = a.CHI[(size_t)(part + PARTS * k) * N + nid];
+            const AggRow2 src = agg_row2(sg, nidl, rs_l, n_l);
+            v4f f4[4], g4[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int col = 32 * wave + 4 * half + 8 * q;
+                f4[q] = *(const v4f*)(src.first + col);
+                g4[q] = *(const v4f*)(src.next + col);
+            }
+            AggRow2 sx[4];
+            float fa[4], ga[4], fb[4], gb[4];
+            const int colb = GCDM_S + 64 + (lane & 31);        // channels 64..95: lanes 32..63 repeat the loads of lanes 0..31, only those store
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                sx[i] = agg_row2(sg, ndx[i], rsx[i], ncx[i]);
+                fa[i] = sx[i].first[GCDM_S + lane];
+                ga[i] = sx[i].next[GCDM_S + lane];
+                fb[i] = sx[i].first[colb];
+                gb[i] = sx[i].next[colb];
+            }
             f32x16 t;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const v4f v = agg_load4(src, 32 * wave + 4 * half + 8 * q);
+                v4f v = f4[q] + g4[q];
+                for (int m = 1; m <= src.more; ++m) v += *(const v4f*)(src.next + (size_t)m * 2 * GCDM_AGGW + 32 * wave + 4 * half + 8 * q);
 #pragma unroll
                 for (int k = 0; k < 4; ++k) t[4 * q + k] = v[k];
             }
             over |= store_block_x3(XH, XL, 4 * wave, t, NTP, lane);
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const v4f v = a.H4[(size_t)(8 * wave + 2 * q + half) * N + nidl];
+            for (int q = 0; q < 4; ++q)
 #pragma unroll
-                for (int k = 0; k < 4; ++k) hst[4 * q + k] = v[k];
-            }
+                for (int k = 0; k < 4; ++k) hst[4 * q + k] = hv[q][k];
             over |= store_block_x3(XH, XL, HB8 + 4 * wave, hst, NTP, lane);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int x = wave + 8 * i;
+                float va = fa[i] + ga[i], vb = fb[i] + gb[i];
+                for (int m = 1; m <= sx[i].more; ++m) {
+                    va += sx[i].next[(size_t)m * 2 * GCDM_AGGW + GCDM_S + lane];
+                    vb += sx[i].next[(size_t)m * 2 * GCDM_AGGW + colb];
+                }
+                VV[lane * NTP + x] = va;
+                if (lane < 32) VV[(64 + lane) * NTP + x] = vb;
+            }
+#pragma unroll
+            for (int k = 0; k < 96 / PARTS; ++k) VV[(CB * 3 + part + PARTS * k) * NTP + e] = cv[k];
         }
-        for (int x = wave; x < NT_; x += 8) {
-            const int nd = min(n0 + x, N - 1);
-            const AggRow src = agg_row(a.agg, nd);
-            VV[lane * NTP + x] = agg_load1(src, GCDM_S + lane);
-            if (lane < 32) VV[(64 + lane) * NTP + x] = agg_load1(src, GCDM_S + 64 + lane);
-        }
-        for (int r = part; r < 96; r += PARTS) VV[(CB * 3 + r) * NTP + e] = a.CHI[(size_t)r * N + nid];
+        NSTAMP(1);
         __syncthreads();
+        NSTAMP(2);
         // ---- feed-forward GCP2 ------------------------------------------------------------------------------------------------
         {
             const GcpW& w = a.ff;
@@ -300,22 +350,29 @@ __global__ __launch_bounds__(NX_THREADS) void k_node_x3(NodeX3Args ax) {
             vecmat_mfma<2, 2, NTP>(ax.ff.vmH, ax.ff.vmL, VV, 0, wave, lane, amax, [&](int row, int x, int nd, float v) {
                 if (row < 19) VH[(row * 3 + x) * NTP + nd] = v;
             });
+            NSTAMP(3);
             __syncthreads();
             over |= gcp2_pre_tail_x3<NT_, 16, NX_THREADS>(VH, FR, XH, XL, 64, 66, 2 * ax.ff.KB, tid);
+            NSTAMP(4);
             __syncthreads();
+            NSTAMP(5);
             acc_bias(w.b);
             gemm(integral_constant<int, 34>{}, ax.ff.wH, ax.ff.wL, ax.ff.KB, 0);        // K' = 512 + 16 + 16
+            NSTAMP(6);
 #pragma unroll
             for (int r = 0; r < 16; ++r) am[0][0][r] = fast_silu(am[0][0][r] + al[0][0][r] * X3_INV_SCALE);
             __syncthreads();                                      // every wave is done reading agg.s (8-groups 0..31)
             over |= store_block_x3(XH, XL, 4 * wave, am[0][0], NTP, lane);   // hidden activations of Linear-SiLU-Linear
             __syncthreads();
+            NSTAMP(7);
             acc_bias(w.b2);
             gemm(integral_constant<int, 16>{}, ax.ff.w2H, ax.ff.w2L, 16, 0);
+            NSTAMP(8);
 #pragma unroll
             for (int r = 0; r < 16; ++r) am[0][0][r] += al[0][0][r] * X3_INV_SCALE;   // nonlinearities (None, None)
             fold_gate(ax.ff.wgH, ax.ff.wgL, am);
             __syncthreads();
+            NSTAMP(9);
             const float ml = a.mask ? a.mask[nidl] : 1.f, me = a.mask ? a.mask[nid] : 1.f;     // masked nodes: h, chi, x <- 0 after the layer (gcpnet.py:914-928)
 #pragma unroll
             for (int r = 0; r < 16; ++r) hst[r] = (hst[r] + am[0][0][r]) * ml;     // h <- h + ff.s (gcpnet.py:907), fp32
@@ -325,7 +382,9 @@ __global__ __launch_bounds__(NX_THREADS) void k_node_x3(NodeX3Args ax) {
                 VV[((CB + c) * 3 + 1) * NTP + e] = (VV[((CB + c) * 3 + 1) * NTP + e] + oy) * me;
                 VV[((CB + c) * 3 + 2) * NTP + e] = (VV[((CB + c) * 3 + 2) * NTP + e] + oz) * me;
             });
+            NSTAMP(10);
             __syncthreads();
+            NSTAMP(11);
         }
         // ---- position update GCP2 -------------------------------------------------------------------------------------------------
         {
@@ -336,8 +395,10 @@ __global__ __launch_bounds__(NX_THREADS) void k_node_x3(NodeX3Args ax) {
             __syncthreads();
             over |= gcp2_pre_tail_x3<NT_, 8, NX_THREADS>(VH, FR, XH, XL, 64, 65, HB8 + 2 * ax.pos.KB, tid);
             __syncthreads();
+            NSTAMP(12);
             acc_bias(w.b);
             gemm(integral_constant<int, 18>{}, ax.pos.wH, ax.pos.wL, ax.pos.KB, HB8);    // K' = 256 + 8 + 16 -> 288
+            NSTAMP(13);
 #pragma unroll
             for (int r = 0; r < 16; ++r) am[0][0][r] = fast_silu(am[0][0][r] + al[0][0][r] * X3_INV_SCALE);
             fold_gate(ax.pos.wgH, ax.pos.wgL, am);
@@ -350,6 +411,7 @@ __global__ __launch_bounds__(NX_THREADS) void k_node_x3(NodeX3Args ax) {
             });
             __syncthreads();
             if (part < 3 && valid) a.XC[(size_t)part * N + nid] = XP[part * NTP + e];
+            NSTAMP(14);
         }
     }
     // ---- write the node state back (h from the register master, chi from LDS) ----------------------------------------------------
@@ -362,30 +424,37 @@ __global__ __launch_bounds__(NX_THREADS) void k_node_x3(NodeX3Args ax) {
         for (int r = part; r < 96; r += PARTS) a.CHI[(size_t)r * N + nid] = VV[(CB * 3 + r) * NTP + e];
     }
 
+    NSTAMP(15);
     if (a.has_next) {
-        // ---- node-level halves of the next layer's msg0: wave w computes M-tiles w (P half) and w + 8 (Q half) --------------------
-        X3Ring<1, PD> r2;
+        // ---- node-level halves of the next layer's msg0 ([P | Q], 16 M-tiles): wave w computes M-tiles 2w and 2w + 1 -------------
+        // (one GEMM with two M-tiles per wave: the activations are read from LDS once and twice as many weight blocks are in flight)
+        {
+            X3Ring<2, PD> r2;
+            f32x16 pm[2][1], pl[2][1];
+            const int mt0 = 2 * wave;
+            acc_init_bias<2, 1>(pm, ax.bpqx, mt0, lane);
 #pragma unroll
-        for (int m = 0; m < 2; ++m) {
-            const int mt = wave + 8 * m;
-            acc_init_bias<1, 1>(am, ax.bpqx, mt, lane);
+            for (int m = 0; m < 2; ++m)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) al[0][0][r] = 0.f;
-            const h8* wh = ax.wpqH + (size_t)mt * 16 * 64;
-            const h8* wl = ax.wpqL + (size_t)mt * 16 * 64;
-            x3_prefetch<1, PD>(r2, wh, wl, 16, lane);
-            tile_gemm_x3<1, 1, PD, 16>(am, al, r2, wh, wl, 16, xh8 + HB8 * NTP, xl8 + HB8 * NTP, NTP, lane);
+                for (int r = 0; r < 16; ++r) pl[m][0][r] = 0.f;
+            const h8* wh = ax.wpqH + (size_t)mt0 * 16 * 64;
+            const h8* wl = ax.wpqL + (size_t)mt0 * 16 * 64;
+            x3_prefetch<2, PD>(r2, wh, wl, 16, lane);
+            tile_gemm_x3<2, 1, PD, 16>(pm, pl, r2, wh, wl, 16, xh8 + HB8 * NTP, xl8 + HB8 * NTP, NTP, lane);
             if (validl) {
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int g = 8 * mt + 2 * q + half;
-                    v4f o;
+                for (int m = 0; m < 2; ++m)
 #pragma unroll
-                    for (int t = 0; t < 4; ++t) o[t] = am[0][0][4 * q + t] + al[0][0][4 * q + t] * X3_INV_SCALE;
-                    a.PQ4[(size_t)g * N + n0 + l31] = o;
-                }
+                    for (int q = 0; q < 4; ++q) {
+                        const int g = 8 * (mt0 + m) + 2 * q + half;
+                        v4f o;
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) o[t] = pm[m][0][4 * q + t] + pl[m][0][4 * q + t] * X3_INV_SCALE;
+                        a.PQ4[(size_t)g * N + n0 + l31] = o;
+                    }
             }
         }
+        NSTAMP(16);
         // vector halves of the next layer's msg0: [W_down; W_frames][:, block] . chi for the row (I) and col (J) block -- 2 x (H0 + 3) rows
         {
             const int rows = a.H0 + 3;
@@ -424,6 +493,7 @@ __global__ __launch_bounds__(NX_THREADS) void k_node_x3(NodeX3Args ax) {
             over |= !(fabsf(v) <= 3.0e38f);
         }
     }
+    NSTAMP(17);
     over |= amax > X3_RANGE;
     if (__any(over) && lane == 0) atomicOr(a.flags_dev, GCDM_FLAG_F16_RANGE_BIT);
 }

@@ -199,7 +199,9 @@ int gcdm_get_option(const gcdm_handle* h, const char* name);
 
 /* Measurement hook: when enabled, every forward brackets each launch of the dominant kernel (the fused edge-message
  * kernel, one launch per interaction layer) with HIP events on `stream`; gcdm_profile_edge_kernel_ms() synchronises on
- * them and returns the summed duration and the launch count of the LAST forward. */
+ * them and returns the summed duration and the launch count of the LAST forward.  enable = 2 adds in-kernel phase time
+ * stamps of that kernel (gcdm_debug_read "phase": [tiles][8 waves][24] shader-clock offsets), enable = 3 the same for the
+ * per-layer node kernel ("phase_node": [node tiles][8][24]); both are diagnostics and slow the kernels slightly. */
 int gcdm_profile_enable(gcdm_handle* h, int32_t enable);
 int gcdm_profile_edge_kernel_ms(gcdm_handle* h, double* total_ms, int32_t* launches);
 

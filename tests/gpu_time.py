@@ -50,3 +50,21 @@ for i in sorted(names):
     dw = pw[:, i] - prevw
     print(f"  {i:2d} {names[i]:<18s} delta={mean[i]-prev:10.0f}  cum={mean[i]:10.0f}   [" + " ".join(f"{x:7.0f}" for x in dw.tolist()) + "]")
     prev, prevw = mean[i], pw[:, i]
+
+# the same for the per-layer node kernel (last layer with a successor)
+lib.gcdm_profile_enable(h, 3)
+net.native_forward(xh, t)
+torch.cuda.synchronize()
+pn = net.debug_read("phase_node").view(-1, 8, 24)
+lib.gcdm_profile_enable(h, 0)
+nnames = {1: "load agg/h/chi", 2: "barrier", 3: "ff vecmat (mfma)", 4: "barrier+ff pre tail", 5: "barrier", 6: "ff GEMM1 (34 kb)", 7: "silu+store+2 barriers",
+          8: "ff GEMM2 (16 kb)", 9: "gate fold+barriers", 10: "h update+vec_finish", 11: "barrier", 12: "pos vecmat+tail+barriers", 13: "pos GEMM (18 kb)",
+          14: "pos gate+finish+x", 15: "state write-back", 16: "PQ GEMMs (2x16 kb)", 17: "VDI/VDJ vecmat"}
+mean = pn.mean(dim=(0, 1))
+pw = pn.mean(dim=0)
+print(f"node kernel phases ({pn.shape[0]} tiles; shader cycles, cumulative -> delta); per-wave deltas in brackets:")
+prev, prevw = 0.0, torch.zeros(8)
+for i in sorted(nnames):
+    dw = pw[:, i] - prevw
+    print(f"  {i:2d} {nnames[i]:<26s} delta={mean[i]-prev:9.0f}  cum={mean[i]:9.0f}   [" + " ".join(f"{x:6.0f}" for x in dw.tolist()) + "]")
+    prev, prevw = mean[i], pw[:, i]
