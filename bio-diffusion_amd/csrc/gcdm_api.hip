@@ -3,6 +3,7 @@
 #include "gcdm_kernels.hip.h"
 #include "gcdm_edge_x3.hip.h"
 #include "gcdm_node_x3.hip.h"
+#include "gcdm_embed_x3.hip.h"
 #include "gcdm_stability.hip.h"
 #include "../../include/gcdm_hip.h"
 
@@ -50,6 +51,7 @@ struct gcdm_handle {
     int F = 0, C = 0, Fin = 0, FinG = 0, D = 0, Se = 0, Ve = 0, L = 0, H0 = 0;
     int sc = 0, FinP = 0;            // self-conditioning: Fin = [h | h_sc | t | ctx] feeds the node embedding, FinP = F + 1 + C is what the projection returns
     const float *ee_wd1 = nullptr, *ee_wdf1 = nullptr, *ee_kappa1 = nullptr;
+    const h8 *ee_xwH = nullptr, *ee_xwL = nullptr, *ee_xgH = nullptr, *ee_xgL = nullptr;     // split-precision A operands of k_edge_embed_x3
     float *X0SC = nullptr, *BL = nullptr, *USC = nullptr;
     // device weights
     float* wpool = nullptr;
@@ -519,7 +521,7 @@ int gcdm_finalize_weights(gcdm_handle* h) {
     Pool pool;
     g_split_absmax = 0.f;
     // ---- edge embedding (1,1) -> (Se,Ve), bottleneck 1: H = max(1, Ve) = Ve ------------------------
-    size_t o_ws, o_bs, o_wd, o_wdf, o_kap, o_wg, o_bg, o_wd1, o_wdf1, o_kap1;
+    size_t o_ws, o_bs, o_wd, o_wdf, o_kap, o_wg, o_bg, o_wd1, o_wdf1, o_kap1, o_exwH, o_exwL, o_exgH, o_exgL;
     {
         const std::string p = "gcp_embedding.edge_embedding.";
         WView ws, bs, wd, wdf, wu, wg, bg;
@@ -540,6 +542,33 @@ int gcdm_finalize_weights(gcdm_handle* h) {
         o_ws = pool.add(*ws.v); o_bs = pool.add(*bs.v); o_wd = pool.add(wd0); o_wdf = pool.add(wdf0);
         o_kap = pool.add(kap); o_wg = pool.add(*wg.v); o_bg = pool.add(*bg.v);
         o_wd1 = pool.add(wd1); o_wdf1 = pool.add(wdf1); o_kap1 = pool.add(kap1);
+        // split-precision A operands (k_edge_embed_x3, gcdm_embed_x3.hip.h): scalar_out with the K-slot order of that kernel
+        // (k = 16 kb + 8 half + s), the bias as the row of the constant-1 slot; vector_out_scale in the register order of the accumulators
+        {
+            const int NH = Ve / 2, MTe = (Se + 31) / 32;
+            Dense Wp(32 * MTe, 32);
+            for (int ch = 0; ch < Se; ++ch) {
+                for (int hf = 0; hf < 2; ++hf)
+                    for (int sl = 0; sl < NH; ++sl) Wp.at(ch, 8 * hf + sl) = ws.at(ch, ne + hf * NH + sl);
+                Wp.at(ch, 16) = ws.at(ch, 0);
+                if (h->sc) Wp.at(ch, 24) = ws.at(ch, 1);
+                for (int sl = 1; sl <= 5; ++sl) Wp.at(ch, 16 + sl) = ws.at(ch, ne + Ve + sl - 1);
+                for (int sl = 1; sl <= 4; ++sl) Wp.at(ch, 24 + sl) = ws.at(ch, ne + Ve + 4 + sl);
+                Wp.at(ch, 16 + 7) = bs.at(0, ch);
+            }
+            std::vector<float> xh, xl;
+            pack_x3(Wp, xh, xl);
+            o_exwH = pool.add(xh); o_exwL = pool.add(xl);
+            const int GB = Se / 16;
+            std::vector<uint16_t> H((size_t)GB * 64 * 8), Lo(H.size());
+            for (int b = 0; b < GB; ++b)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int sl = 0; sl < 8; ++sl) {
+                        const int c = lane & 31, ch = 32 * (b >> 1) + 16 * (b & 1) + 8 * (sl >> 2) + 4 * (lane >> 5) + (sl & 3);
+                        split_f16(c < Ve ? wg.at(c, ch) : 0.f, H[((size_t)b * 64 + lane) * 8 + sl], Lo[((size_t)b * 64 + lane) * 8 + sl]);
+                    }
+            o_exgH = pool.add(f16_words(H)); o_exgL = pool.add(f16_words(Lo));
+        }
     }
     // ---- node embedding (Fin,2) -> (S,V), bottleneck 1 ------------------------------------------------
     GcpOff emb, proj;
@@ -694,6 +723,7 @@ int gcdm_finalize_weights(gcdm_handle* h) {
     h->ee_ws = base + o_ws; h->ee_bs = base + o_bs; h->ee_wd = base + o_wd; h->ee_wdf = base + o_wdf;
     h->ee_kappa = base + o_kap; h->ee_wg = base + o_wg; h->ee_bg = base + o_bg;
     h->ee_wd1 = base + o_wd1; h->ee_wdf1 = base + o_wdf1; h->ee_kappa1 = base + o_kap1;
+    h->ee_xwH = (const h8*)(base + o_exwH); h->ee_xwL = (const h8*)(base + o_exwL); h->ee_xgH = (const h8*)(base + o_exgH); h->ee_xgL = (const h8*)(base + o_exgL);
     h->emb = resolve(emb, base);
     h->proj = resolve(proj, base);
     h->embx = resolve_x3(emb, base);
@@ -875,9 +905,16 @@ int gcdm_forward_sc(gcdm_handle* h, const float* xh, const float* xh_sc, const f
     EdgeEmbedArgs ea{h->X0, h->XC, N, h->d_erow, h->d_ecol, E, h->ee_ws, h->ee_bs, h->ee_wd, h->ee_wdf, h->ee_kappa, h->ee_wg, h->ee_bg,
                      (v4f*)h->EP4, h->AL, h->U, h->FR,
                      h->sc, (h->sc ? 2 : 1) + h->Ve + 9, h->X0SC, h->ee_wd1, h->ee_wdf1, h->ee_kappa1, h->BL, h->USC};
-    const int egrid = (E + 255) / 256;
-    if (h->Se == 64) hipLaunchKernelGGL((k_edge_embed<64, 16>), dim3(egrid), dim3(256), 0, st, ea);
-    else hipLaunchKernelGGL((k_edge_embed<16, 8>), dim3(egrid), dim3(256), 0, st, ea);
+    if (h->use_x3()) {
+        EdgeEmbedX3Args ex{ea, h->ee_xwH, h->ee_xwL, h->ee_xgH, h->ee_xgL};
+        const int egrid = (E + 127) / 128;           // 4 waves x 32 edges
+        if (h->Se == 64) hipLaunchKernelGGL((k_edge_embed_x3<64, 16>), dim3(egrid), dim3(256), 0, st, ex);
+        else hipLaunchKernelGGL((k_edge_embed_x3<16, 8>), dim3(egrid), dim3(256), 0, st, ex);
+    } else {
+        const int egrid = (E + 255) / 256;
+        if (h->Se == 64) hipLaunchKernelGGL((k_edge_embed<64, 16>), dim3(egrid), dim3(256), 0, st, ea);
+        else hipLaunchKernelGGL((k_edge_embed<16, 8>), dim3(egrid), dim3(256), 0, st, ea);
+    }
 
     const int L = (h->layer_limit >= 0 && h->layer_limit < h->L) ? h->layer_limit : h->L;
     const bool truncated = L < h->L;
