@@ -92,9 +92,16 @@ __device__ __forceinline__ bool gcp2_pre_x3g(const float* __restrict__ wdd, cons
 // n = l & 15 -- A[row n][k = 8q + j], B[k = 8q + j][col n], D[row 4q + i][col n]).  `store(row, x, node_in_tile, value)` receives
 // the results.  As VALU FMAs (16 threads per node, every thread re-reading all vector components) the same contractions cost
 // 700 (feed-forward pre-phase) and 670 (next layer's msg0 halves) instructions per thread.
+template <int MT, int KB>
+struct VecMatW {                 // the A operands of one vecmat_mfma, requested ahead of the phase that uses them
+    h8 aH[MT * KB], aL[MT * KB];
+    __device__ __forceinline__ void load(const h8* __restrict__ wH, const h8* __restrict__ wL, int lane) {
+#pragma unroll
+        for (int i = 0; i < MT * KB; ++i) { aH[i] = wH[i * 64 + lane]; aL[i] = wL[i * 64 + lane]; }
+    }
+};
 template <int MT, int KB, int TP, typename StoreFn>
-__device__ __forceinline__ void vecmat_mfma(const h8* __restrict__ wH, const h8* __restrict__ wL, const float* VV, int vch0, int wave, int lane,
-                                            float& amax, StoreFn store) {
+__device__ __forceinline__ void vecmat_mfma(const VecMatW<MT, KB>& w, const float* VV, int vch0, int wave, int lane, float& amax, StoreFn store) {
     if (wave >= 6) return;
     const int x = wave % 3, g = wave / 3, q = lane >> 4, n = lane & 15;
     f32x4 am[MT], al[MT];
@@ -114,10 +121,9 @@ __device__ __forceinline__ void vecmat_mfma(const h8* __restrict__ wH, const h8*
         const h8 bh = cat44(h0, h1), bl = cat44(l0, l1);
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
-            const h8 aH = wH[(m * KB + kb) * 64 + lane], aL = wL[(m * KB + kb) * 64 + lane];
-            am[m] = MFMA1632(aH, bh, am[m]);
-            al[m] = MFMA1632(aH, bl, al[m]);
-            al[m] = MFMA1632(aL, bh, al[m]);
+            am[m] = MFMA1632(w.aH[m * KB + kb], bh, am[m]);
+            al[m] = MFMA1632(w.aH[m * KB + kb], bl, al[m]);
+            al[m] = MFMA1632(w.aL[m * KB + kb], bh, al[m]);
         }
     }
 #pragma unroll
@@ -156,6 +162,51 @@ __device__ __forceinline__ bool gcp2_pre_tail_x3(const float* VH, const float* F
         }
     }
     return over;
+}
+
+// vector_up weights and gate bias of the channels a thread finishes (c = part + PARTS * i), requested long before vec_finish needs them:
+// loaded at the point of use they cost the phase an exposed L2 round trip (two waves per SIMD, all of them in the same phase)
+template <int H, int NC>
+struct VecFinW {
+    float bg[NC];
+    v4f w[NC][H / 4];
+    __device__ __forceinline__ void load(const float* __restrict__ bgp, const float* __restrict__ wup, int V_out, int part, int parts) {
+#pragma unroll
+        for (int i = 0; i < NC; ++i) {
+            const int c = min(part + parts * i, V_out - 1);
+            bg[i] = bgp[c];
+#pragma unroll
+            for (int k = 0; k < H / 4; ++k) w[i][k] = *(const v4f*)(wup + c * H + 4 * k);
+        }
+    }
+};
+template <int T, int H, int NC, int NTHR, typename StoreFn>
+__device__ __forceinline__ void vec_finish_w(const float* PG, const VecFinW<H, NC>& fw, int V_out, const float* VH, int e, int part, StoreFn store) {
+    constexpr int TP = T + 1, PARTS = NTHR / T;
+    float hx[H], hy[H], hz[H];
+#pragma unroll
+    for (int h = 0; h < H; ++h) {
+        hx[h] = VH[(h * 3 + 0) * TP + e];
+        hy[h] = VH[(h * 3 + 1) * TP + e];
+        hz[h] = VH[(h * 3 + 2) * TP + e];
+    }
+#pragma unroll
+    for (int i = 0; i < NC; ++i) {
+        const int c = part + PARTS * i;
+        if (c < V_out) {
+            float g = fw.bg[i];
+#pragma unroll
+            for (int w = 0; w < 4; ++w) g += PG[(w * 32 + c) * TP + e];
+            const float sg = fast_sigmoid(g);
+            float ox = 0.f, oy = 0.f, oz = 0.f;
+#pragma unroll
+            for (int h = 0; h < H; ++h) {
+                const float wv = fw.w[i][h >> 2][h & 3];
+                ox += wv * hx[h]; oy += wv * hy[h]; oz += wv * hz[h];
+            }
+            store(c, ox * sg, oy * sg, oz * sg);
+        }
+    }
 }
 
 // hi / lo' images of a C-layout register block (one M-tile, one N-tile) -> 8-groups gbase8 .. gbase8+3
@@ -226,7 +277,34 @@ __global__ __launch_bounds__(NX_THREADS) void k_node_x3(NodeX3Args ax) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) al[0][0][r] = 0.f;
     };
-    auto fold_gate = [&](const h8* wgH, const h8* wgL, const f32x16 (&act)[1][1]) {   // two-stage fold of the 8 gate partials
+    struct GateW { h8 aH[2], aL[2]; };
+    auto load_gate = [&](const h8* wgH, const h8* wgL) {      // called before the GEMM whose output the gate contracts
+        GateW g;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) { g.aH[j] = wgH[(wave * 2 + j) * 64 + lane]; g.aL[j] = wgL[(wave * 2 + j) * 64 + lane]; }
+        return g;
+    };
+    auto fold_gate_w = [&](const GateW& g, const f32x16 (&act)[1][1]) {   // two-stage fold of the 8 gate partials
+        const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            h8 bh, bl;
+#pragma unroll
+            for (int t = 0; t < 8; t += 2) {
+                h2 hi, lo;
+                split16x2(act[0][0][8 * j + t], act[0][0][8 * j + t + 1], hi, lo);
+                bh[t] = hi[0]; bh[t + 1] = hi[1];
+                bl[t] = lo[0]; bl[t + 1] = lo[1];
+            }
+            gm[0] = MFMA16(g.aH[j], bh, j == 0 ? zero : gm[0]);
+            gl[0] = MFMA16(g.aH[j], bl, j == 0 ? zero : gl[0]);
+            gl[0] = MFMA16(g.aL[j], bh, gl[0]);
+        }
+        if (wave < 4) put_gate_partial<1>(PG, gm, gl, NTP, wave, lane, false);
+        __syncthreads();
+        if (wave >= 4) put_gate_partial<1>(PG, gm, gl, NTP, wave - 4, lane, true);
+    };
+    auto fold_gate = [&](const h8* wgH, const h8* wgL, const f32x16 (&act)[1][1]) {   // (embedding: weights loaded at the point of use)
 #pragma unroll
         for (int r = 0; r < 16; ++r) { gm[0][r] = 0.f; gl[0][r] = 0.f; }
         gate_partial_x3<1, 1>(gm, gl, act, wgH, wgL, wave, lane);
@@ -235,6 +313,10 @@ __global__ __launch_bounds__(NX_THREADS) void k_node_x3(NodeX3Args ax) {
         if (wave >= 4) put_gate_partial<1>(PG, gm, gl, NTP, wave - 4, lane, true);
     };
 
+    VecFinW<16, GCDM_V / PARTS> fw_ff;
+    VecFinW<8, 1> fw_pos;
+    VecMatW<2, 2> vm_ff;
+    VecMatW<1, 1> vm_pos;
     if (EMBED) {
         // h_in (fp32 float4 groups in HBM) -> images; zero the unused half of the last 8-group
         const int G8in = (a.FinG + 1) >> 1;
@@ -293,6 +375,9 @@ __global__ __launch_bounds__(NX_THREADS) void k_node_x3(NodeX3Args ax) {
             float cv[96 / PARTS];
 #pragma unroll
             for (int k = 0; k < 96 / PARTS; ++k) cv[k] = a.CHI[(size_t)(part + PARTS * k) * N + nid];
+            vm_ff.load(ax.ff.vmH, ax.ff.vmL, lane);
+            fw_ff.load(a.ff.bg, a.ff.wup, GCDM_V, part, PARTS);
+            fw_pos.load(a.pos.bg, a.pos.wup, 1, part, PARTS);
             const AggRow2 src = agg_row2(sg, nidl, rs_l, n_l);
             v4f f4[4], g4[4];
 #pragma unroll
@@ -347,7 +432,7 @@ __global__ __launch_bounds__(NX_THREADS) void k_node_x3(NodeX3Args ax) {
         {
             const GcpW& w = a.ff;
             // pre-phase: [W_down (16); W_frames (3)] x 64 input vectors on the matrix pipe -> VH, then norms / frame scalars
-            vecmat_mfma<2, 2, NTP>(ax.ff.vmH, ax.ff.vmL, VV, 0, wave, lane, amax, [&](int row, int x, int nd, float v) {
+            vecmat_mfma<2, 2, NTP>(vm_ff, VV, 0, wave, lane, amax, [&](int row, int x, int nd, float v) {
                 if (row < 19) VH[(row * 3 + x) * NTP + nd] = v;
             });
             NSTAMP(3);
@@ -366,18 +451,20 @@ __global__ __launch_bounds__(NX_THREADS) void k_node_x3(NodeX3Args ax) {
             __syncthreads();
             NSTAMP(7);
             acc_bias(w.b2);
+            const GateW gw = load_gate(ax.ff.wgH, ax.ff.wgL);
+            vm_pos.load(ax.pos.vmH, ax.pos.vmL, lane);
             gemm(integral_constant<int, 16>{}, ax.ff.w2H, ax.ff.w2L, 16, 0);
             NSTAMP(8);
 #pragma unroll
             for (int r = 0; r < 16; ++r) am[0][0][r] += al[0][0][r] * X3_INV_SCALE;   // nonlinearities (None, None)
-            fold_gate(ax.ff.wgH, ax.ff.wgL, am);
+            fold_gate_w(gw, am);
             __syncthreads();
             NSTAMP(9);
             const float ml = a.mask ? a.mask[nidl] : 1.f, me = a.mask ? a.mask[nid] : 1.f;     // masked nodes: h, chi, x <- 0 after the layer (gcpnet.py:914-928)
 #pragma unroll
             for (int r = 0; r < 16; ++r) hst[r] = (hst[r] + am[0][0][r]) * ml;     // h <- h + ff.s (gcpnet.py:907), fp32
             over |= store_block_x3(XH, XL, HB8 + 4 * wave, hst, NTP, lane);
-            vec_finish<NT_, 16, NX_THREADS>(PG, w.bg, w.wup, GCDM_V, VH, e, part, [&](int c, float ox, float oy, float oz) {
+            vec_finish_w<NT_, 16, GCDM_V / PARTS, NX_THREADS>(PG, fw_ff, GCDM_V, VH, e, part, [&](int c, float ox, float oy, float oz) {
                 VV[((CB + c) * 3 + 0) * NTP + e] = (VV[((CB + c) * 3 + 0) * NTP + e] + ox) * me;
                 VV[((CB + c) * 3 + 1) * NTP + e] = (VV[((CB + c) * 3 + 1) * NTP + e] + oy) * me;
                 VV[((CB + c) * 3 + 2) * NTP + e] = (VV[((CB + c) * 3 + 2) * NTP + e] + oz) * me;
@@ -389,7 +476,7 @@ __global__ __launch_bounds__(NX_THREADS) void k_node_x3(NodeX3Args ax) {
         // ---- position update GCP2 -------------------------------------------------------------------------------------------------
         {
             const GcpW& w = a.pos;
-            vecmat_mfma<1, 1, NTP>(ax.pos.vmH, ax.pos.vmL, VV, CB, wave, lane, amax, [&](int row, int x, int nd, float v) {
+            vecmat_mfma<1, 1, NTP>(vm_pos, VV, CB, wave, lane, amax, [&](int row, int x, int nd, float v) {
                 if (row < 11) VH[(row * 3 + x) * NTP + nd] = v;
             });
             __syncthreads();
@@ -397,13 +484,14 @@ __global__ __launch_bounds__(NX_THREADS) void k_node_x3(NodeX3Args ax) {
             __syncthreads();
             NSTAMP(12);
             acc_bias(w.b);
+            const GateW gw = load_gate(ax.pos.wgH, ax.pos.wgL);
             gemm(integral_constant<int, 18>{}, ax.pos.wH, ax.pos.wL, ax.pos.KB, HB8);    // K' = 256 + 8 + 16 -> 288
             NSTAMP(13);
 #pragma unroll
             for (int r = 0; r < 16; ++r) am[0][0][r] = fast_silu(am[0][0][r] + al[0][0][r] * X3_INV_SCALE);
-            fold_gate(ax.pos.wgH, ax.pos.wgL, am);
+            fold_gate_w(gw, am);
             __syncthreads();
-            vec_finish<NT_, 8, NX_THREADS>(PG, w.bg, w.wup, 1, VH, e, part, [&](int c, float ox, float oy, float oz) {
+            vec_finish_w<NT_, 8, 1, NX_THREADS>(PG, fw_pos, 1, VH, e, part, [&](int c, float ox, float oy, float oz) {
                 const float mp = a.mask ? a.mask[nid] : 1.f;
                 XP[0 * NTP + e] = (XP[0 * NTP + e] + ox * a.pos_weight) * mp;
                 XP[1 * NTP + e] = (XP[1 * NTP + e] + oy * a.pos_weight) * mp;
@@ -428,6 +516,8 @@ __global__ __launch_bounds__(NX_THREADS) void k_node_x3(NodeX3Args ax) {
     if (a.has_next) {
         // ---- node-level halves of the next layer's msg0 ([P | Q], 16 M-tiles): wave w computes M-tiles 2w and 2w + 1 -------------
         // (one GEMM with two M-tiles per wave: the activations are read from LDS once and twice as many weight blocks are in flight)
+        VecMatW<3, 1> vm_next;
+        vm_next.load(ax.vdH, ax.vdL, lane);
         {
             X3Ring<2, PD> r2;
             f32x16 pm[2][1], pl[2][1];
@@ -458,7 +548,7 @@ __global__ __launch_bounds__(NX_THREADS) void k_node_x3(NodeX3Args ax) {
         // vector halves of the next layer's msg0: [W_down; W_frames][:, block] . chi for the row (I) and col (J) block -- 2 x (H0 + 3) rows
         {
             const int rows = a.H0 + 3;
-            vecmat_mfma<3, 1, NTP>(ax.vdH, ax.vdL, VV, CB, wave, lane, amax, [&](int row, int x, int nd, float v) {
+            vecmat_mfma<3, 1, NTP>(vm_next, VV, CB, wave, lane, amax, [&](int row, int x, int nd, float v) {
                 if (row < 2 * rows && n0 + nd < N) {
                     const int side = row >= rows, hh = side ? row - rows : row;
                     (side ? a.VDJ : a.VDI)[(size_t)(hh * 3 + x) * N + n0 + nd] = v;
