@@ -72,6 +72,15 @@ __device__ __forceinline__ void split16x2(float x0, float x1, h2& hi, h2& lo) {
     __builtin_memcpy(&lo, &lou, 4);
 }
 
+// Registers written by the inline-asm splits above and consumed DIRECTLY by an MFMA pass through x3_settle first.  The last writer of
+// such a register is a partial (16-bit, op_sel) write; for the consumer of an inline-asm definition the compiler's hazard recognizer
+// leaves one wait state, and with a v_fma_mixhi_f16 issued right in front of the MFMA that reads its destination the MFMA was measured
+// to pick up the OLD value in its first lane groups (edge-embedding kernel: 16 of a wave's 32 edges wrong, in a few of 1 300 waves, on
+// different waves from run to run; tests/gpu_ragged_diag.py).  The asm below is a data-dependent fence: two more wait states between
+// the splits and the MFMA, whatever the scheduler does around them.
+__device__ __forceinline__ void x3_settle(h8& a, h8& b) { asm("s_nop 1" : "+v"(a), "+v"(b)); }
+__device__ __forceinline__ void x3_settle(h8& a) { asm("s_nop 1" : "+v"(a)); }
+
 // ---- tile GEMM on split operands: am += Whi.Xhi ; al += Whi.Xlo' + Wlo'.Xhi ------------------------------------------------
 // A-operand ring of one GEMM (PD+1 statically indexed register sets of hi / lo' weights).  `x3_prefetch` issues the loads of the
 // first PD k-blocks; it is called one phase EARLY (right after the previous GEMM), so that the cold L2 round trip of a GEMM that
@@ -273,6 +282,8 @@ __device__ __forceinline__ void gate_partial_x3(f32x16 (&gm)[NT], f32x16 (&gl)[N
                     bl[n][s] = lo[0]; bl[n][s + 1] = lo[1];
                 }
 #pragma unroll
+            for (int n = 0; n < NT; ++n) x3_settle(bh[n], bl[n]);
+#pragma unroll
             for (int n = 0; n < NT; ++n) gm[n] = MFMA16(aH, bh[n], (ZERO && m == 0 && j == 0) ? zero : gm[n]);
 #pragma unroll
             for (int n = 0; n < NT; ++n) gl[n] = MFMA16(aH, bl[n], (ZERO && m == 0 && j == 0) ? zero : gl[n]);
@@ -464,6 +475,7 @@ struct VecStage {
         split4(v1, sh1, sl1, amax);
         bh[b] = cat44(sh0, sh1);
         bl[b] = cat44(sl0, sl1);
+        x3_settle(bh[b], bl[b]);
     }
     __device__ __forceinline__ void split_vv(int x) {                                             // B images of vector_down: own groups q | 4 + q
         const float b0[4] = {va[x][0], va[x][1], va[x][2], va[x][3]}, b1[4] = {vb[x][0], vb[x][1], vb[x][2], vb[x][3]};
@@ -471,7 +483,8 @@ struct VecStage {
         split4(b1, sh1, sl1, amax);
     }
     __device__ __forceinline__ void pre_x(int x) {
-        const h8 xh = cat44(sh0, sh1), xl = cat44(sl0, sl1);
+        h8 xh = cat44(sh0, sh1), xl = cat44(sl0, sl1);
+        x3_settle(xh, xl);
         f32x4 am = {0.f, 0.f, 0.f, 0.f}, al = {0.f, 0.f, 0.f, 0.f};
         am = MFMA1632(pa[0], xh, am);
         al = MFMA1632(pa[0], xl, al);
@@ -484,6 +497,7 @@ struct VecStage {
         h4 vh, vl;
         split4(v, vh, vl, amax);
         img = cat44(vh, vl);
+        x3_settle(img);
     }
 
     // the common tail: vector_down of GCP2 k from va / vb (stages T0 .. T0+9)

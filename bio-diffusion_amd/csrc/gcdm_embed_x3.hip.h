@@ -104,6 +104,8 @@ __global__ __launch_bounds__(256) void k_edge_embed_x3(EdgeEmbedX3Args ax) {
         bh[1][s] = hi[0]; bh[1][s + 1] = hi[1];
         bl[1][s] = lo[0]; bl[1][s + 1] = lo[1];
     }
+    x3_settle(bh[0], bl[0]);
+    x3_settle(bh[1], bl[1]);
     const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     f32x16 p[MT];
 #pragma unroll
@@ -137,6 +139,7 @@ __global__ __launch_bounds__(256) void k_edge_embed_x3(EdgeEmbedX3Args ax) {
             xh[s] = hi[0]; xh[s + 1] = hi[1];
             xl[s] = lo[0]; xl[s + 1] = lo[1];
         }
+        x3_settle(xh, xl);
         gm = MFMA16(gh[b], xh, gm);
         gl = MFMA16(gh[b], xl, gl);
         gl = MFMA16(gl_[b], xh, gl);

@@ -118,7 +118,8 @@ __device__ __forceinline__ void vecmat_mfma(const VecMatW<MT, KB>& w, const floa
         h4 h0, l0, h1, l1;
         split4(v0, h0, l0, amax);
         split4(v1, h1, l1, amax);
-        const h8 bh = cat44(h0, h1), bl = cat44(l0, l1);
+        h8 bh = cat44(h0, h1), bl = cat44(l0, l1);
+        x3_settle(bh, bl);
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
             am[m] = MFMA1632(w.aH[m * KB + kb], bh, am[m]);
@@ -296,6 +297,7 @@ __global__ __launch_bounds__(NX_THREADS) void k_node_x3(NodeX3Args ax) {
                 bh[t] = hi[0]; bh[t + 1] = hi[1];
                 bl[t] = lo[0]; bl[t + 1] = lo[1];
             }
+            x3_settle(bh, bl);
             gm[0] = MFMA16(g.aH[j], bh, j == 0 ? zero : gm[0]);
             gl[0] = MFMA16(g.aH[j], bl, j == 0 ? zero : gl[0]);
             gl[0] = MFMA16(g.aL[j], bh, gl[0]);

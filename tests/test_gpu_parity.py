@@ -255,6 +255,27 @@ def test_forward_matches_oracle_ragged(case, num_nodes, mode):
     assert (out - ref).abs().max().item() <= TOL * scale
 
 
+def test_edge_embedding_of_both_modes_agrees_on_a_large_ragged_batch():
+    """The split-precision edge-embedding kernel feeds MFMAs straight from inline-asm 16-bit partial writes; without the settle fence
+    (x3_settle, gcdm_edge_x3.hip.h) a few waves of a grid larger than one round of workgroups read stale B lanes, different waves from
+    run to run.  40 870 edges (320 workgroups), 6 repeats, every edge within 1e-5 of the fp32 kernel's e' and alpha."""
+    d = _dims("geom")
+    num_nodes = [181, 3, 90]
+    xh, t, bi, nn_, ctx = synth.make_inputs(num_nodes, synth.dims_feat(d), seed=31, t_value=0.63, n_ctx=d["n_ctx"])
+    want = None
+    for mode, reps in ((0, 1), (1, 6)):
+        net, _, _ = _net("geom", seed=23, scale=0.5, mode=mode)
+        for _ in range(reps):
+            _fwd(net, xh, t, bi, ctx)
+            E = net.debug_read("u").numel() // 3
+            got = (_un_g4(net.debug_read("ep"), d["Se"] // 4, E), net.debug_read("alpha").view(d["Ve"], E).t().clone())
+            if want is None:
+                want = got
+                continue
+            for g, w in zip(got, want):
+                assert (g - w).abs().max().item() <= 1e-5 * max(1.0, w.abs().max().item())
+
+
 @pytest.mark.parametrize("mode", MODES)
 @pytest.mark.parametrize("case,num_nodes", [("qm9", [29] * 7 + [3]), ("geom", [181, 3, 90])])
 def test_forward_32_edge_tiles(case, num_nodes, mode):
