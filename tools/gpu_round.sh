@@ -1,0 +1,23 @@
+#!/bin/bash
+# The round's measurement set in ONE gpurun call (one box): rocprofv3 stats + PMC passes for QM9 and GEOM, the PMC summaries written
+# into profiles/ of the box's copy (so that the bench lines that follow carry `traffic` of THIS build), then the three bench lines.
+#   GCDM_GIT_HEAD=<short sha> tools/gpu_round.sh r02        -> gpurun_out/<tag>_*  (copy what is to be kept into profiles/)
+set -u
+TAG=${1:-r02}
+ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$ROOT/gpurun_out
+mkdir -p $OUT
+cd $ROOT
+tools/gpu_profile.sh ${TAG} qm9 > $OUT/${TAG}_profile_qm9.log 2>&1
+tools/gpu_profile.sh ${TAG}g geom > $OUT/${TAG}_profile_geom.log 2>&1
+python profiles/pmc_summarize.py $OUT/${TAG}_pmc1 $OUT/${TAG}_pmc2 $OUT/${TAG}_pmc3 $OUT/${TAG}_pmc4 > $OUT/${TAG}_pmc_summary_qm9_x3.json
+python profiles/pmc_summarize.py $OUT/${TAG}g_pmc1 $OUT/${TAG}g_pmc2 $OUT/${TAG}g_pmc3 $OUT/${TAG}g_pmc4 > $OUT/${TAG}_pmc_summary_geom_x3.json
+cp $OUT/${TAG}_pmc_summary_qm9_x3.json $OUT/${TAG}_pmc_summary_geom_x3.json profiles/
+for d in ${TAG} ${TAG}g; do f=$(ls -t $OUT/${d}_stats/*/*kernel_stats.csv 2>/dev/null | head -1); [ -n "$f" ] && cp "$f" $OUT/${d}_kernel_stats.csv; done
+# raw counter dumps are large: keep the summaries and the per-kernel stats only
+rm -rf $OUT/${TAG}_pmc[1-4] $OUT/${TAG}g_pmc[1-4] $OUT/${TAG}_stats $OUT/${TAG}g_stats
+timeout 280 python bench.py --steps 100 --warmup 5 > $OUT/${TAG}_bench_qm9.json 2> $OUT/${TAG}_bench_qm9.err
+timeout 200 python bench.py --workload geom --steps 100 --warmup 5 --no-cpu-baseline > $OUT/${TAG}_bench_geom.json 2> $OUT/${TAG}_bench_geom.err
+timeout 200 python bench.py --lanes 1 --steps 100 --warmup 5 --no-cpu-baseline --no-other-configs > $OUT/${TAG}_bench_qm9_lanes1.json 2> $OUT/${TAG}_bench_lanes1.err
+timeout 100 python tests/gpu_time.py qm9 1024 > $OUT/${TAG}_phase_stamps_qm9.txt 2>&1
+tail -c 600 $OUT/${TAG}_bench_qm9.json; echo; tail -3 $OUT/${TAG}_profile_qm9.log
