@@ -1003,14 +1003,27 @@ __global__ __launch_bounds__(ET * 8) __attribute__((amdgpu_waves_per_eu(2, 2))) 
             const bool whole = (en - sb) == a.NCNT[node];
             float* dst = whole ? a.AGG + (size_t)node * GCDM_AGGW : a.PART + ((size_t)(e0 / ET) * 2 + (sb == 0 ? 0 : 1)) * GCDM_AGGW;
             if (un < GCDM_SG) {
+                // (4 edges per trip: the LDS reads of a trip are independent, the additions keep the edge order -- same bits as the plain loop)
                 v4f s = {0.f, 0.f, 0.f, 0.f};
-                for (int x = sb; x < en; ++x) s += XS4[un * ETP + x] * m_att[x];
+                const v4f* xp = XS4 + un * ETP;
+                int x = sb;
+                for (; x + 4 <= en; x += 4) {
+                    const v4f v0 = xp[x], v1 = xp[x + 1], v2 = xp[x + 2], v3 = xp[x + 3];
+                    const float a0 = m_att[x], a1 = m_att[x + 1], a2 = m_att[x + 2], a3 = m_att[x + 3];
+                    s += v0 * a0; s += v1 * a1; s += v2 * a2; s += v3 * a3;
+                }
+                for (; x < en; ++x) s += xp[x] * m_att[x];
                 *(v4f*)(dst + 4 * un) = s * (1.0f / X3_C);           // back to true units
             } else {
                 const int r = un - GCDM_SG, c = r / 3, comp = r - 3 * c;      // AGG column S + 3c + comp (reference flatten layout)
                 const float* vp = (const float*)(VV4 + (comp * 8 + (c >> 2)) * ETP) + (c & 3);
                 float s = 0.f;
-                for (int x = sb; x < en; ++x) s += vp[4 * x];
+                int x = sb;
+                for (; x + 4 <= en; x += 4) {
+                    const float v0 = vp[4 * x], v1 = vp[4 * x + 4], v2 = vp[4 * x + 8], v3 = vp[4 * x + 12];
+                    s += v0; s += v1; s += v2; s += v3;
+                }
+                for (; x < en; ++x) s += vp[4 * x];
                 dst[GCDM_S + r] = s;
             }
         }
