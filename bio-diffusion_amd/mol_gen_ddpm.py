@@ -24,7 +24,7 @@ from .config import cfg_get, dataset_info as _dataset_info
 from .gcpnet import GCPNetDynamics
 from .stability import CategoricalDistribution, check_molecular_stability_batch
 from .xyz import save_xyz_file
-from .variational_diffusion import EquivariantVariationalDiffusion
+from .variational_diffusion import EquivariantVariationalDiffusion, _segment_mean_sub
 
 
 class _Dummy:
@@ -137,6 +137,53 @@ class _MoleculeGenerationDDPM(nn.Module):
         if map_location is not None:
             model = model.to(map_location)
         return model
+
+    # ---- likelihood of a data batch (validation / test step), qm9_mol_gen_ddpm.py:184-277, 429-459 -------------------------------
+    @torch.inference_mode()
+    def forward(self, batch: Any, dtype: torch.dtype = torch.float32, t_int: Optional[torch.Tensor] = None,
+                noise: Optional[List[torch.Tensor]] = None) -> Tuple[torch.Tensor, Dict[str, Any]]:
+        """NLL per molecule and the batch means of the monitored loss terms, EVALUATION mode (two evaluations of the network; the training
+        objective needs the backward pass and is not built).  ``batch``: x, one_hot, charges, batch, mask and -- for a conditional model -- the
+        per-node ``props_context`` (the reference derives it from the training set's property statistics, qm9utils.prepare_context; that data
+        path is outside this package).  ``t_int`` / ``noise``: see EquivariantVariationalDiffusion.forward."""
+        if self.training:
+            raise NotImplementedError("training step: the backward pass of the network is not built (SURVEY 8 f4); call .eval()")
+        bi, mask = batch.batch, batch.mask
+        B = int(bi.max().item()) + 1
+        batch.x = _segment_mean_sub(batch.x, bi, B, mask)                         # centralize(..., edm=True): translation-invariant positions
+        batch.h = {"categorical": batch.one_hot, "integer": batch.charges}
+        ctx = getattr(batch, "props_context", None)
+        if self.condition_on_context:
+            if ctx is None:
+                raise ValueError("conditional model: batch.props_context (per node, normalised like the training set's) is required")
+            batch.props_context = ctx.type(dtype)
+        else:
+            batch.props_context = None
+        num_nodes = torch.zeros(B, dtype=torch.long, device=bi.device).index_add_(0, bi, mask.long())
+        batch.num_nodes_present, batch.num_graphs = num_nodes, B
+        (delta_log_px, error_t, SNR_weight, loss_0_x, loss_0_h, neg_log_const_0, kl_prior, log_pN, t_int, loss_info) = self.ddpm(
+            batch, return_loss_info=True, t_int=t_int, noise=noise)
+        loss_t = self.T * 0.5 * SNR_weight * error_t                             # evaluation always scores the variational bound (:246-250)
+        loss_0 = loss_0_x + loss_0_h + neg_log_const_0
+        nll = loss_t + loss_0 + kl_prior - delta_log_px - log_pN                  # normalisation of x undone, joint with the size prior (:253-262)
+        for name, v in (("loss_t", loss_t), ("SNR_weight", SNR_weight), ("loss_0", loss_0), ("kl_prior", kl_prior), ("delta_log_px", delta_log_px),
+                        ("neg_log_const_0", neg_log_const_0), ("log_pN", log_pN)):
+            loss_info[name] = v.mean(0)
+        return nll, loss_info
+
+    def step(self, batch: Any, **kw) -> Tuple[torch.Tensor, Dict[str, Any]]:
+        return self.forward(batch, **kw)
+
+    @torch.inference_mode()
+    def validation_step(self, batch: Any, batch_idx: int = 0, **kw) -> Dict[str, Any]:
+        """The metrics dictionary of the reference's validation / test step (without the Lightning logging around it)."""
+        nll, metrics = self.step(batch, **kw)
+        metrics["loss"] = nll.mean(0)
+        g = self.ddpm.gamma.gamma
+        metrics["log_SNR_max"], metrics["log_SNR_min"] = -g[0], -g[-1]            # -gamma(0), -gamma(1)
+        return metrics
+
+    test_step = validation_step
 
     @torch.inference_mode()
     def sample(self, num_samples: int, num_nodes: Optional[torch.Tensor] = None, node_mask: Optional[torch.Tensor] = None,

@@ -6,7 +6,8 @@ Mirror of the *sampling subset* of ``src/models/components/variational_diffusion
 ``sample_normal`` (:822-837), ``sample_p_zs_given_zt`` (:1204-1278), ``sample_p_xh_given_z0`` (:840-907) and
 ``mol_gen_sample`` (:1282-1412), plus ``NumNodesDistribution`` (src/models/__init__.py:264-308).
 RePaint inpainting (``inpaint``, :1582-1789) and the property-guided optimisation loop (``mol_gen_optimize``, :1416-1546) are built
-below on the same step / decode entry points; the training loss is out of scope.
+below on the same step / decode entry points.  ``forward`` (:948-1160) is built for EVALUATION mode -- the validation / test likelihood terms,
+two evaluations of the network per batch; the training objective needs the backward pass of the network and raises.
 
 Two ways to take a step:
   * ``sample_p_zs_given_zt`` -- the reference's method signature, torch ops on the device for the O(N) algebra
@@ -216,6 +217,133 @@ class EquivariantVariationalDiffusion(nn.Module):
         error = torch.sum(x, dim=0, keepdim=True).abs().max().item()
         rel_error = error / (largest_value + eps)
         assert rel_error < 1e-2, f"Mean is not zero, as relative_error {rel_error}"
+
+    # ---- likelihood terms of a data batch, evaluation mode (:371-397, 449-454, 493-557, 580-732, 910-1160) ---------------------
+    @staticmethod
+    def sum_node_features_except_batch(values, batch_index, num_graphs: Optional[int] = None):
+        B = int(batch_index.max().item()) + 1 if num_graphs is None else num_graphs
+        return torch.zeros(B, dtype=values.dtype, device=values.device).index_add_(0, batch_index, values.sum(-1))
+
+    @staticmethod
+    def gaussian_KL(q_mu_minus_p_mu_squared, q_sigma, p_sigma, d):
+        return d * torch.log(p_sigma / q_sigma) + 0.5 * (d * q_sigma ** 2 + q_mu_minus_p_mu_squared) / p_sigma ** 2 - 0.5 * d
+
+    @staticmethod
+    def cdf_standard_gaussian(x):
+        return 0.5 * (1.0 + torch.erf(x * (0.5 ** 0.5)))
+
+    def subspace_dimensionality(self, num_nodes):
+        return (num_nodes - 1) * self.num_x_dims
+
+    def delta_log_px(self, num_nodes):
+        return -self.subspace_dimensionality(num_nodes) * float(np.log(cfg_get(self.diffusion_cfg, "norm_values")[0]))
+
+    def log_pN(self, num_nodes):
+        return self.num_nodes_distribution.log_prob(num_nodes)
+
+    def normalize(self, x, h, node_mask, generate_x_only: bool = False):
+        nv, nb = cfg_get(self.diffusion_cfg, "norm_values"), cfg_get(self.diffusion_cfg, "norm_biases")
+        x = x / nv[0]
+        if generate_x_only:
+            return x, (h.float() - nb[1]) / nv[1]
+        m = node_mask.float()
+        h_cat = (h["categorical"].float() - nb[1]) / nv[1] * m.unsqueeze(-1)
+        h_int = (h["integer"].float() - nb[2]) / nv[2]
+        if self.include_charges:
+            h_int = h_int * m
+        return x, {"categorical": h_cat, "integer": h_int}
+
+    def compute_noised_representation(self, xh, batch_index, node_mask, gamma_t, generate_x_only: bool = False, eps: Optional[torch.Tensor] = None):
+        """z_t ~ q(z_t | x, h) (:910-931).  ``eps``: optional RAW standard-normal draws [N, 3 + F] (masked and CoM-projected here)."""
+        if eps is None:
+            eps = self.sample_combined_position_feature_noise(batch_index, node_mask, generate_x_only=generate_x_only)
+        else:
+            m = node_mask.float().unsqueeze(-1)
+            ex = _segment_mean_sub(eps[:, : self.num_x_dims] * m, batch_index, int(gamma_t.shape[0]), node_mask)
+            eps = torch.cat([ex, eps[:, self.num_x_dims:] * m], dim=-1)
+        return self.alpha(gamma_t, xh)[batch_index] * xh + self.sigma(gamma_t, xh)[batch_index] * eps, eps
+
+    def compute_kl_prior(self, xh, batch_index, node_mask, num_nodes, device=None, generate_x_only: bool = False):
+        B = len(num_nodes)
+        gamma_T = self.gamma(torch.ones((B, 1), device=xh.device))
+        mu_T = self.alpha(gamma_T, xh)[batch_index] * xh
+        sigma_T = self.sigma(gamma_T, xh).reshape(B)
+        one = torch.ones_like(sigma_T)
+        nx = self.num_x_dims
+        kl = self.gaussian_KL(self.sum_node_features_except_batch(mu_T[:, :nx] ** 2, batch_index, B), sigma_T, one, self.subspace_dimensionality(num_nodes))
+        if generate_x_only:
+            return kl
+        mu_h2 = self.sum_node_features_except_batch(mu_T[:, nx:] ** 2 * node_mask.float().unsqueeze(-1), batch_index, B)
+        return kl + self.gaussian_KL(mu_h2, sigma_T, one, 1)
+
+    def log_constants_p_x_given_z0(self, num_nodes, device=None):
+        B = len(num_nodes)
+        gamma_0 = self.gamma(torch.zeros((B, 1), device=self.gamma.gamma.device))
+        return self.subspace_dimensionality(num_nodes).to(gamma_0.device) * (-0.5 * gamma_0.view(B) - 0.5 * float(np.log(2 * np.pi)))
+
+    def log_pxh_given_z0_without_constants(self, h, z_0, eps, net_out, gamma_0, batch_index, node_mask, device=None,
+                                           generate_x_only: bool = False, epsilon: float = 1e-10):
+        nv, nb = cfg_get(self.diffusion_cfg, "norm_values"), cfg_get(self.diffusion_cfg, "norm_biases")
+        nx, B = self.num_x_dims, int(gamma_0.shape[0])
+        psum = lambda v: self.sum_node_features_except_batch(v, batch_index, B)
+        log_px = -0.5 * psum((eps[:, :nx] - net_out[:, :nx]) ** 2)
+        if generate_x_only:
+            return log_px, None
+        m = node_mask.float().unsqueeze(-1)
+        sigma_0 = self.sigma(gamma_0[batch_index], target_tensor=z_0)
+
+        def mass(centre, width):             # probability of [centre - 0.5, centre + 0.5] under N(0, width)
+            return torch.log(self.cdf_standard_gaussian((centre + 0.5) / width) - self.cdf_standard_gaussian((centre - 0.5) / width) + epsilon)
+
+        z_cat = z_0[:, nx:-1] if self.include_charges else z_0[:, nx:]
+        lp = mass(z_cat * nv[1] + nb[1] - 1.0, sigma_0 * nv[1])
+        lp = lp - torch.logsumexp(lp, dim=-1, keepdim=True)
+        log_ph = psum(lp * (h["categorical"] * nv[1] + nb[1]) * m)
+        if self.include_charges:
+            h_int = torch.round(h["integer"].reshape(h["integer"].shape[0], -1) * nv[2] + nb[2]).long()
+            log_ph = log_ph + psum(mass(h_int - (z_0[:, -1:] * nv[2] + nb[2]), sigma_0 * nv[2]) * m)
+        return log_px, log_ph
+
+    @torch.inference_mode()
+    def forward(self, batch, return_loss_info: bool = False, t_int: Optional[torch.Tensor] = None, noise: Optional[List[torch.Tensor]] = None):
+        """Loss / NLL terms of a data batch (:948-1160), EVALUATION mode: (delta_log_px, error_t, SNR_weight, loss_0_x, loss_0_h,
+        neg_log_constants, kl_prior, log_pN, t_int[, loss_info]), each per molecule.  ``batch``: x (CoM-free), h = {categorical, integer},
+        batch, mask, num_graphs, num_nodes_present, props_context (per node or None).  Extensions for reproducible evaluation: ``t_int``
+        [B, 1] instead of the torch.randint draw, ``noise`` = the two raw standard-normal draws [N, 3 + F] for z_t and z_0."""
+        if self.training:
+            raise NotImplementedError("the training objective needs the network's backward pass, which is not built (SURVEY 8 f4); call .eval() for the likelihood terms")
+        if self.diffusion_target != "atom_types_and_coords":
+            raise NotImplementedError(f"diffusion_target {self.diffusion_target!r}")
+        x, h = self.normalize(batch.x, batch.h, node_mask=batch.mask)
+        bi, B, num_nodes, mask = batch.batch, int(batch.num_graphs), batch.num_nodes_present, batch.mask
+        dev = x.device
+        if t_int is None:
+            t_int = torch.randint(1, self.T + 1, size=(B, 1), device=dev)            # lowest_t = 1 outside training (:988-994)
+        t_int = t_int.to(dev).reshape(B, 1)
+        s, t = (t_int - 1) / self.T, t_int / self.T
+        gamma_s, gamma_t = inflate_batch_array(self.gamma(s), x), inflate_batch_array(self.gamma(t), x)
+        xh = torch.cat([x, h["categorical"]] + ([h["integer"].reshape(-1, 1)] if self.include_charges else []), dim=-1)
+        z_t, eps_t = self.compute_noised_representation(xh, bi, mask, gamma_t, eps=None if noise is None else noise[0].to(dev))
+        _, net_out = self.dynamics_network(batch, z_t, t[bi], xh_self_cond=None)
+        error_t = self.sum_node_features_except_batch((eps_t - net_out) ** 2, bi, B)
+        SNR_weight = (self.SNR(gamma_s - gamma_t) - 1).squeeze(-1)
+        neg_log_constants = -self.log_constants_p_x_given_z0(num_nodes.to(dev), dev)
+        kl_prior = self.compute_kl_prior(xh, batch_index=bi, node_mask=mask, num_nodes=num_nodes.to(dev), device=dev)
+        # L_0 from its own draw at t = 0 (second evaluation of the network, :1107-1128)
+        t_zeros = torch.zeros_like(s)
+        gamma_0 = inflate_batch_array(self.gamma(t_zeros), x)
+        z_0, eps_0 = self.compute_noised_representation(xh, bi, mask, gamma_0, eps=None if noise is None else noise[1].to(dev))
+        _, net_out_0 = self.dynamics_network(batch, z_0, t_zeros[bi], xh_self_cond=None)
+        log_px, log_ph = self.log_pxh_given_z0_without_constants(h=h, z_0=z_0, eps=eps_0, net_out=net_out_0, gamma_0=gamma_0, batch_index=bi,
+                                                                 node_mask=mask, device=dev)
+        num_nodes = num_nodes.to(dev)
+        terms = (self.delta_log_px(num_nodes), error_t, SNR_weight, -log_px, -log_ph, neg_log_constants, kl_prior, self.log_pN(num_nodes), t_int.squeeze(-1))
+        if not return_loss_info:
+            return terms
+        cnt = torch.zeros(B, dtype=x.dtype, device=dev).index_add_(0, bi, torch.ones_like(bi, dtype=x.dtype)).clamp(min=1)
+        gmean = lambda v: (torch.zeros(B, dtype=x.dtype, device=dev).index_add_(0, bi, v) / cnt).mean()
+        info = {"eps_hat_x": gmean(net_out[:, : self.num_x_dims].abs().mean(-1)), "eps_hat_h": gmean(net_out[:, self.num_x_dims:].abs().mean(-1))}
+        return (*terms, info)
 
     # ---- one step with the reference's signature (:1204-1278) --------------------------------------
     @torch.inference_mode()

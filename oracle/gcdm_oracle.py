@@ -588,6 +588,106 @@ def inpaint(P: Params, cfg: OracleConfig, x: Tensor, h_cat: Tensor, h_int: Optio
 # ------------------------------------------------------------------------------------------------
 # algorithmic FLOP count -- used by bench.py for the roofline line
 # ------------------------------------------------------------------------------------------------
+# ------------------------------------------------------------------------------------------------
+# likelihood terms of a data batch in evaluation mode (validation / test NLL: two evaluations of the network)
+# ------------------------------------------------------------------------------------------------
+def _per_graph_sum(v: Tensor, batch_index: Tensor, B: int) -> Tensor:
+    """sum_node_features_except_batch, variational_diffusion.py:449-454."""
+    return torch.zeros(B, dtype=v.dtype).index_add_(0, batch_index, v.sum(-1))
+
+
+def _gaussian_kl(mu2: Tensor, q_sigma: Tensor, d) -> Tensor:
+    """gaussian_KL against N(0, 1), variational_diffusion.py:371-391."""
+    return d * torch.log(1.0 / q_sigma) + 0.5 * (d * q_sigma ** 2 + mu2) - 0.5 * d
+
+
+def _std_normal_cdf(x: Tensor) -> Tensor:
+    """variational_diffusion.py:395-396."""
+    return 0.5 * (1.0 + torch.erf(x / math.sqrt(2)))
+
+
+def log_pxh_given_z0(cfg: OracleConfig, gam0: Tensor, h_cat_n: Tensor, h_int_n: Optional[Tensor], z0: Tensor, eps: Tensor, net_out: Tensor,
+                     batch_index: Tensor, B: int, mask: Tensor, epsilon: float = 1e-10) -> Tuple[Tensor, Tensor]:
+    """log_pxh_given_z0_without_constants, variational_diffusion.py:598-699.  `h_cat_n` / `h_int_n`: NORMALISED one-hot / integer features."""
+    nv, nb = cfg.norm_values, cfg.norm_biases
+    nt = cfg.num_atom_types
+    m = mask.to(z0.dtype)[:, None]
+    log_px = -0.5 * _per_graph_sum((eps[:, :3] - net_out[:, :3]) ** 2, batch_index, B)
+    sigma0 = torch.sqrt(torch.sigmoid(gam0))[batch_index][:, None]
+    # categorical part: probability mass of [0.5, 1.5] under N(estimate, sigma0 * norm), normalised over the classes (:672-684)
+    est_cat = z0[:, 3:3 + nt] * nv[1] + nb[1] - 1.0
+    s_cat = sigma0 * nv[1]
+    lp = torch.log(_std_normal_cdf((est_cat + 0.5) / s_cat) - _std_normal_cdf((est_cat - 0.5) / s_cat) + epsilon)
+    lp = lp - torch.logsumexp(lp, dim=-1, keepdim=True)
+    onehot = h_cat_n * nv[1] + nb[1]
+    log_ph = _per_graph_sum(lp * onehot * m, batch_index, B)
+    if cfg.include_charges:              # integer part: mass of [-0.5, 0.5] around (true - estimate) (:655-668)
+        h_int = torch.round(h_int_n.reshape(-1, 1) * nv[2] + nb[2]).long()
+        centred = h_int - (z0[:, -1:] * nv[2] + nb[2])
+        s_int = sigma0 * nv[2]
+        li = torch.log(_std_normal_cdf((centred + 0.5) / s_int) - _std_normal_cdf((centred - 0.5) / s_int) + epsilon)
+        log_ph = log_ph + _per_graph_sum(li * m, batch_index, B)
+    return log_px, log_ph
+
+
+def nll_terms(P: Params, cfg: OracleConfig, x: Tensor, one_hot: Tensor, charges: Optional[Tensor], num_nodes: Tensor, t_int: Tensor, noise,
+              context: Optional[Tensor] = None, log_pN: Optional[Tensor] = None, dtype=torch.float32) -> Dict[str, Tensor]:
+    """EquivariantVariationalDiffusion.atom_types_and_coords_forward in EVALUATION mode (variational_diffusion.py:955-1160; helpers :493-557,
+    580-596, 702-732, 910-931, 943-945): the per-molecule terms of the variational bound.  `x` CoM-free raw positions, `one_hot` / `charges` raw
+    features, `t_int` [B] the drawn timesteps (the reference draws them with torch.randint(1, T + 1)), `noise(n, k)` the standard-normal source in the
+    reference's call order (x-part, h-part for z_t, then the same for z_0), `context` per MOLECULE."""
+    B, T = len(num_nodes), cfg.num_timesteps
+    bi = num_nodes_to_batch_index(num_nodes)
+    mask = torch.ones(len(bi), dtype=torch.bool)
+    nv, nb = cfg.norm_values, cfg.norm_biases
+    gam = gamma_table(cfg).to(dtype)
+    x = x.to(dtype) / nv[0]
+    h_cat = (one_hot.to(dtype) - nb[1]) / nv[1]
+    h_int = ((charges.to(dtype) - nb[2]) / nv[2]) if cfg.include_charges else None
+    xh = torch.cat([x, h_cat] + ([h_int.reshape(-1, 1)] if cfg.include_charges else []), dim=-1)
+    Fh = cfg.num_node_scalar_features
+    dof = ((num_nodes - 1) * 3).to(dtype)
+    out: Dict[str, Tensor] = {"delta_log_px": -dof * math.log(nv[0])}
+    t = t_int.to(dtype) / T
+    s = (t_int - 1).to(dtype) / T
+    g_t, g_s = gamma_at(gam, t, T), gamma_at(gam, s, T)
+    ctx = None if context is None else context.to(dtype)[bi]
+
+    def noised(g):                        # compute_noised_representation, :910-931
+        eps = sample_combined_noise(noise, bi, B, mask, Fh, dtype)
+        a, sg = torch.sqrt(torch.sigmoid(-g))[bi][:, None], torch.sqrt(torch.sigmoid(g))[bi][:, None]
+        return a * xh + sg * eps, eps
+
+    z_t, eps_t = noised(g_t)
+    net_t = dynamics_forward(P, cfg, z_t, t[bi][:, None], bi, None, ctx)
+    out["error_t"] = _per_graph_sum((eps_t - net_t) ** 2, bi, B)
+    out["SNR_weight"] = torch.exp(-(g_s - g_t)) - 1.0
+    g0 = gamma_at(gam, torch.zeros(B, dtype=dtype), T)
+    out["neg_log_constants"] = -(dof * (-0.5 * g0 - 0.5 * math.log(2 * math.pi)))
+    # KL(q(z_T | x) || N(0, 1)), :501-557
+    g_T = gamma_at(gam, torch.ones(B, dtype=dtype), T)
+    mu_T = torch.sqrt(torch.sigmoid(-g_T))[bi][:, None] * xh
+    sig_T = torch.sqrt(torch.sigmoid(g_T))
+    out["kl_prior"] = _gaussian_kl(_per_graph_sum(mu_T[:, :3] ** 2, bi, B), sig_T, dof) + _gaussian_kl(_per_graph_sum(mu_T[:, 3:] ** 2, bi, B), sig_T, 1)
+    # L_0 from a separate draw at t = 0 (:1107-1128)
+    z_0, eps_0 = noised(g0)
+    net_0 = dynamics_forward(P, cfg, z_0, torch.zeros(len(bi), 1, dtype=dtype), bi, None, ctx)
+    lx, lh = log_pxh_given_z0(cfg, g0, h_cat, h_int, z_0, eps_0, net_0, bi, B, mask)
+    out["loss_0_x"], out["loss_0_h"] = -lx, -lh
+    if log_pN is not None:
+        out["log_pN"] = log_pN.to(dtype)
+    out["eps_hat_x"] = (torch.zeros(B, dtype=dtype).index_add_(0, bi, net_t[:, :3].abs().mean(-1)) / num_nodes.to(dtype)).mean()
+    out["eps_hat_h"] = (torch.zeros(B, dtype=dtype).index_add_(0, bi, net_t[:, 3:].abs().mean(-1)) / num_nodes.to(dtype)).mean()
+    return out
+
+
+def nll_from_terms(terms: Dict[str, Tensor], T: int) -> Tensor:
+    """The evaluation branch of the module's forward, qm9_mol_gen_ddpm.py:246-262: NLL per molecule from the terms above."""
+    loss_t = T * 0.5 * terms["SNR_weight"] * terms["error_t"]
+    loss_0 = terms["loss_0_x"] + terms["loss_0_h"] + terms["neg_log_constants"]
+    return loss_t + loss_0 + terms["kl_prior"] - terms["delta_log_px"] - terms["log_pN"]
+
+
 def _gcp2_flops(M, S_in, V_in, S_out, V_out, bn, ff=False):
     H = V_in // bn if bn > 1 else max(V_in, V_out)
     f = 3 * V_in * H + 9 * V_in + 27 + (S_in + H + 9) * S_out

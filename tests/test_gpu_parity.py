@@ -945,3 +945,58 @@ def test_full_size_properties(case, B, n, mode):
         assert (sub[n:2 * n] - out[b * n:(b + 1) * n]).abs().max().item() <= TOL * scale
         ref = O.dynamics_forward(W, _ocfg(case), xh[lo:hi], t[lo:hi], bi[lo:hi] - (b - 1), None, cs)
         assert (sub - ref).abs().max().item() <= TOL * scale
+
+
+NLL_TERMS = ("delta_log_px", "error_t", "SNR_weight", "loss_0_x", "loss_0_h", "neg_log_constants", "kl_prior", "log_pN")
+
+
+@pytest.mark.parametrize("mode", MODES)
+@pytest.mark.parametrize("case", ["qm9", "qm9cond", "geom"])
+def test_nll_terms_match_reference_golden(case, mode, golden_dir):
+    """Evaluation-mode likelihood terms (EquivariantVariationalDiffusion.forward, variational_diffusion.py:948-1160: two evaluations of the
+    network per batch) and the NLL the module assembles from them (qm9_mol_gen_ddpm.py:184-272) against what the REFERENCE's own forward
+    returned on the same batch, timesteps and noise tape (tests/golden/nll_full_*.npz), both matrix modes.  Bar per term: 4 x the reference's
+    own fp32-vs-fp64 gap + 1e-4 x its magnitude."""
+    g = np.load(os.path.join(golden_dir, f"nll_full_{case}.npz"))
+    d = _dims(case)
+    net, W, cfgs = _net(case, seed=int(g["weight_seed"]), mode=mode)
+    ds = {"qm9": "qm9", "qm9cond": "qm9_second_half", "geom": "geom"}[case]       # the conditional experiment trains on the second half of QM9
+    ddpm = pkg.EquivariantVariationalDiffusion(net, cfgs["diffusion_cfg"], cfgs["dataloader_cfg"], pkg.dataset_info(ds)).cuda().eval()
+    dev = torch.device("cuda")
+    nn_ = torch.tensor(g["num_nodes"])
+    bi = O.num_nodes_to_batch_index(nn_).to(dev)
+    N, F = int(nn_.sum()), synth.dims_feat(d)
+    tape = O.TapeNoise(int(g["noise_seed"]))
+    noise = [torch.cat((tape(N, 3), tape(N, F)), dim=-1) for _ in range(2)]          # the reference's call order: x-part, h-part; z_t then z_0
+    ctx = torch.tensor(g["ctx"])[bi.cpu()].to(dev) if "ctx" in g.files else None
+
+    def batch():
+        return pkg.config.AttrDict(x=torch.tensor(g["x"]).to(dev), one_hot=torch.tensor(g["one_hot"]).to(dev), charges=torch.tensor(g["charges"]).to(dev),
+                                   batch=bi, mask=torch.ones(N, dtype=torch.bool, device=dev), props_context=ctx)
+
+    b = batch()
+    b.h = {"categorical": b.one_hot, "integer": b.charges}
+    b.num_graphs, b.num_nodes_present = len(nn_), nn_.to(dev)
+    out = ddpm(b, return_loss_info=True, t_int=torch.tensor(g["t_int"]).view(-1, 1), noise=noise)
+    assert (net.read_flags() & pkg._native.FLAG_F16_RANGE) == 0
+    for name, got in zip(NLL_TERMS, out[:8]):
+        w32, w64 = torch.tensor(g[f"{name}_32"]).double(), torch.tensor(g[f"{name}_64"]).double()
+        bar = 4 * (w32 - w64).abs() + 1e-4 * w64.abs().clamp(min=1.0)
+        err = (got.double().cpu() - w64).abs()
+        assert (err <= bar).all(), (name, err.tolist(), bar.tolist())
+    assert torch.equal(out[8].cpu(), torch.tensor(g["t_int"]))
+    for k in ("eps_hat_x", "eps_hat_h"):
+        assert abs(out[9][k].item() - float(g[f"{k}_64"])) <= 1e-4 * max(1.0, abs(float(g[f"{k}_64"])))
+    # the module-level forward: NLL per molecule from the same terms
+    cls = pkg.GEOMMoleculeGenerationDDPM if case == "geom" else pkg.QM9MoleculeGenerationDDPM
+    model = cls(**cfgs)
+    model.ddpm.dynamics_network.load_state_dict(W)
+    model = model.cuda().eval()
+    model.ddpm.dynamics_network._ensure_handle(dev)
+    model.ddpm.dynamics_network.set_mfma_mode(mode)
+    nll, info = model(batch(), t_int=torch.tensor(g["t_int"]).view(-1, 1), noise=noise)
+    want = O.nll_from_terms({k: torch.tensor(g[f"{k}_64"]).double() for k in NLL_TERMS}, int(cfgs["diffusion_cfg"]["num_timesteps"]))
+    assert (nll.double().cpu() - want).abs().max().item() <= 2e-4 * want.abs().max().item()
+    assert abs(info["kl_prior"].item() - float(torch.tensor(g["kl_prior_64"]).mean())) <= 1e-4 * max(1.0, abs(float(torch.tensor(g["kl_prior_64"]).mean())))
+    metrics = model.validation_step(batch(), t_int=torch.tensor(g["t_int"]).view(-1, 1), noise=noise)
+    assert abs(metrics["loss"].item() - want.mean().item()) <= 2e-4 * abs(want.mean().item()) and metrics["log_SNR_max"] > metrics["log_SNR_min"]

@@ -2,6 +2,7 @@
 and a NumPy emulation of the MFMA operand mapping that the weight packing relies on."""
 import ctypes
 import importlib
+import math
 import os
 import re
 
@@ -375,3 +376,64 @@ def test_config_tree_refuses_gcp_v1(tmp_path):
     yaml.safe_dump(d, open(path, "w"))
     with pytest.raises(NotImplementedError, match="selected_GCP"):
         pkg.load_cfg_tree(str(dst), "qm9", ())
+
+
+def test_likelihood_forward_is_evaluation_only():
+    """EquivariantVariationalDiffusion.forward / the module's forward are built for evaluation mode (validation / test NLL); in training mode
+    they raise instead of returning a loss nobody can back-propagate (no CPU fallback, no silent approximation)."""
+    cfgs = pkg.default_cfgs("qm9")
+    model = pkg.QM9MoleculeGenerationDDPM(**cfgs)
+    batch = pkg.config.AttrDict(x=torch.zeros(3, 3), one_hot=torch.zeros(3, 5), charges=torch.zeros(3), batch=torch.zeros(3, dtype=torch.long),
+                                mask=torch.ones(3, dtype=torch.bool))
+    model.train()
+    with pytest.raises(NotImplementedError):
+        model(batch)
+    with pytest.raises(NotImplementedError):
+        model.ddpm(batch)
+    # the pieces that need no network: schedule-only terms on the CPU
+    ddpm = model.ddpm.eval()
+    nn_ = torch.tensor([5, 19])
+    assert torch.allclose(ddpm.delta_log_px(nn_), torch.zeros(2))                                   # norm_values[0] = 1
+    assert ddpm.subspace_dimensionality(nn_).tolist() == [12, 54]
+    c = ddpm.log_constants_p_x_given_z0(nn_)
+    g0 = ddpm.gamma.gamma[0].item()
+    assert torch.allclose(c, torch.tensor([12.0, 54.0]) * (-0.5 * g0 - 0.5 * math.log(2 * math.pi)), rtol=1e-6)
+    assert torch.isfinite(ddpm.log_pN(nn_)).all()
+
+
+@pytest.mark.parametrize("case", ["qm9", "qm9cond", "geom"])
+def test_likelihood_algebra_of_the_mirror_matches_reference_golden(case):
+    """The host-side algebra of EquivariantVariationalDiffusion.forward and of the module's forward (everything but the two network
+    evaluations, which the CPU oracle stands in for HERE ONLY) against the terms the reference returned (tests/golden/nll_full_*.npz)."""
+    from oracle import gcdm_oracle as O
+    g = np.load(os.path.join(ROOT, "tests", "golden", f"nll_full_{case}.npz"))
+    d = synth.DATASET_DIMS[case]
+    P = synth.make_weights(synth.dynamics_shapes(d["S"], d["V"], d["Se"], d["Ve"], d["L"], synth.dims_h_in(d)), seed=int(g["weight_seed"]))
+    ocfg = O.OracleConfig(num_atom_types=d["num_atom_types"], include_charges=d["include_charges"], num_context=d["n_ctx"], num_layers=d["L"],
+                          norm_values=d["norm_values"])
+
+    class OracleNet(torch.nn.Module):
+        def forward(self, batch, xh, t, x_self_cond=None, xh_self_cond=None):
+            return None, O.dynamics_forward(P, ocfg, xh, t, batch.batch, None, batch.props_context)
+
+    ds = "geom" if case == "geom" else "qm9"
+    cfgs = pkg.default_cfgs(ds, ("alpha",) if d["n_ctx"] else ())
+    cls = pkg.GEOMMoleculeGenerationDDPM if case == "geom" else pkg.QM9MoleculeGenerationDDPM
+    model = cls(**cfgs).eval()
+    model.ddpm.dynamics_network = OracleNet()
+    nn_ = torch.tensor(g["num_nodes"])
+    bi = O.num_nodes_to_batch_index(nn_)
+    N, F = int(nn_.sum()), synth.dims_feat(d)
+    tape = O.TapeNoise(int(g["noise_seed"]))
+    noise = [torch.cat((tape(N, 3), tape(N, F)), dim=-1) for _ in range(2)]
+    ctx = torch.tensor(g["ctx"])[bi] if "ctx" in g.files else None
+    batch = pkg.config.AttrDict(x=torch.tensor(g["x"]), one_hot=torch.tensor(g["one_hot"]), charges=torch.tensor(g["charges"]), batch=bi,
+                                mask=torch.ones(N, dtype=torch.bool), props_context=ctx)
+    nll, info = model(batch, t_int=torch.tensor(g["t_int"]).view(-1, 1), noise=noise)
+    names = ("delta_log_px", "error_t", "SNR_weight", "loss_0_x", "loss_0_h", "neg_log_constants", "kl_prior", "log_pN")
+    want = O.nll_from_terms({k: torch.tensor(g[f"{k}_32"]).double() for k in names}, int(cfgs["diffusion_cfg"]["num_timesteps"]))
+    assert (nll.double() - want).abs().max().item() <= 5e-5 * want.abs().max().item()
+    for k in ("kl_prior", "delta_log_px", "log_pN", "SNR_weight"):
+        assert abs(info[k].item() - float(torch.tensor(g[f"{k}_32"]).double().mean())) <= 1e-5 * max(1.0, abs(float(torch.tensor(g[f"{k}_32"]).double().mean())))
+    for k in ("eps_hat_x", "eps_hat_h"):
+        assert abs(info[k].item() - float(g[f"{k}_32"])) <= 1e-5

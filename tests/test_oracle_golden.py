@@ -302,3 +302,30 @@ def test_oracle_masked_nodes_match_reference_golden(case, golden_dir):
     assert (out - g["out32"]).abs().max().item() <= 2e-5
     assert (out - g["out64"]).abs().max().item() <= 1e-4
     assert out[~mask][:, :3].abs().max().item() == 0.0
+
+
+NLL_TERMS = ("delta_log_px", "error_t", "SNR_weight", "loss_0_x", "loss_0_h", "neg_log_constants", "kl_prior")
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_nll_terms_match_reference_golden(golden_dir, case):
+    """Evaluation-mode likelihood terms (variational_diffusion.py:948-1160; two evaluations of the network per batch) vs the terms the
+    REFERENCE's own forward returned on the same batch, timesteps and noise tape (tests/golden/make_nll_golden.py), in fp32 and fp64, and the
+    NLL assembled from them (qm9_mol_gen_ddpm.py:246-262)."""
+    g = load(golden_dir, f"nll_full_{case}")
+    d = synth.DATASET_DIMS[case]
+    P = synth.make_weights(synth.dynamics_shapes(d["S"], d["V"], d["Se"], d["Ve"], d["L"], synth.dims_h_in(d)), seed=int(g["weight_seed"]))
+    cfg = cfg_for(case, d["L"])
+    for dtype, tag, tol in ((torch.float32, "32", 2e-5), (torch.float64, "64", 1e-9)):
+        Pd = {k: v.to(dtype) for k, v in P.items()}
+        out = O.nll_terms(Pd, cfg, g["x"], g["one_hot"], g["charges"] if d["include_charges"] else None, g["num_nodes"], g["t_int"],
+                          O.TapeNoise(int(g["noise_seed"])), context=g.get("ctx"), log_pN=g[f"log_pN_{tag}"], dtype=dtype)
+        for name in NLL_TERMS + ("eps_hat_x", "eps_hat_h"):
+            want = g[f"{name}_{tag}"].to(torch.float64)
+            err = (out[name].to(torch.float64) - want).abs().max().item()
+            assert err <= tol * max(1.0, want.abs().max().item()), (name, tag, err)
+        ref_terms = {k: g[f"{k}_{tag}"].to(torch.float64) for k in NLL_TERMS + ("log_pN",)}
+        nll = O.nll_from_terms({k: v.to(torch.float64) for k, v in out.items()}, cfg.num_timesteps)
+        want = O.nll_from_terms(ref_terms, cfg.num_timesteps)
+        assert (nll - want).abs().max().item() <= 10 * tol * max(1.0, want.abs().max().item())
+    assert torch.isfinite(want).all() and want.abs().max().item() > 10.0          # the fixture is not degenerate
