@@ -18,7 +18,7 @@ one launch per interaction layer) timed with HIP events inside the library on th
 have changed since (``pmc_stale``).  ``cpu_baseline`` times the CPU oracle (torch, 32 threads) on the BASELINE.json
 configs[0] shape (64 molecules x 19 atoms, >= 10 steps).  Extra fields at N=1: ``modes`` (both matrix modes -- the default
 f16x3 split precision and exact fp32 MFMA -- measured the same way, each with its roofline), ``other_configs``
-(configs[2] alpha-conditional QM9 and configs[3] GEOM-Drugs, short runs), ``plug_point_1`` (the reference's unchanged
+(configs[2] alpha-conditional QM9 and configs[3] GEOM-Drugs, short runs), ``nll_evaluation`` (one validation batch: the evaluation-mode likelihood terms), ``plug_point_1`` (the reference's unchanged
 per-step method on top of GCPNetDynamics.forward).
 """
 from __future__ import annotations
@@ -387,7 +387,7 @@ def main():
 
     # plug point 1: what the reference's UNCHANGED mol_gen_sample loop costs after the one-line registry swap -- per step one
     # reference-signature sample_p_zs_given_zt (torch algebra on the device + GCPNetDynamics.forward, deferred range guard: no host sync)
-    plug1_ms = None
+    plug1_ms = nll_ms = None
     if world == 1 and args.streams == 1:
         ddpm.to(dev)                                   # the reference-signature method does its schedule algebra with torch ops on the device
         bidx = torch.repeat_interleave(torch.arange(B, device=dev), num_nodes.to(dev).long())
@@ -406,6 +406,23 @@ def main():
             zz = plug_step(890 - i)
         torch.cuda.synchronize(dev)
         plug1_ms = (time.perf_counter() - tp) / 12 * 1e3
+        dyn.check_deferred_flags()
+        # one validation / test batch = the likelihood terms in evaluation mode (two network evaluations + O(N) torch algebra)
+        gq = torch.Generator().manual_seed(5)
+        types_q = torch.randint(0, d["num_atom_types"], (N,), generator=gq)
+        vb = pkg.config.AttrDict(x=z[:, :3].clone(), batch=bidx, mask=nmask, props_context=None if ctx_b1 is None else ctx_b1[bidx],
+                                 h={"categorical": torch.nn.functional.one_hot(types_q, d["num_atom_types"]).float().to(dev),
+                                    "integer": (torch.randint(1, 10, (N,), generator=gq).float().to(dev) if d["include_charges"] else torch.zeros((N, 0), device=dev))},
+                                 num_graphs=B, num_nodes_present=num_nodes.to(dev).long())
+        ddpm.eval()
+        for _ in range(2):
+            ddpm(vb)
+        torch.cuda.synchronize(dev)
+        tq = time.perf_counter()
+        for _ in range(6):
+            ddpm(vb)
+        torch.cuda.synchronize(dev)
+        nll_ms = (time.perf_counter() - tq) / 6 * 1e3
         dyn.check_deferred_flags()
 
     # finish the sample properly once (decode) so the path is exercised end to end, and gather like a real run would
@@ -482,6 +499,9 @@ def main():
         res["plug_point_1"] = {"ms_per_step": plug1_ms, "value": None if plug1_ms is None else world * B / (plug1_ms * 1e-3 * NET_EVALS_PER_SAMPLE), "unit": "molecules/s",
                                "what": "reference-signature sample_p_zs_given_zt per step (torch algebra + GCPNetDynamics.forward on one handle, no per-call host sync): "
                                        "the cost of the reference's unchanged sampling loop after the dynamics_networks registry swap"}
+        res["nll_evaluation"] = {"ms_per_batch": nll_ms, "value": None if nll_ms is None else B / (nll_ms * 1e-3), "unit": "molecules/s",
+                                 "what": "likelihood terms of one validation / test batch of the headline shape (EquivariantVariationalDiffusion.forward, evaluation mode: "
+                                         "two network evaluations on one handle + the O(N) algebra of the terms in torch, incl. the host-side size-prior lookup)"}
         res["roofline"]["pmc_stale"] = pmc.get("stale")
         res["roofline"]["pmc_collected_at_commit"] = pmc.get("collected_at_commit")
         if other_configs is not None:

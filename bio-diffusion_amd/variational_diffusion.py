@@ -139,7 +139,7 @@ class NumNodesDistribution(nn.Module):
         return self.num_nodes[idx.to(self.num_nodes.device)]
 
     def log_prob(self, batch_n_nodes: torch.Tensor) -> torch.Tensor:
-        idcs = torch.tensor([self.keys[i.item()] for i in batch_n_nodes], device=batch_n_nodes.device)
+        idcs = torch.tensor([self.keys[n] for n in batch_n_nodes.tolist()], device=batch_n_nodes.device)        # one host copy, not one per molecule
         return torch.log(self.prob + self.eps)[idcs]
 
 
