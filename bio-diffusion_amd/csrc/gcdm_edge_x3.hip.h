@@ -73,11 +73,14 @@ __device__ __forceinline__ void split16x2(float x0, float x1, h2& hi, h2& lo) {
 }
 
 // Registers written by the inline-asm splits above and consumed DIRECTLY by an MFMA pass through x3_settle first.  The last writer of
-// such a register is a partial (16-bit, op_sel) write; for the consumer of an inline-asm definition the compiler's hazard recognizer
-// leaves one wait state, and with a v_fma_mixhi_f16 issued right in front of the MFMA that reads its destination the MFMA was measured
-// to pick up the OLD value in its first lane groups (edge-embedding kernel: 16 of a wave's 32 edges wrong, in a few of 1 300 waves, on
-// different waves from run to run; tests/gpu_ragged_diag.py).  The asm below is a data-dependent fence: two more wait states between
-// the splits and the MFMA, whatever the scheduler does around them.
+// such a register is a 16-bit partial write (op_sel destination).  On gfx950 an MFMA issued with NO wait state behind such a write reads
+// the old register -- always when the two are back to back, in ~0.1 % of the cases when another MFMA was issued just before the write
+// (tools/mfma_partial_write_hazard.hip); one wait state is enough there, and one is what the compiler inserts between an inline-asm
+// definition and its consumer.  The edge-embedding kernel nevertheless produced stale B columns (16 of a wave's 32 edges, in a few of
+// 1 300 waves, different waves from run to run, only in waves of the grid's second round) while the compiler interleaved the splits of
+// one k-block with the MFMAs of the previous one; the exact instruction pair was not isolated (tests/gpu_ragged_diag.py: 16 s_nops
+// around the MFMAs without a data dependence do not help, the compiler-generated split and this fence both do).  The fence is a
+// data dependence: every split of an operand is complete, plus two wait states, before the first MFMA that reads it.
 __device__ __forceinline__ void x3_settle(h8& a, h8& b) { asm("s_nop 1" : "+v"(a), "+v"(b)); }
 __device__ __forceinline__ void x3_settle(h8& a) { asm("s_nop 1" : "+v"(a)); }
 
