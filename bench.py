@@ -113,14 +113,38 @@ def cpu_baseline(dataset, cond, dims, seconds_budget=25.0):
                       f"{steps} denoise steps timed, extrapolated x{NET_EVALS_PER_SAMPLE}"}
 
 
-def csrc_sha16():
-    """Fingerprint of the device/host sources the library is built from: a PMC summary collected on other sources is stale."""
+def strip_cxx_comments(text):
+    """Source text without // and /* */ comments and without blank / whitespace-only differences (string literals are respected)."""
+    out, i, n = [], 0, len(text)
+    while i < n:
+        c = text[i]
+        if c == '"' or c == "'":
+            j = i + 1
+            while j < n and text[j] != c:
+                j += 2 if text[j] == "\\" else 1
+            out.append(text[i:j + 1])
+            i = j + 1
+        elif text.startswith("//", i):
+            while i < n and text[i] != "\n":
+                i += 1
+        elif text.startswith("/*", i):
+            i = text.find("*/", i + 2)
+            i = n if i < 0 else i + 2
+        else:
+            out.append(c)
+            i += 1
+    return "\n".join(ln.rstrip() for ln in "".join(out).splitlines() if ln.strip())
+
+
+def csrc_sha16(directory=None):
+    """Fingerprint of the device/host sources the library is built from (comments and blank lines excluded: they do not change the
+    kernels): a PMC summary collected on other sources is stale."""
     import hashlib
     hsh = hashlib.sha256()
-    d = os.path.join(ROOT, "bio-diffusion_amd", "csrc")
+    d = directory or os.path.join(ROOT, "bio-diffusion_amd", "csrc")
     for f in sorted(os.listdir(d)):
-        with open(os.path.join(d, f), "rb") as fh:
-            hsh.update(f.encode() + b"\0" + fh.read())
+        with open(os.path.join(d, f), "r", encoding="utf-8", errors="replace") as fh:
+            hsh.update(f.encode() + b"\0" + strip_cxx_comments(fh.read()).encode())
     return hsh.hexdigest()[:16]
 
 

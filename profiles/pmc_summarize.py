@@ -34,19 +34,15 @@ for k, cs in agg.items():
         e["l2_hit_rate"] = m["TCC_HIT_sum"] / (m["TCC_HIT_sum"] + m["TCC_MISS_sum"])
     out[k] = e
 # provenance: bench.py nulls `traffic` / `mfma_busy_frac` when the kernels have changed since these counters were collected
-import hashlib
 import os
 import subprocess
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-hsh = hashlib.sha256()
-cs = os.path.join(root, "bio-diffusion_amd", "csrc")
-for f in sorted(os.listdir(cs)):
-    with open(os.path.join(cs, f), "rb") as fh:
-        hsh.update(f.encode() + b"\0" + fh.read())
+sys.path.insert(0, root)
+import bench          # the fingerprint bench.py compares against: csrc/ with comments and blank lines excluded
 try:
     head = subprocess.run(["git", "-C", root, "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip() or os.environ.get("GCDM_GIT_HEAD")
 except Exception:
     head = os.environ.get("GCDM_GIT_HEAD")
-out["_meta"] = {"csrc_sha16": hsh.hexdigest()[:16], "git_head": head, "note": "git_head = the commit checked out when the counters were summarised "
+out["_meta"] = {"csrc_sha16": bench.csrc_sha16(), "git_head": head, "note": "git_head = the commit checked out when the counters were summarised "
                 "(on the GPU box there is no .git: the summary is then re-stamped in the build container from GCDM_GIT_HEAD)"}
 json.dump(out, sys.stdout, indent=1)

@@ -437,3 +437,14 @@ def test_likelihood_algebra_of_the_mirror_matches_reference_golden(case):
         assert abs(info[k].item() - float(torch.tensor(g[f"{k}_32"]).double().mean())) <= 1e-5 * max(1.0, abs(float(torch.tensor(g[f"{k}_32"]).double().mean())))
     for k in ("eps_hat_x", "eps_hat_h"):
         assert abs(info[k].item() - float(g[f"{k}_32"])) <= 1e-5
+
+
+def test_source_fingerprint_ignores_comments_only():
+    """bench.csrc_sha16 (the staleness stamp of the committed PMC summaries) is blind to comments and blank lines and to nothing else."""
+    import bench
+    a = 'int f(int x) { return x + 1; }   // add one\n/* block\n comment */\nconst char* s = "// not a comment";\n\n'
+    b = 'int f(int x) { return x + 1; }\nconst char* s = "// not a comment";\n'
+    c = 'int f(int x) { return x + 2; }\nconst char* s = "// not a comment";\n'
+    assert bench.strip_cxx_comments(a) == bench.strip_cxx_comments(b) != bench.strip_cxx_comments(c)
+    assert '"// not a comment"' in bench.strip_cxx_comments(a)
+    assert len(bench.csrc_sha16()) == 16
