@@ -448,3 +448,22 @@ def test_source_fingerprint_ignores_comments_only():
     assert bench.strip_cxx_comments(a) == bench.strip_cxx_comments(b) != bench.strip_cxx_comments(c)
     assert '"// not a comment"' in bench.strip_cxx_comments(a)
     assert len(bench.csrc_sha16()) == 16
+
+
+def test_no_mfma_directly_behind_a_partial_write_of_its_source():
+    """Static check of the compiled gfx950 kernels (no GPU): an MFMA issued with no wait state behind a v_fma_mix{lo,hi}_f16 write of one
+    of its source registers reads the old register on gfx950 (tools/mfma_partial_write_hazard.hip); the compiler is expected to separate the
+    two -- this fails the moment a build comes out without the separation."""
+    import shutil
+    sys_path = os.path.join(ROOT, "tools")
+    import sys
+    sys.path.insert(0, sys_path)
+    import isa_census
+    fake = ("_Z1kv:                                  ; @_Z1kv\n\tv_fma_mixhi_f16 v17, v37, s6, v22 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n"
+            "\tv_mfma_f32_32x32x16_f16 a[16:31], v[12:15], v[16:19], a[16:31]\n\ts_endpgm\n\t.end_amdhsa_kernel\n")
+    assert len(isa_census.lint_partial_writes(fake)) == 1
+    assert isa_census.lint_partial_writes(fake.replace("\tv_mfma", "\ts_nop 0\n\tv_mfma")) == []
+    assert isa_census.lint_partial_writes(fake.replace("v[16:19]", "v[20:23]")) == []
+    if shutil.which(os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")) is None:
+        pytest.skip("hipcc not available")
+    assert isa_census.lint_partial_writes() == []
