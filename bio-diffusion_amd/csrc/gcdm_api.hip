@@ -81,7 +81,7 @@ struct gcdm_handle {
     // automatic choice, measured on MI355X: split-precision kernels -> 32 (QM9 +-0 ... +2 %, GEOM +2 %, 100-molecule
     // evaluation batches +12 ... 25 %: less round quantisation), fp32 kernels -> 64.  Rows cut by tile boundaries are summed from per-tile
     // partials in tile order (AggSrc), so every choice is bit-reproducible for any molecule size.
-    int tile() const { return edge_tile ? edge_tile : (use_x3() ? 32 : 64); }
+    int tile() const { return edge_tile ? edge_tile : 64; }
     bool x3_weights_ok = true;       // every GEMM weight fits the split-precision images (|W| < 31.9); else mfma_mode 1 is refused
     int mfma_x3 = 1;                 // requested mode -- 1: split-precision f16 x3 kernels (default; env GCDM_MFMA=f16x3|f32), 0: fp32 MFMA
     bool use_x3() const { return mfma_x3 && x3_weights_ok; }   // effective mode: models whose weights do not fit the split images run fp32 MFMA
@@ -796,7 +796,9 @@ int gcdm_plan_batch_masked(gcdm_handle* h, int32_t B, const int32_t* nn, const u
     if (E >= (int64_t)1 << 31) return fail(h, "gcdm_plan_batch: too many edges");
     // k_sample / k_prep stage one molecule in LDS (max_n * (3 + F) floats, 64 KB without an opt-in attribute)
     if (max_n > 4096 || (size_t)max_n * h->D * sizeof(float) > 65536) return fail(h, "gcdm_plan_batch: molecule too large (max_n * (3 + F) floats must fit 64 KB of LDS)");
-    free_plan(h);                 // only now: a rejected request leaves the previous plan in place
+    free_plan(h);                 // only now: a request rejected by the ARGUMENT checks above leaves the previous plan in place; one that fails
+                                  // below (workspace over 4 GB, hipMalloc) leaves NO plan (callers must not assume the old one survives:
+                                  // GCPNetDynamics.plan forgets its plan key before the call)
     const int N = noff[B];
     std::vector<int> erow(E), ecol(E), ncnt(N), rowstart(N);
     int64_t p = 0;
@@ -1248,6 +1250,8 @@ int gcdm_profile_enable(gcdm_handle* h, int32_t enable) {
         h->ev.resize(2 * (size_t)h->L);
         for (auto& e : h->ev) HIP_OK(h, hipEventCreate(&e));
     }
+    if (enable >= 2 && !GCDM_HAVE_STAMPS)
+        return fail(h, "gcdm_profile_enable: in-kernel phase stamps need a library built with -DGCDM_STAMPS (tools/build_variants.sh stamps:-DGCDM_STAMPS)");
     h->profile = enable != 0;
     h->profile_phases = enable == 2;
     h->profile_node = enable == 3;
@@ -1294,9 +1298,13 @@ int64_t gcdm_debug_read(gcdm_handle* h, const char* name, float* host_out, int64
             hipMemcpy(nc.data(), h->d_ncnt, n * sizeof(int), hipMemcpyDeviceToHost) != hipSuccess)
             return fail(h, "gcdm_debug_read: copy failed");
         for (int64_t i = 0; i < n; ++i) {
+            float* dst = host_out + i * GCDM_AGGW;
+            if (nc[i] == 0) {           // masked node (no edges): its aggregate is zero, as the device-side agg_row has it
+                for (int c = 0; c < GCDM_AGGW; ++c) dst[c] = 0.f;
+                continue;
+            }
             const int t0 = rs[i] >> sh, t1 = (rs[i] + nc[i] - 1) >> sh;
             if (t0 == t1) continue;
-            float* dst = host_out + i * GCDM_AGGW;
             const float* src = part.data() + ((size_t)t0 * 2 + ((rs[i] & (ET - 1)) ? 1 : 0)) * GCDM_AGGW;
             for (int c = 0; c < GCDM_AGGW; ++c) dst[c] = src[c];
             for (int t = t0 + 1; t <= t1; ++t)

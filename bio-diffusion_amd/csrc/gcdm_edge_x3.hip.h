@@ -19,7 +19,11 @@
 // SiLU in the scaled units of this kernel: the message scalars are kept as c * m.s with c = -log2(e) (the host folds c into the weights, gcdm_api.hip
 // X3_C), so for x' = c * x:  c * SiLU(x) = x' / (1 + exp2(x'))  -- exp2, add, rcp, mul: one multiply less than x * sigmoid(x)
 #define X3_C (-1.4426950408889634f)
+#ifdef GCDM_ABL_NOSILU          // (GCDM_ABL_*: timing ablations, wrong results by construction -- tools/ab_run.sh)
+__device__ __forceinline__ float silu_scaled(float xs) { return xs; }
+#else
 __device__ __forceinline__ float silu_scaled(float xs) { return xs * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(xs)); }
+#endif
 
 // v_sqrt_f32 (1 ulp) instead of the ~20-instruction correctly rounded expansion: the argument is >= 1e-8, never denormal
 __device__ __forceinline__ float fast_sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
@@ -48,24 +52,24 @@ typedef _Float16 h4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ void split16(float x, _Float16& hi, _Float16& lo) {
     hi = (_Float16)(x * X3_PRE);
-    // (x 2^-8 - hi) * 2^11, written so that it maps to one mixed-precision FMA (v_fma_mixlo_f16): both products are exact (powers of two)
+    // x - hi * 2^11 (hi holds x * 2^-11), written so that it maps to one mixed-precision FMA (v_fma_mixlo_f16): the product is exact (power of two)
     static_assert(X3_SCALE * X3_PRE == 1.0f, "lo' = x - hi * 2^11");
     lo = (_Float16)__builtin_fmaf((float)hi, -X3_SCALE, x);
 }
 
-// Two values at once, 3 VALU instructions per value: one multiply (x * 2^3) and two mixed-precision FMAs -- v_fma_mix{lo,hi}_f16 writes
-// f16(x * 2^-8) resp. f16(x * 2^3 - hi * 2^11) into one half of the destination, reading hi as f16 (the compiler does not form these
-// reliably).  Bit-identical to split16: all products are by powers of two, one rounding to f16 at the end of each.
+// Two values at once, 2 VALU instructions per value: two mixed-precision FMAs -- v_fma_mix{lo,hi}_f16 writes f16(x * 2^-11) resp.
+// f16(x - hi * 2^11) into one half of the destination, reading hi as f16 (the compiler does not form these reliably).  Bit-identical to
+// split16: all products are by powers of two, one rounding to f16 at the end of each.
 typedef _Float16 h2 __attribute__((ext_vector_type(2)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void split16x2(float x0, float x1, h2& hi, h2& lo) {
     const float pre = X3_PRE, neg = -X3_SCALE;
     const float s0 = x0, s1 = x1;
     uint32_t hiu, lou;
-    // hi = f16(x * 2^-8) (round to nearest), both halves of one register
+    // hi = f16(x * 2^-11) (round to nearest), both halves of one register
     asm("v_fma_mixlo_f16 %0, %1, %2, 0 op_sel_hi:[0,0,0]" : "=v"(hiu) : "v"(x0), "s"(pre));
     asm("v_fma_mixhi_f16 %0, %1, %2, 0 op_sel_hi:[0,0,0]" : "+v"(hiu) : "v"(x1), "s"(pre));
-    // lo' = f16(x * 2^3 - hi * 2^11): hi is read as f16 from the low / high half
+    // lo' = f16(x - hi * 2^11): hi is read as f16 from the low / high half
     asm("v_fma_mixlo_f16 %0, %1, %2, %3 op_sel_hi:[1,0,0]" : "=v"(lou) : "v"(hiu), "s"(neg), "v"(s0));
     asm("v_fma_mixhi_f16 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(lou) : "v"(hiu), "s"(neg), "v"(s1));
     __builtin_memcpy(&hi, &hiu, 4);
@@ -108,6 +112,16 @@ struct WPool {
         __builtin_memcpy(&r, &v, 16);
         return r;
     }
+    // k-block `blk` of a packed array at scalar offset `arr`: blocks are 1 KB apart, so four consecutive blocks share ONE scalar offset
+    // and differ in the instruction's 12-bit immediate (the compiler folds a constant added to the lane offset into it): one s_add per
+    // four blocks and array instead of one per load
+    template <int BLK>
+    __device__ __forceinline__ h8 ldk(uint32_t arr) const {
+        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff + (uint32_t)((BLK & 3) * 1024), arr + (uint32_t)((BLK >> 2) * 4096), 0);
+        h8 r;
+        __builtin_memcpy(&r, &v, 16);
+        return r;
+    }
 };
 __device__ __forceinline__ WPool make_wpool(const void* pool, uint32_t bytes, int lane) {
     WPool w;
@@ -136,20 +150,40 @@ __device__ __forceinline__ BufView make_view(const void* pool, uint32_t bytes) {
     return b;
 }
 
+// One explicit wait for ALL A operands of the current k-block (at most VM younger loads -- the next blocks' -- stay in flight) in front of
+// its MFMAs: the compiler's own per-operand waits (2-3 per block) become redundant and are dropped.  Never weaker than what the
+// compiler would insert, so only the instruction count changes.
+template <int VM>
+__device__ __forceinline__ void x3_wait_block() {
+    static_assert(VM < 64, "vmcnt is a 6-bit field");
+    __builtin_amdgcn_s_waitcnt((15 << 8) | (7 << 4) | (VM & 15) | ((VM >> 4) << 14));
+}
+
 template <int MT, int PD>
 __device__ __forceinline__ void x3_prefetch_b(X3Ring<MT, PD>& ring, const WPool& wp, uint32_t oH, uint32_t oL, int KB) {
     const uint32_t wstride = KB * 64 * 16;
 #pragma unroll
-    for (int r = 0; r < PD; ++r)
+    for (int r = 0; r < PD; ++r) {
 #pragma unroll
-        for (int m = 0; m < MT; ++m) { ring.ah[r][m] = wp.ld(oH + m * wstride + r * 1024); ring.alo[r][m] = wp.ld(oL + m * wstride + r * 1024); }
+        for (int m = MT - 1; m >= 0; --m) ring.alo[r][m] = wp.ld(oL + m * wstride + r * 1024);
+#pragma unroll
+        for (int m = MT - 1; m >= 0; --m) ring.ah[r][m] = wp.ld(oH + m * wstride + r * 1024);
+    }
 }
 
 // NOTE: the prefetches run PD k-blocks (A) / one k-block (B) past the end of the contraction without clamping: the packed weight
 // arrays carry X3_TAIL_BLOCKS zero blocks of padding behind the last M-tile, and the LDS reads stay inside the XH8|XL8|VV allocation.
 #define X3_TAIL_BLOCKS 4
 #ifndef GCDM_X3_PD
-#define GCDM_X3_PD 1             // k-blocks of weight prefetch distance in the edge kernel (register ring of PD + 1 sets)
+#define GCDM_X3_PD 2             // k-blocks of weight prefetch distance in the edge kernel (register ring of PD + 1 sets)
+#endif
+#ifndef GCDM_X3_NO_ILV          // operand requests of the next k-blocks between the MFMAs of the current one (needs GCDM_X3_PD >= 2)
+constexpr bool X3_ILV = GCDM_X3_PD >= 2;
+#else
+constexpr bool X3_ILV = false;
+#endif
+#ifndef GCDM_X3_NO_GATEPF       // vector_out_scale A operands requested ahead of the SiLU that produces their B operand
+#define GCDM_X3_GATEPF 1
 #endif
 #ifndef GCDM_VEC_PER_MFMA
 #define GCDM_VEC_PER_MFMA 6      // instructions of a vector stage issued behind each MFMA of the hosting k-block
@@ -239,27 +273,52 @@ __device__ __forceinline__ void tile_gemm_x3z(f32x16 (&am)[MT][NT], f32x16 (&al)
     for (int n = 0; n < NT; ++n) { bh[0][n] = sh[n * 32]; bl[0][n] = sl[n * 32]; }
     static_for<0, KB>([&](auto rc) {
         constexpr int r = decltype(rc)::value;
+        auto loads = [&] {
 #pragma unroll
-        for (int m = 0; m < MT; ++m) {
-            ring.ah[(r + PD) % R][m] = wp.ld(wH + ((r + PD) * 64 + m * wstride) * 16);
-            ring.alo[(r + PD) % R][m] = wp.ld(wL + ((r + PD) * 64 + m * wstride) * 16);
+            for (int m = MT - 1; m >= 0; --m) ring.alo[(r + PD) % R][m] = wp.template ldk<r + PD>(wL + m * wstride * 16);
+#pragma unroll
+            for (int m = MT - 1; m >= 0; --m) ring.ah[(r + PD) % R][m] = wp.template ldk<r + PD>(wH + m * wstride * 16);
+        };
+        auto breads = [&] {
+#pragma unroll
+            for (int n = 0; n < NT; ++n) { bh[(r + 1) & 1][n] = sh[(r + 1) * 2 * TP + n * 32]; bl[(r + 1) & 1][n] = sl[(r + 1) * 2 * TP + n * 32]; }
+        };
+        auto mfmas = [&] {
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int n = 0; n < NT; ++n) am[m][n] = MFMA16(ring.ah[r % R][m], bh[r & 1][n], (ZAM && r == 0) ? zero : am[m][n]);
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int n = 0; n < NT; ++n) al[m][n] = MFMA16(ring.ah[r % R][m], bl[r & 1][n], (ZAL && r == 0) ? zero : al[m][n]);
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int n = 0; n < NT; ++n) al[m][n] = MFMA16(ring.alo[r % R][m], bh[r & 1][n], al[m][n]);
+        };
+        if constexpr (X3_ILV) {          // (see tile_gemm_x3s)
+            x3_wait_block<2 * MT * (PD - 1)>();
+            __builtin_amdgcn_sched_barrier(0);
+            mfmas();
+            breads();
+            loads();
+#pragma unroll
+            for (int i = 0; i < 3 * MT * NT; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                if (i < 2 * NT) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                else if (i < 2 * NT + 2 * MT) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        } else {
+            loads();
+            breads();
+            __builtin_amdgcn_sched_barrier(0);
+            x3_wait_block<2 * MT * PD>();
+            __builtin_amdgcn_sched_barrier(0);
+            mfmas();
+            __builtin_amdgcn_sched_barrier(0);
         }
-#pragma unroll
-        for (int n = 0; n < NT; ++n) { bh[(r + 1) & 1][n] = sh[(r + 1) * 2 * TP + n * 32]; bl[(r + 1) & 1][n] = sl[(r + 1) * 2 * TP + n * 32]; }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int m = 0; m < MT; ++m)
-#pragma unroll
-            for (int n = 0; n < NT; ++n) am[m][n] = MFMA16(ring.ah[r % R][m], bh[r & 1][n], (ZAM && r == 0) ? zero : am[m][n]);
-#pragma unroll
-        for (int m = 0; m < MT; ++m)
-#pragma unroll
-            for (int n = 0; n < NT; ++n) al[m][n] = MFMA16(ring.ah[r % R][m], bl[r & 1][n], (ZAL && r == 0) ? zero : al[m][n]);
-#pragma unroll
-        for (int m = 0; m < MT; ++m)
-#pragma unroll
-            for (int n = 0; n < NT; ++n) al[m][n] = MFMA16(ring.alo[r % R][m], bh[r & 1][n], al[m][n]);
-        __builtin_amdgcn_sched_barrier(0);
     });
 }
 
@@ -272,8 +331,64 @@ __device__ __forceinline__ void gate_partial_x3(f32x16 (&gm)[NT], f32x16 (&gl)[N
     for (int m = 0; m < MT; ++m)
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
+#ifdef GCDM_ABL_GATE_NOLOAD
+            h8 aH, aL;
+            for (int s = 0; s < 8; ++s) { aH[s] = (_Float16)(0.01f * (lane + m + j)); aL[s] = (_Float16)(0.002f * s); }
+#else
             const h8 aH = wgH[((mt0 + m) * 2 + j) * 64 + lane];
             const h8 aL = wgL[((mt0 + m) * 2 + j) * 64 + lane];
+#endif
+            h8 bh[NT], bl[NT];
+#ifdef GCDM_ABL_GATE_NOSPLIT
+            for (int n = 0; n < NT; ++n) {
+                const v4f t0 = {act[m][n][8 * j], act[m][n][8 * j + 1], act[m][n][8 * j + 2], act[m][n][8 * j + 3]};
+                const v4f t1 = {act[m][n][8 * j + 4], act[m][n][8 * j + 5], act[m][n][8 * j + 6], act[m][n][8 * j + 7]};
+                bh[n] = __builtin_bit_cast(h8, t0); bl[n] = __builtin_bit_cast(h8, t1);
+            }
+#else
+#pragma unroll
+            for (int n = 0; n < NT; ++n)
+#pragma unroll
+                for (int s = 0; s < 8; s += 2) {
+                    h2 hi, lo;
+                    split16x2(act[m][n][8 * j + s], act[m][n][8 * j + s + 1], hi, lo);
+                    bh[n][s] = hi[0]; bh[n][s + 1] = hi[1];
+                    bl[n][s] = lo[0]; bl[n][s + 1] = lo[1];
+                }
+#pragma unroll
+            for (int n = 0; n < NT; ++n) x3_settle(bh[n], bl[n]);
+#endif
+#pragma unroll
+            for (int n = 0; n < NT; ++n) gm[n] = MFMA16(aH, bh[n], (ZERO && m == 0 && j == 0) ? zero : gm[n]);
+#pragma unroll
+            for (int n = 0; n < NT; ++n) gl[n] = MFMA16(aH, bl[n], (ZERO && m == 0 && j == 0) ? zero : gl[n]);
+#pragma unroll
+            for (int n = 0; n < NT; ++n) gl[n] = MFMA16(aL, bh[n], gl[n]);
+        }
+}
+
+// The same with the A operands (this wave's slices of vector_out_scale: 2 k-blocks per M-tile, hi and lo') requested AHEAD of the SiLU
+// that produces the B operand: as plain loads at the point of use their L2 round trip was exposed once per GCP2 (-3 % of the tile's
+// cycles in the ablation, tools/ab_run.sh g_noload)
+template <int MT>
+struct GateW {
+    h8 aH[MT][2], aL[MT][2];
+};
+template <int MT>
+__device__ __forceinline__ void gate_prefetch(GateW<MT>& g, const WPool& wp, const h8* wgH, const h8* wgL, int mt0) {
+    const uint32_t oH = wp.off(wgH + (size_t)mt0 * 2 * 64), oL = wp.off(wgL + (size_t)mt0 * 2 * 64);
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) { g.aH[m][j] = wp.ld(oH + (m * 2 + j) * 1024); g.aL[m][j] = wp.ld(oL + (m * 2 + j) * 1024); }
+}
+template <int MT, int NT, bool ZERO = false>
+__device__ __forceinline__ void gate_partial_x3p(f32x16 (&gm)[NT], f32x16 (&gl)[NT], const f32x16 (&act)[MT][NT], const GateW<MT>& g) {
+    const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
             h8 bh[NT], bl[NT];
 #pragma unroll
             for (int n = 0; n < NT; ++n)
@@ -287,11 +402,11 @@ __device__ __forceinline__ void gate_partial_x3(f32x16 (&gm)[NT], f32x16 (&gl)[N
 #pragma unroll
             for (int n = 0; n < NT; ++n) x3_settle(bh[n], bl[n]);
 #pragma unroll
-            for (int n = 0; n < NT; ++n) gm[n] = MFMA16(aH, bh[n], (ZERO && m == 0 && j == 0) ? zero : gm[n]);
+            for (int n = 0; n < NT; ++n) gm[n] = MFMA16(g.aH[m][j], bh[n], (ZERO && m == 0 && j == 0) ? zero : gm[n]);
 #pragma unroll
-            for (int n = 0; n < NT; ++n) gl[n] = MFMA16(aH, bl[n], (ZERO && m == 0 && j == 0) ? zero : gl[n]);
+            for (int n = 0; n < NT; ++n) gl[n] = MFMA16(g.aH[m][j], bl[n], (ZERO && m == 0 && j == 0) ? zero : gl[n]);
 #pragma unroll
-            for (int n = 0; n < NT; ++n) gl[n] = MFMA16(aL, bh[n], gl[n]);
+            for (int n = 0; n < NT; ++n) gl[n] = MFMA16(g.aL[m][j], bh[n], gl[n]);
         }
 }
 
@@ -592,39 +707,79 @@ __device__ __forceinline__ void tile_gemm_x3s(f32x16 (&am)[MT][NT], f32x16 (&al)
     auto body = [&](auto rc, auto hooked) {
         constexpr int r = decltype(rc)::value;
         constexpr bool HK = decltype(hooked)::value;
+        auto loads = [&] {
+#ifndef GCDM_X3_NOWLOAD                          // (timing ablation only: the GEMM without its weight stream)
+            // uniform base + compile-time block offset + lane: no per-block VALU pointer arithmetic.  Issue order: the operand of the
+            // block's FIRST MFMA (ah[0]) last, so that one s_waitcnt covers the whole block instead of one per operand
 #pragma unroll
-        for (int m = 0; m < MT; ++m) {          // uniform base + compile-time block offset + lane: no per-block VALU pointer arithmetic
-            ring.ah[(r + PD) % R][m] = wp.ld(wH + ((r + PD) * 64 + m * wstride) * 16);
-            ring.alo[(r + PD) % R][m] = wp.ld(wL + ((r + PD) * 64 + m * wstride) * 16);
-        }
-        if constexpr (r + 1 != SPLIT) {          // the block behind the barrier is read after the barrier
+            for (int m = MT - 1; m >= 0; --m) ring.alo[(r + PD) % R][m] = wp.template ldk<r + PD>(wL + m * wstride * 16);
 #pragma unroll
-            for (int n = 0; n < NT; ++n) { bh[(r + 1) & 1][n] = sh[(r + 1) * 2 * TP + n * 32]; bl[(r + 1) & 1][n] = sl[(r + 1) * 2 * TP + n * 32]; }
-        }
-        __builtin_amdgcn_sched_barrier(0);
+            for (int m = MT - 1; m >= 0; --m) ring.ah[(r + PD) % R][m] = wp.template ldk<r + PD>(wH + m * wstride * 16);
+#endif
+        };
+        auto breads = [&] {
+#ifndef GCDM_ABL_NOB
+            if constexpr (r + 1 != SPLIT) {          // the block behind the barrier is read after the barrier
 #pragma unroll
-        for (int m = 0; m < MT; ++m)
+                for (int n = 0; n < NT; ++n) { bh[(r + 1) & 1][n] = sh[(r + 1) * 2 * TP + n * 32]; bl[(r + 1) & 1][n] = sl[(r + 1) * 2 * TP + n * 32]; }
+            }
+#else
+            for (int n = 0; n < NT; ++n) { bh[(r + 1) & 1][n] = bh[r & 1][n]; bl[(r + 1) & 1][n] = bl[r & 1][n]; }
+#endif
+        };
+        auto mfmas = [&] {
 #pragma unroll
-            for (int n = 0; n < NT; ++n) am[m][n] = MFMA16(ring.ah[r % R][m], bh[r & 1][n], r == 0 ? zero : am[m][n]);
+            for (int m = 0; m < MT; ++m)
 #pragma unroll
-        for (int m = 0; m < MT; ++m)
+                for (int n = 0; n < NT; ++n) am[m][n] = MFMA16(ring.ah[r % R][m], bh[r & 1][n], r == 0 ? zero : am[m][n]);
+#ifndef GCDM_ABL_MFMA1
 #pragma unroll
-            for (int n = 0; n < NT; ++n) al[m][n] = MFMA16(ring.ah[r % R][m], bl[r & 1][n], r == 0 ? zero : al[m][n]);
+            for (int m = 0; m < MT; ++m)
 #pragma unroll
-        for (int m = 0; m < MT; ++m)
+                for (int n = 0; n < NT; ++n) al[m][n] = MFMA16(ring.ah[r % R][m], bl[r & 1][n], r == 0 ? zero : al[m][n]);
 #pragma unroll
-            for (int n = 0; n < NT; ++n) al[m][n] = MFMA16(ring.alo[r % R][m], bh[r & 1][n], al[m][n]);
-        if constexpr (HK) {
-            hook(rc);
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int n = 0; n < NT; ++n) al[m][n] = MFMA16(ring.alo[r % R][m], bh[r & 1][n], al[m][n]);
+#else
+            if (r == 0) { for (int m = 0; m < MT; ++m) for (int n = 0; n < NT; ++n) al[m][n] = zero; }
+#endif
+        };
+        if constexpr (X3_ILV && !HK) {
+            // the next blocks' operand requests ride BETWEEN this block's MFMAs (one per MFMA: B reads first, their latency is the shorter
+            // one to cover), issued while the matrix pipe works on the MFMA in front of them, instead of in a burst ahead of the block
+            static_assert(PD >= 2, "interleaved requests are waited for one block later: two blocks of prefetch distance");
+            x3_wait_block<2 * MT * (PD - 1)>();
+            __builtin_amdgcn_sched_barrier(0);
+            mfmas();
+            breads();
+            loads();
+#pragma unroll
+            for (int i = 0; i < 3 * MT * NT; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                if (i < 2 * NT) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                else if (i < 2 * NT + 2 * MT) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        } else {
+            loads();
+            breads();
+            __builtin_amdgcn_sched_barrier(0);
+            x3_wait_block<2 * MT * PD>();
+            __builtin_amdgcn_sched_barrier(0);
+            mfmas();
+            if constexpr (HK) {
+                hook(rc);
 #if GCDM_VEC_PER_MFMA > 0
 #pragma unroll
-            for (int i = 0; i < 3 * MT * NT; ++i) {      // one MFMA, then up to GCDM_VEC_PER_MFMA other instructions of the stage, ...
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x002 | 0x004 | 0x080 | 0x400 | 0x020, GCDM_VEC_PER_MFMA, 0);
-            }
+                for (int i = 0; i < 3 * MT * NT; ++i) {      // one MFMA, then up to GCDM_VEC_PER_MFMA other instructions of the stage, ...
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002 | 0x004 | 0x080 | 0x400 | 0x020, GCDM_VEC_PER_MFMA, 0);
+                }
 #endif
+            }
+            __builtin_amdgcn_sched_barrier(0);
         }
-        __builtin_amdgcn_sched_barrier(0);
     };
     static_for<0, SPLIT>([&](auto rc) { body(rc, std::integral_constant<bool, HOOKED>{}); });
     __syncthreads();
@@ -767,6 +922,7 @@ __global__ __launch_bounds__(ET * 8) __attribute__((amdgpu_waves_per_eu(2, 2))) 
         }
     }
     // ---- P1: msg0 pre-phase ---------------------------------------------------------------------------------------------
+#ifndef GCDM_ABL_NOP1
     {
         if (part == 0) {
 #pragma unroll
@@ -799,13 +955,21 @@ __global__ __launch_bounds__(ET * 8) __attribute__((amdgpu_waves_per_eu(2, 2))) 
             const uint32_t vI = ((uint32_t)(hh * 3) * N + ni) * 4u, vJ = ((uint32_t)(hh * 3) * N + nj) * 4u;   // the row depends on the lane's part
 #pragma unroll
             for (int x = 0; x < 3; ++x) {
+#ifdef GCDM_ABL_NOGATHER
+                gi[i][x] = 0.1f * x; gj[i][x] = 0.2f;
+#else
                 gi[i][x] = ws.ld1(vI, oI + x * rowN);
                 gj[i][x] = ws.ld1(vJ, oJ + x * rowN);
+#endif
             }
             const uint32_t vW = (uint32_t)(hh * VE) * 4u;
             float bsum = 0.f;
+#ifdef GCDM_ABL_NOBETA
+            bsum = al[0];
+#else
 #pragma unroll
             for (int c = 0; c < VE; ++c) bsum += wv.ld1(vW, oW + c * 4) * al[c];
+#endif
             beta[i] = bsum;
             beta2[i] = 0.f;
         }
@@ -830,6 +994,10 @@ __global__ __launch_bounds__(ET * 8) __attribute__((amdgpu_waves_per_eu(2, 2))) 
             const float vx = gi[i][0] + beta[i] * u0 + beta2[i] * s0 + gj[i][0];
             const float vy = gi[i][1] + beta[i] * u1 + beta2[i] * s1 + gj[i][1];
             const float vz = gi[i][2] + beta[i] * u2 + beta2[i] * s2 + gj[i][2];
+#ifdef GCDM_ABL_NOP1W
+            if (vx + vy + vz == 123.456f) VH[e] = vx;
+            continue;
+#endif
             if (hh < H0) {
                 over |= put16(XH, XL, ETP, N8 + (hh >> 3), hh & 7, e, fast_sqrt(vx * vx + vy * vy + vz * vz + 1e-8f) + 1e-8f);
                 VH[(hh * 3 + 0) * ETP + e] = vx;
@@ -853,6 +1021,7 @@ __global__ __launch_bounds__(ET * 8) __attribute__((amdgpu_waves_per_eu(2, 2))) 
             }
         }
     }
+#endif
     STAMP(1);
     __syncthreads();
     STAMP(2);
@@ -883,10 +1052,18 @@ __global__ __launch_bounds__(ET * 8) __attribute__((amdgpu_waves_per_eu(2, 2))) 
 #pragma unroll
                 for (int q = 0; q < 4; ++q)
 #pragma unroll
+#ifdef GCDM_ABL_NOPQ
+                    for (int t = 0; t < 4; ++t) am[m][n][4 * q + t] = 0.f;
+#else
                     for (int t = 0; t < 4; ++t) am[m][n][4 * q + t] = pqi[m][n][q][t] + pqj[m][n][q][t];
+#endif
         STAMP(3);
         tile_gemm_x3z<MT, NT, PD, KB0C, false, true>(am, al2, ring, wp, o0H, o0L, xh8, xl8, ETP, lane);
         x3_prefetch_b<MT, PD>(ring, wp, wp.off(ax.wH[0] + (size_t)mt0 * 18 * 64), wp.off(ax.wL[0] + (size_t)mt0 * 18 * 64), 18);
+#ifdef GCDM_X3_GATEPF
+        GateW<MT> gw0;
+        gate_prefetch<MT>(gw0, wp, ax.wg0H, ax.wg0L, mt0);
+#endif
         STAMP(4);
 #pragma unroll
         for (int m = 0; m < MT; ++m)
@@ -895,7 +1072,12 @@ __global__ __launch_bounds__(ET * 8) __attribute__((amdgpu_waves_per_eu(2, 2))) 
 #pragma unroll
                 for (int r = 0; r < 16; ++r) st[m][n][r] = silu_scaled(am[m][n][r] + al2[m][n][r] * X3_INV_SCALE);
         STAMP(5);
+#ifndef GCDM_ABL_NOGATE
+#ifdef GCDM_X3_GATEPF
+        gate_partial_x3p<MT, NT, true>(gm, gl, st, gw0);
+#else
         gate_partial_x3<MT, NT, true>(gm, gl, st, ax.wg0H, ax.wg0L, mt0, lane);
+#endif
         if (NW == 4) {               // four partials = the four slots the vector waves sum: no fold needed
             put_gate_partial<NT, ET>(PG, gm, gl, wave, lane, false);
         } else {
@@ -903,12 +1085,15 @@ __global__ __launch_bounds__(ET * 8) __attribute__((amdgpu_waves_per_eu(2, 2))) 
             __syncthreads();
             if (wave >= 4) put_gate_partial<NT, ET>(PG, gm, gl, wave - 4, lane, true);
         }
+#endif
         STAMP(6);
     }
     __syncthreads();
     STAMP(7);
     // ---- P3: state images ---------------------------------------------------------------------------------------------------
+#ifndef GCDM_ABL_NOSTORE
     store_state_x3<MT, NT>(XH, XL, 0, st, ETP, mt0, lane, amax);
+#endif
     STAMP(8);
     __syncthreads();
     STAMP(9);
@@ -919,6 +1104,22 @@ __global__ __launch_bounds__(ET * 8) __attribute__((amdgpu_waves_per_eu(2, 2))) 
         const GcpW& w = a.mk[k];
         const uint32_t gwH = wp.off(ax.wH[k] + (size_t)mt0 * 18 * 64), gwL = wp.off(ax.wL[k] + (size_t)mt0 * 18 * 64);
         if (k == 0) STAMP(10);
+#ifdef GCDM_X3_UNHOOK
+        // vector stages AHEAD of the wave's scalar GEMM instead of between its MFMAs: the stage registers are dead before the GEMM
+        // starts, which leaves room for a deeper weight ring (GCDM_X3_PD up to X3_TAIL_BLOCKS)
+        if (vhalf == (k & 1)) {
+            VecStage<ET, H0, k == 0> vs;
+            vs.PG = PG; vs.bg = k == 0 ? a.bg0 : a.mk[k == 0 ? 0 : k - 1].bg; vs.FR = FR; vs.VH = VH; vs.VHB = VHB; vs.VV4 = VV4; vs.XH = XH; vs.XL = XL;
+            vs.fA = k == 0 ? ax.vf0H : ax.vf1[k == 0 ? 0 : k - 1]; vs.fB = k == 0 ? ax.vf0L : ax.vf2[k == 0 ? 0 : k - 1];
+            vs.pH = ax.vpH[k]; vs.pL = ax.vpL[k];
+            vs.ve = ve; vs.vq = vq; vs.lane = lane;
+#ifndef GCDM_ABL_NOVEC
+            static_for<0, 16>([&](auto ic) { vs.template run<decltype(ic)::value>(); });
+#endif
+            amax = fmaxf(amax, vs.amax);
+        }
+        tile_gemm_x3s<MT, NT, PD, 18, 16, false>(am, al2, ring, wp, gwH, gwL, xh8, xl8, ETP, lane, [](auto) {});
+#else
         if (vhalf == (k & 1)) {
             VecStage<ET, H0, k == 0> vs;
             vs.PG = PG; vs.bg = k == 0 ? a.bg0 : a.mk[k == 0 ? 0 : k - 1].bg; vs.FR = FR; vs.VH = VH; vs.VHB = VHB; vs.VV4 = VV4; vs.XH = XH; vs.XL = XL;
@@ -930,7 +1131,12 @@ __global__ __launch_bounds__(ET * 8) __attribute__((amdgpu_waves_per_eu(2, 2))) 
         } else {
             tile_gemm_x3s<MT, NT, PD, 18, 16, false>(am, al2, ring, wp, gwH, gwL, xh8, xl8, ETP, lane, [](auto) {});
         }
+#endif
         if (k < 2) x3_prefetch_b<MT, PD>(ring, wp, wp.off(ax.wH[k < 2 ? k + 1 : 2] + (size_t)mt0 * 18 * 64), wp.off(ax.wL[k < 2 ? k + 1 : 2] + (size_t)mt0 * 18 * 64), 18);
+#ifdef GCDM_X3_GATEPF
+        GateW<MT> gwk;
+        gate_prefetch<MT>(gwk, wp, ax.wgH[k], ax.wgL[k], mt0);
+#endif
         if (k == 0) STAMP(12);
 #pragma unroll
         for (int m = 0; m < MT; ++m)
@@ -939,14 +1145,25 @@ __global__ __launch_bounds__(ET * 8) __attribute__((amdgpu_waves_per_eu(2, 2))) 
 #pragma unroll
                 for (int r = 0; r < 16; ++r) am[m][n][r] = silu_scaled(am[m][n][r] + al2[m][n][r] * X3_INV_SCALE);
         if (k == 0) STAMP(13);
+#ifndef GCDM_ABL_NOGATE
+#ifdef GCDM_X3_GATEPF
+        gate_partial_x3p<MT, NT, true>(gm, gl, am, gwk);
+#else
         gate_partial_x3<MT, NT, true>(gm, gl, am, ax.wgH[k], ax.wgL[k], mt0, lane);
+#endif
+#ifdef GCDM_ABL_GATE_NOPG
+        asm volatile("" ::"v"(gm[0]), "v"(gl[0]));
+        if (false) {
+#else
         if (NW == 4) {
+#endif
             put_gate_partial<NT, ET>(PG, gm, gl, wave, lane, false);
         } else {
             if (wave < 4) put_gate_partial<NT, ET>(PG, gm, gl, wave, lane, false);
             __syncthreads();
             if (wave >= 4) put_gate_partial<NT, ET>(PG, gm, gl, wave - 4, lane, true);
         }
+#endif
         if (k == 0) STAMP(14);
         __syncthreads();                 // every wave is done reading the old XH8 / XL8 images; gate partials complete
         if (k == 0) STAMP(15);
@@ -957,7 +1174,9 @@ __global__ __launch_bounds__(ET * 8) __attribute__((amdgpu_waves_per_eu(2, 2))) 
 #pragma unroll
                 for (int r = 0; r < 16; ++r) st[m][n][r] += am[m][n][r];       // residual add in fp32 (gcpnet.py:701)
         if (k < 2) {
+#ifndef GCDM_ABL_NOSTORE
             store_state_x3<MT, NT>(XH, XL, 0, st, ETP, mt0, lane, amax);
+#endif
         } else {                          // last GCP2: fp32 image for attention + segment sums (aliases XH8 / XL8), and its vector part
             store_state<MT, NT, false>(XS4, 0, st, ETP, mt0, lane, 0);
             if (vhalf == 1) {
@@ -977,6 +1196,7 @@ __global__ __launch_bounds__(ET * 8) __attribute__((amdgpu_waves_per_eu(2, 2))) 
     if (__any(over) && lane == 0) atomicOr(ax.flags_dev, GCDM_FLAG_F16_RANGE_BIT);
 
     // ---- scalar message attention + aggregation: identical to the fp32 kernel (fp32 data) ---------------------------------
+#ifndef GCDM_ABL_NOAGG
     {
         float s = 0.f;
         constexpr int GPP = GCDM_SG / PARTS;
@@ -1031,5 +1251,6 @@ __global__ __launch_bounds__(ET * 8) __attribute__((amdgpu_waves_per_eu(2, 2))) 
             }
         }
     }
+#endif
     STAMP(20);
 }

@@ -592,10 +592,19 @@ struct EdgeMsgArgs {
     float* prof;                 // optional [tiles][8 waves][24] phase time stamps (shader cycles since kernel start)
 };
 
+// In-kernel phase time stamps are compiled in only with -DGCDM_STAMPS (tools/build_variants.sh; gcdm_profile_enable(h, 2 | 3) fails
+// without it): even switched off at run time each stamp costs the wave an exec-mask save, a branch and a restore -- 20 of them are
+// ~2 % of the edge kernel's issue slots, and they pin the instruction schedule around them.
+#ifdef GCDM_STAMPS
 #define STAMP(i)                                                                                        \
     do {                                                                                                \
         if (a.prof && lane == 0) a.prof[((size_t)blockIdx.x * 8 + wave) * 24 + (i)] = (float)(__builtin_amdgcn_s_memtime() - t_start); \
     } while (0)
+#define GCDM_HAVE_STAMPS 1
+#else
+#define STAMP(i) ((void)0)
+#define GCDM_HAVE_STAMPS 0
+#endif
 
 // Tile geometry.  T = 64: one 8-wave workgroup per CU (152 KB LDS).  T = 32: 4-wave workgroups of 77 KB, two per CU,
 // which run out of phase so that one's VALU phases overlap the other's MFMA phases (weights are then streamed twice).

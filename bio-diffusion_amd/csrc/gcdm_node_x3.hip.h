@@ -24,10 +24,14 @@ struct NodeX3Args {
     float* prof;                   // optional [tiles][8 waves][24] phase time stamps (gcdm_profile_enable(h, 3))
 };
 
+#ifdef GCDM_STAMPS          // (see STAMP in gcdm_kernels.hip.h)
 #define NSTAMP(i)                                                                                       \
     do {                                                                                                \
         if (ax.prof && lane == 0) ax.prof[((size_t)blockIdx.x * 8 + wave) * 24 + (i)] = (float)(__builtin_amdgcn_s_memtime() - t_start); \
     } while (0)
+#else
+#define NSTAMP(i) ((void)0)
+#endif
 
 // generic GCP2 pre-phase writing the extended-K rows as hi / lo' images (rows of [W_down; W_frames] split over the PARTS threads of an entity)
 template <int T, int H, int V_IN, int NTHR>

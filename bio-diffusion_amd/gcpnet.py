@@ -182,11 +182,15 @@ class GCPNetDynamics(nn.Module):
         self._plan_key = None
         self._flags = None
         # Range guard of the split-precision mode on the module-level call (plug point 1):
-        #   "deferred" (default): no host sync per call -- the device flag word of call k is copied to pinned host memory asynchronously and
-        #                         looked at when call k+1 (or read_flags / check_deferred_flags) comes; an activation beyond the f16 images
-        #                         (|x| > 1.2e8; trained models stay below 1e3) then raises F16RangeError and the handle falls back to fp32 MFMA;
-        #   True: one host sync per call, the call recomputes itself with fp32 MFMA (self-healing);   False: no check.
-        self.check_f16_range = "deferred"
+        #   True (default): one host sync per call, the call recomputes itself with fp32 MFMA when an activation left the f16 images
+        #                   (|x| > 1.2e8; trained models stay below 1e3) -- every output handed to a foreign caller has been checked;
+        #   "deferred":     no host sync per call -- the device flag word of call k is copied to pinned host memory asynchronously and looked at
+        #                   when call k+1 (or read_flags / check_deferred_flags) comes; an overflow then raises F16RangeError and the handle
+        #                   falls back to fp32 MFMA.  The LAST call of a sequence is only checked by check_deferred_flags(wait=True): this
+        #                   package's own drivers (ddpm.forward, sample_p_zs_given_zt + sample_p_xh_given_z0) select it per call
+        #                   (`_range_check="deferred"`) and do that final check before they return anything;
+        #   False:          no check.
+        self.check_f16_range = True
         self._flags_host = None
         self._flags_event = None
 
@@ -229,8 +233,12 @@ class GCPNetDynamics(nn.Module):
         _native.check(self._lib, h, st, "gcdm_create")
         self._weights_version = None
         self._plan_key = None
-        with torch.inference_mode(False):       # a normal tensor even when the handle is first created under inference_mode
+        with torch.inference_mode(False):       # normal tensors even when the handle is first created under inference_mode: the NLL path,
+            # sample_p_zs_given_zt and sample() run under @torch.inference_mode(), a later plain no_grad call must still be able to write them
             self._flags = torch.zeros(1, dtype=torch.int32, device=device)
+            self._flags_host = torch.zeros(1, dtype=torch.int32).pin_memory()
+        self._flags_event = torch.cuda.Event()
+        self._flags_pending = False
 
     def _params_fingerprint(self):
         return tuple(p._version for p in self.parameters()) + tuple(p.data_ptr() for p in self.parameters())
@@ -258,6 +266,7 @@ class GCPNetDynamics(nn.Module):
             key = key + (mk.numpy().tobytes(),)
         if key == self._plan_key:
             return
+        self._plan_key = None          # a rejected request leaves NO plan behind (the library drops the old one first)
         if mk is None:
             st = self._lib.gcdm_plan_batch(self._handle, len(nn_), C.c_void_p(nn_.data_ptr()))
         else:
@@ -286,17 +295,15 @@ class GCPNetDynamics(nn.Module):
         self.sync_weights()
         self._plan_from_batch_index(cfg_get(batch, "batch"), cfg_get(batch, "mask"))
         ctx = cfg_get(batch, "props_context") if self.condition_on_context else None
-        if self.check_f16_range == "deferred":
+        guard = kwargs.get("_range_check", self.check_f16_range)
+        if guard == "deferred":
             self.check_deferred_flags(wait=False)          # the previous call's flag word, if it has arrived
         out = self.native_forward(xh, t, ctx, xh_self_cond=sc)
-        if self.mfma_mode == 1 and self.check_f16_range == "deferred":
-            if self._flags_host is None:
-                self._flags_host = torch.zeros(1, dtype=torch.int32).pin_memory()
-                self._flags_event = torch.cuda.Event()
+        if self.mfma_mode == 1 and guard == "deferred":
             self._flags_host.copy_(self._flags, non_blocking=True)
             self._flags_event.record(torch.cuda.current_stream(xh.device))
             self._flags_pending = True
-        elif self.mfma_mode == 1 and self.check_f16_range:
+        elif self.mfma_mode == 1 and guard:
             # one host sync to make the module-level call self-healing (the fused sampler loop reads the flag once per run instead):
             # an activation beyond the f16 range -> recompute this call with fp32 MFMA
             if self.read_flags() & _native.FLAG_F16_RANGE:

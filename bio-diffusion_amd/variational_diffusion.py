@@ -29,6 +29,7 @@ from torch import nn
 
 from . import _native
 from .config import AttrDict, cfg_get
+from .gcpnet import F16RangeError
 
 log = logging.getLogger(__name__)
 
@@ -324,16 +325,24 @@ class EquivariantVariationalDiffusion(nn.Module):
         gamma_s, gamma_t = inflate_batch_array(self.gamma(s), x), inflate_batch_array(self.gamma(t), x)
         xh = torch.cat([x, h["categorical"]] + ([h["integer"].reshape(-1, 1)] if self.include_charges else []), dim=-1)
         z_t, eps_t = self.compute_noised_representation(xh, bi, mask, gamma_t, eps=None if noise is None else noise[0].to(dev))
-        _, net_out = self.dynamics_network(batch, z_t, t[bi], xh_self_cond=None)
-        error_t = self.sum_node_features_except_batch((eps_t - net_out) ** 2, bi, B)
-        SNR_weight = (self.SNR(gamma_s - gamma_t) - 1).squeeze(-1)
-        neg_log_constants = -self.log_constants_p_x_given_z0(num_nodes.to(dev), dev)
-        kl_prior = self.compute_kl_prior(xh, batch_index=bi, node_mask=mask, num_nodes=num_nodes.to(dev), device=dev)
         # L_0 from its own draw at t = 0 (second evaluation of the network, :1107-1128)
         t_zeros = torch.zeros_like(s)
         gamma_0 = inflate_batch_array(self.gamma(t_zeros), x)
         z_0, eps_0 = self.compute_noised_representation(xh, bi, mask, gamma_0, eps=None if noise is None else noise[1].to(dev))
-        _, net_out_0 = self.dynamics_network(batch, z_0, t_zeros[bi], xh_self_cond=None)
+
+        def two_evaluations():          # no host sync between them; ONE check of the range guard after both (one sync per batch)
+            a = self.dynamics_network(batch, z_t, t[bi], xh_self_cond=None, _range_check="deferred")[1]
+            b = self.dynamics_network(batch, z_0, t_zeros[bi], xh_self_cond=None, _range_check="deferred")[1]
+            self._final_range_check()
+            return a, b
+        try:
+            net_out, net_out_0 = two_evaluations()
+        except F16RangeError:           # an activation left the f16 images: the handle now runs fp32 MFMA, same inputs again
+            net_out, net_out_0 = two_evaluations()
+        error_t = self.sum_node_features_except_batch((eps_t - net_out) ** 2, bi, B)
+        SNR_weight = (self.SNR(gamma_s - gamma_t) - 1).squeeze(-1)
+        neg_log_constants = -self.log_constants_p_x_given_z0(num_nodes.to(dev), dev)
+        kl_prior = self.compute_kl_prior(xh, batch_index=bi, node_mask=mask, num_nodes=num_nodes.to(dev), device=dev)
         log_px, log_ph = self.log_pxh_given_z0_without_constants(h=h, z_0=z_0, eps=eps_0, net_out=net_out_0, gamma_0=gamma_0, batch_index=bi,
                                                                  node_mask=mask, device=dev)
         num_nodes = num_nodes.to(dev)
@@ -356,7 +365,9 @@ class EquivariantVariationalDiffusion(nn.Module):
         sigma_t = self.sigma(gamma_t, target_tensor=z)
         if batch is None:
             batch = _Batch(batch=batch_index, mask=node_mask, props_context=context)
-        _, eps_t = self.dynamics_network(batch, z, t[batch_index], x_self_cond=xh_self_cond, xh_self_cond=xh_self_cond)
+        # deferred range guard: the reference's loop calls this T times; call k looks at the flag word of call k-1 (no host sync), and
+        # sample_p_xh_given_z0 -- the call that ends every one of the reference's loops -- checks the last one before it returns samples
+        _, eps_t = self.dynamics_network(batch, z, t[batch_index], x_self_cond=xh_self_cond, xh_self_cond=xh_self_cond, _range_check="deferred")
         mu = z / alpha_t_given_s[batch_index] - (sigma2_t_given_s[batch_index] / alpha_t_given_s[batch_index] / sigma_t[batch_index]) * eps_t
         sigma = sigma_t_given_s * sigma_s / sigma_t
         if noise is not None:  # raw standard-normal draws [N,3+F] (x-part gets CoM-projected like the reference's sampler)
@@ -366,6 +377,55 @@ class EquivariantVariationalDiffusion(nn.Module):
         zs = self.sample_normal(mu, sigma, batch_index, node_mask, fix_noise=fix_noise, generate_x_only=generate_x_only, eps=noise)
         zs_x = _segment_mean_sub(zs[:, : self.num_x_dims], batch_index, int(s.shape[0]), node_mask)
         return zs_x if generate_x_only else torch.cat([zs_x, zs[:, self.num_x_dims:]], dim=-1)
+
+    def unnormalize(self, x, node_mask, h_cat=None, h_int=None, generate_x_only: bool = False):
+        """(:735-759)"""
+        nv, nb = cfg_get(self.diffusion_cfg, "norm_values"), cfg_get(self.diffusion_cfg, "norm_biases")
+        x = x * nv[0]
+        if generate_x_only:
+            return x, None, None
+        m = node_mask.float().unsqueeze(-1)
+        h_cat = (h_cat * nv[1] + nb[1]) * m
+        h_int = h_int * nv[2] + nb[2]
+        if self.include_charges:
+            h_int = h_int * m
+        return x, h_cat, h_int
+
+    @torch.inference_mode()
+    def sample_p_xh_given_z0(self, z_0, batch_index, node_mask, batch_size: int, batch=None, context=None, fix_noise: bool = False,
+                             generate_x_only: bool = False, xh_self_cond=None, noise: Optional[torch.Tensor] = None):
+        """x, h ~ p(x, h | z0) with the reference's signature (:839-907): the call that ends each of the reference's sampling loops.  One
+        network evaluation at t = 0 plus O(N) torch algebra; extension: ``noise`` = the raw standard-normal draw [N, 3 + F].  Before the
+        samples are returned the deferred range guard of this evaluation AND of the sample_p_zs_given_zt calls in front of it is checked
+        (one host sync); F16RangeError means the trajectory has to be re-run (the handle has been switched to fp32 MFMA)."""
+        if generate_x_only:
+            raise NotImplementedError("generate_x_only needs a network built for positions only; the reference's drivers never set it")
+        t_zeros = torch.zeros(size=(batch_size, 1), device=batch_index.device)
+        gamma_0 = self.gamma(t_zeros)
+        sigma_x = self.SNR(-0.5 * gamma_0)
+        if batch is None:
+            batch = _Batch(batch=batch_index, mask=node_mask, props_context=context)
+        _, net_out = self.dynamics_network(batch, z_0, t_zeros[batch_index], x_self_cond=xh_self_cond, xh_self_cond=xh_self_cond, _range_check="deferred")
+        mu_x = self.compute_x_pred(z_0, net_out, gamma_0, batch_index)
+        if noise is not None:
+            m = node_mask.float().unsqueeze(-1)
+            noise = torch.cat([_segment_mean_sub(noise[:, : self.num_x_dims] * m, batch_index, batch_size, node_mask), noise[:, self.num_x_dims:] * m], dim=-1)
+        xh = self.sample_normal(mu=mu_x, sigma=sigma_x, batch_index=batch_index, node_mask=node_mask, fix_noise=fix_noise, eps=noise)
+        x = xh[:, : self.num_x_dims]
+        h_cat = xh[:, self.num_x_dims:-1] if self.include_charges else xh[:, self.num_x_dims:]
+        h_int = xh[:, -1:] if self.include_charges else torch.zeros(0, device=x.device)
+        x, h_cat, h_int = self.unnormalize(x, node_mask, h_cat=h_cat, h_int=h_int)
+        h_cat = F.one_hot(torch.argmax(h_cat, dim=-1), self.num_atom_types) * node_mask.long().unsqueeze(-1)
+        h_int = torch.round(h_int).long() * node_mask.long().unsqueeze(-1)
+        self._final_range_check()
+        return x, {"integer": h_int, "categorical": h_cat}
+
+    def _final_range_check(self) -> None:
+        """Deferred range guard of the module-level calls (GCPNetDynamics.check_f16_range): the flag word of the LAST network evaluation is
+        looked at here, with one host sync, before a driver hands results to its caller.  Raises F16RangeError (handle switched to fp32)."""
+        chk = getattr(self.dynamics_network, "check_deferred_flags", None)
+        if chk is not None:
+            chk(wait=True)
 
     # ---- production loop (:1282-1412) ---------------------------------------------------------------
     def _native(self, device):

@@ -185,8 +185,8 @@ int gcdm_debug_set_layer_limit(gcdm_handle* h, int32_t num_layers_to_run);
  * A model with a matrix weight of magnitude >= 31.9 (the split images hold 2^11 W in f16) runs in mode 0 whatever was requested
  * (gcdm_get_option reports the effective mode) and setting mode 1 on it fails.
  * "edge_tile": edges per workgroup of the edge-message kernels: 64 (one 8-wave workgroup per CU), 32 (two 4-wave workgroups per CU) or
- * 0 = automatic (default; env GCDM_EDGE_TILE): 32 for the split-precision kernel at the QM9 edge width (rows of <= 32 edges), else 64
- * -- DESIGN.md 3.4.
+ * 0 = automatic (default; env GCDM_EDGE_TILE): 64 -- with the operand requests of the next k-blocks issued between the MFMAs of the
+ * current one the 64-edge tile (every weight byte read once per 64 edges) is the faster one for both edge widths, DESIGN.md 3.4.
  * "cog_fix": 1 (default) / 0, see gcdm_unnormalize_z.
  * "fix_noise" (0/1): the x-part of every noise draw is centred over the whole flat batch instead of per molecule, as the reference's
  * `fix_noise=True` does (variational_diffusion.py:832-834, 1323-1325; used by sample_sweep_conditionally, src/models/__init__.py:200-226).
@@ -201,7 +201,8 @@ int gcdm_get_option(const gcdm_handle* h, const char* name);
  * kernel, one launch per interaction layer) with HIP events on `stream`; gcdm_profile_edge_kernel_ms() synchronises on
  * them and returns the summed duration and the launch count of the LAST forward.  enable = 2 adds in-kernel phase time
  * stamps of that kernel (gcdm_debug_read "phase": [tiles][8 waves][24] shader-clock offsets), enable = 3 the same for the
- * per-layer node kernel ("phase_node": [node tiles][8][24]); both are diagnostics and slow the kernels slightly. */
+ * per-layer node kernel ("phase_node": [node tiles][8][24]); both are diagnostics that exist only in a library built with
+ * -DGCDM_STAMPS (the stamps cost issue slots even when switched off): enable >= 2 fails on the default build. */
 int gcdm_profile_enable(gcdm_handle* h, int32_t enable);
 int gcdm_profile_edge_kernel_ms(gcdm_handle* h, double* total_ms, int32_t* launches);
 

@@ -352,6 +352,31 @@ def test_checkpoint_unpickler_resolves_names_not_modules(tmp_path):
     for mod, name in (("builtins", "eval"), ("builtins", "exec"), ("builtins", "getattr"), ("builtins", "__import__"), ("os", "system"),
                       ("torch", "load"), ("torch.serialization", "load"), ("subprocess", "Popen"), ("numpy", "fromfile")):
         assert mg._StateDictUnpickler(open(os.devnull, "rb")).find_class(mod, name) is mg._Dummy, (mod, name)
+    # nested pickle: torch.storage._load_from_bytes is torch.load(BytesIO(b), weights_only=False) with the DEFAULT unpickler -- REDUCEd onto a
+    # bytes payload it would run an unrestricted inner pickle.  It is not on the whitelist (zip-format checkpoints never need it).
+    import io
+    inner = io.BytesIO()
+    pickle.dump(Evil(), inner)
+
+    class Nested:
+        def __reduce__(self):
+            return (torch.storage._load_from_bytes, (inner.getvalue(),))
+
+    for how in ("unpickler", "loader"):
+        p = tmp_path / "nested.ckpt"
+        with open(p, "wb") as f:
+            pickle.dump({"state_dict": {"w": Nested()}}, f)
+        if how == "unpickler":
+            with open(p, "rb") as f:
+                obj = mg._StateDictUnpickler(f).load()
+        else:
+            try:                       # (a bare pickle is not a torch file: torch.load may refuse it before any unpickling -- also fine)
+                obj = {"state_dict": mg.load_lightning_state_dict(str(p))}
+            except RuntimeError:
+                obj = None
+        assert not marker.exists(), how
+        assert obj is None or type(obj["state_dict"]["w"]).__name__ == "_Dummy"
+    assert mg._StateDictUnpickler(open(os.devnull, "rb")).find_class("torch.storage", "_load_from_bytes") is mg._Dummy
     good = tmp_path / "good.ckpt"
     sd = {"ddpm.x": torch.arange(6, dtype=torch.float32).view(2, 3), "ddpm.y": torch.nn.Parameter(torch.ones(3)), "n": torch.tensor(3)}
     torch.save({"state_dict": sd, "hyper_parameters": {"a": 1}}, good)

@@ -64,4 +64,13 @@ for i in range(K):
     lib.gcdm_sample_step(h, zp, None, 986 - i, 1000, None, sd, fp, st)
 ev[1].record()
 torch.cuda.synchronize()
-print(f"AB {tag} {case} edge_tile={lib.gcdm_get_option(h, b'edge_tile')} fwd={h_fwd} z3={h_z} ms_per_step={ev[0].elapsed_time(ev[1]) / K:.4f} flags={int(flags.item())}{rel}")
+# in-kernel phase stamps of the edge kernel (shader cycles: independent of the clock the box settles at)
+cyc = ""
+if os.environ.get("GCDM_AB_STAMPS", "1") != "0" and lib.gcdm_profile_enable(h, 2) == 0:
+    dyn.native_forward(xh.to(dev), t.to(dev))
+    torch.cuda.synchronize()
+    nw = 4 if lib.gcdm_get_option(h, b"edge_tile") == 32 else 8
+    ph = dyn.debug_read("phase").view(-1, 8, 24)[:, :nw].mean(dim=(0, 1))
+    lib.gcdm_profile_enable(h, 0)
+    cyc = " tile_cycles=%d phases=[%s]" % (ph[20], " ".join("%d:%d" % (i, ph[i]) for i in (1, 2, 4, 6, 7, 8, 9, 12, 14, 15, 16, 17, 18, 19, 20)))
+print(f"AB {tag} {case} edge_tile={lib.gcdm_get_option(h, b'edge_tile')} fwd={h_fwd} z3={h_z} ms_per_step={ev[0].elapsed_time(ev[1]) / K:.4f} flags={int(flags.item())}{rel}{cyc}")
