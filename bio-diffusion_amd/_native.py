@@ -10,8 +10,12 @@ from typing import Optional
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libgcdm_hip.so")
 SOURCES = [os.path.join(_HERE, "csrc", "gcdm_api.hip")]
-HEADERS = ([os.path.join(_HERE, "csrc", f) for f in sorted(os.listdir(os.path.join(_HERE, "csrc"))) if f.endswith(".h")]
+HEADERS = ([os.path.join(_HERE, "csrc", f) for f in sorted(os.listdir(os.path.join(_HERE, "csrc"))) if f.endswith(".h") and f != "gcdm_ops.hip.h"]
            + [os.path.join(os.path.dirname(_HERE), "include", "gcdm_hip.h")])
+# the module-level operators (forward + backward) live in their own small library (include/gcdm_ops.h)
+OPS_LIB_PATH = os.path.join(_HERE, "libgcdm_ops.so")
+OPS_SOURCES = [os.path.join(_HERE, "csrc", "gcdm_ops.hip")]
+OPS_HEADERS = [os.path.join(_HERE, "csrc", "gcdm_ops.hip.h"), os.path.join(os.path.dirname(_HERE), "include", "gcdm_ops.h")]
 ABI_VERSION = 2
 
 FLAG_NAN_VEL, FLAG_MEAN_NOT_ZERO, FLAG_COG_DRIFT, FLAG_F16_RANGE = 1, 2, 4, 8
@@ -71,6 +75,67 @@ def build(force: bool = False) -> str:
         if os.path.exists(tmp):
             os.remove(tmp)
     return LIB_PATH
+
+
+def build_ops(force: bool = False) -> str:
+    deps = OPS_SOURCES + OPS_HEADERS
+    if not force and os.path.exists(OPS_LIB_PATH) and all(os.path.getmtime(OPS_LIB_PATH) >= os.path.getmtime(d) for d in deps):
+        return OPS_LIB_PATH
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    tmp = f"{OPS_LIB_PATH}.{os.getpid()}.tmp"
+    try:
+        subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-o", tmp] + OPS_SOURCES, check=True)
+        os.replace(tmp, OPS_LIB_PATH)
+    finally:
+        if os.path.exists(tmp):
+            os.remove(tmp)
+    return OPS_LIB_PATH
+
+
+P, I32, I64 = C.c_void_p, C.c_int32, C.c_int64
+OPS_SIGNATURES = {
+    "gcdm_op_gemm": [P, I64, I64, P, I64, I64, P, P, I64, I32, I64, I32, P],
+    "gcdm_op_reduce_slices": [P, P, I64, I32, P],
+    "gcdm_op_colsum": [P, P, I64, I32, P],
+    "gcdm_op_act": [I32, P, P, I64, P],
+    "gcdm_op_act_bwd": [I32, P, P, P, I64, P],
+    "gcdm_op_norm3": [P, P, I64, I32, I32, P],
+    "gcdm_op_norm3_bwd": [P, P, P, P, I64, I32, I32, P],
+    "gcdm_op_scalarize": [P, P, P, I64, I32, P],
+    "gcdm_op_scalarize_bwd": [P, P, P, I64, I32, P],
+    "gcdm_op_vectorize": [P, P, P, I64, I32, P],
+    "gcdm_op_vectorize_bwd": [P, P, P, I64, I32, P],
+    "gcdm_op_rowscale": [P, P, P, I64, I32, P],
+    "gcdm_op_rowscale_bwd": [P, P, P, P, P, I64, I32, P],
+    "gcdm_op_rowptr": [P, I64, I64, P, P, P],
+    "gcdm_op_gather": [P, P, P, I64, I32, P],
+    "gcdm_op_segment_sum": [P, P, P, I64, I32, I32, P],
+    "gcdm_op_segment_bwd": [P, P, P, P, I64, I32, I32, P],
+    "gcdm_op_scatter_add": [P, P, P, I64, I32, P],
+    "gcdm_op_localize": [P, P, P, P, I64, I32, P],
+    "gcdm_op_edge_features": [P, P, P, P, P, I64, P],
+    "gcdm_op_orientations": [P, P, I64, P],
+    "gcdm_op_centralize": [P, P, P, P, I64, I32, P],
+    "gcdm_op_fc_edges": [P, P, I32, P, P, I64, P],
+}
+OPS_EXPORTS = list(OPS_SIGNATURES)
+_ops_lib: Optional[C.CDLL] = None
+
+
+def load_ops() -> C.CDLL:
+    """Loads libgcdm_ops.so (module-level operators); raises if it has not been built -- there is no eager / CPU fallback."""
+    global _ops_lib
+    if _ops_lib is not None:
+        return _ops_lib
+    if not os.path.exists(OPS_LIB_PATH):
+        raise RuntimeError(f"{OPS_LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` (hipcc --offload-arch=gfx950)")
+    lib = C.CDLL(OPS_LIB_PATH)
+    for name, sig in OPS_SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.argtypes = sig
+        fn.restype = C.c_int
+    _ops_lib = lib
+    return lib
 
 
 def load() -> C.CDLL:

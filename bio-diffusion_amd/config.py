@@ -140,8 +140,10 @@ def load_cfg_tree(config_root: str, dataset: str = "qm9", conditioning: Iterable
     sel = mod.pop("selected_GCP", None)
     if sel is not None:          # configs/model/module_cfg/*.yaml: {_target_: src.models.components.gcpnet.GCP2, _partial_: true}
         target = sel.get("_target_", "") if isinstance(sel, dict) else str(getattr(sel, "__name__", sel))
-        if target.rsplit(".", 1)[-1] != "GCP2":
-            raise NotImplementedError(f"module_cfg.selected_GCP = {target!r}: only GCP2 (the production module, gcpnet.py:265-491) is built")
+        name = target.rsplit(".", 1)[-1]
+        if name not in ("GCP", "GCP2"):
+            raise NotImplementedError(f"module_cfg.selected_GCP = {target!r}: expected GCP or GCP2 (gcpnet.py:33, 265)")
+        mod["selected_GCP"] = name   # GCP2 -> the fused kernels (production flags) or the module path; GCP -> the module path
     mod.pop("nonlinearities", None)
     keep_cond = cfgs["module_cfg"]["conditioning"]
     cfgs["module_cfg"].update(to_attr(mod))

@@ -2,11 +2,14 @@
 
 Mirrors (names, constructor keywords, ``forward`` signature, ``state_dict`` keys) of
 ``src/models/components/gcpnet.py``: ``GCP2`` (:265-491), ``GCPEmbedding`` (:494-603), ``GCPMessagePassing``
-(:618-737), ``GCPInteractions`` (:740-930) and ``GCPNetDynamics`` (:933-1232).  The sub-modules here are
-*parameter containers* whose attribute names reproduce the reference's state-dict keys (so a released
-``*-EMA.ckpt`` loads under the prefix ``ddpm.dynamics_network.``); all arithmetic of
-``GCPNetDynamics.forward`` happens in ``libgcdm_hip.so`` (HIP, gfx950) through the C ABI in
-``include/gcdm_hip.h``.  There is no eager / CPU fallback.
+(:618-737), ``GCPInteractions`` (:740-930) and ``GCPNetDynamics`` (:933-1232).  The sub-modules (gcp_modules.py) reproduce the
+reference's state-dict keys (so a released ``*-EMA.ckpt`` loads under the prefix ``ddpm.dynamics_network.``) and are callable.
+``GCPNetDynamics.forward`` has two HIP paths and no eager / CPU fallback:
+  * FUSED (libgcdm_hip.so, C ABI include/gcdm_hip.h): the production configuration, evaluation / sampling -- ~25 launches per call;
+  * MODULES (libgcdm_ops.so, C ABI include/gcdm_ops.h): the reference's module graph composed of this repository's forward / backward
+    operators -- every flag and width of the Hydra surface, and training with autograd.
+``GCPNetDynamics.path`` ("auto" | "fused" | "modules") selects; "auto" takes the fused path whenever the configuration allows it and no
+gradient is being recorded.
 """
 from __future__ import annotations
 
@@ -22,112 +25,8 @@ from .config import cfg_get
 NODE_FEATURE_DIFFUSION_TARGETS = ["atom_types_and_coords"]
 
 
-def _fused_only(name):
-    raise NotImplementedError(
-        f"{name}.forward is not a stand-alone op in bio-diffusion_amd: the GCP2 blocks are fused into the HIP kernels "
-        "driven by GCPNetDynamics.forward (libgcdm_hip.so).")
-
-
-class GCP2(nn.Module):
-    """Parameter container with the reference's GCP2 layout (gcpnet.py:286-348); production flags only
-    (vector_gate=True, frame_gate=False, no residuals, no ablations)."""
-
-    def __init__(self, input_dims, output_dims, nonlinearities=("silu", "silu"), scalar_out_nonlinearity="silu",
-                 scalar_gate: int = 0, vector_gate: bool = True, frame_gate: bool = False, sigma_frame_gate: bool = False,
-                 feedforward_out: bool = False, bottleneck: int = 1, vector_residual: bool = False,
-                 vector_frame_residual: bool = False, ablate_frame_updates: bool = False, ablate_scalars: bool = False,
-                 ablate_vectors: bool = False, scalarization_vectorization_output_dim: int = 3, **kwargs):
-        super().__init__()
-        if (frame_gate or not vector_gate or vector_residual or ablate_frame_updates or ablate_scalars or ablate_vectors
-                or scalar_gate or scalarization_vectorization_output_dim != 3):
-            raise NotImplementedError("bio-diffusion_amd builds the production GCP2 variant only "
-                                      "(vector_gate, no frame_gate / residual / ablation / scalar_gate)")
-        self.scalar_input_dim, self.vector_input_dim = input_dims
-        self.scalar_output_dim, self.vector_output_dim = output_dims
-        self.nonlinearities = tuple(nonlinearities) if nonlinearities is not None else (None, None)
-        self.feedforward_out = feedforward_out
-        self.bottleneck = bottleneck
-        if not self.vector_input_dim:
-            raise NotImplementedError("scalar-only GCP2 is not on the GCDM sampling path")
-        assert self.vector_input_dim % bottleneck == 0
-        self.hidden_dim = (self.vector_input_dim // bottleneck if bottleneck > 1
-                           else max(self.vector_input_dim, self.vector_output_dim))
-        k = self.hidden_dim + self.scalar_input_dim + 9
-        self.vector_down = nn.Linear(self.vector_input_dim, self.hidden_dim, bias=False)
-        self.scalar_out = (nn.Sequential(nn.Linear(k, self.scalar_output_dim), nn.SiLU(),
-                                         nn.Linear(self.scalar_output_dim, self.scalar_output_dim))
-                           if feedforward_out else nn.Linear(k, self.scalar_output_dim))
-        self.vector_down_frames = nn.Linear(self.vector_input_dim, 3, bias=False)
-        if self.vector_output_dim:
-            self.vector_up = nn.Linear(self.hidden_dim, self.vector_output_dim, bias=False)
-            self.vector_out_scale = nn.Linear(self.scalar_output_dim, self.vector_output_dim)
-
-    def forward(self, *a, **k):
-        _fused_only("GCP2")
-
-
-def _gcp_from_cfg(cfg, input_dims, output_dims, **kw) -> GCP2:
-    """get_GCP_with_custom_cfg (gcpnet.py:606-615) for the production flags."""
-    args = dict(nonlinearities=cfg_get(cfg, "nonlinearities"), scalar_gate=cfg_get(cfg, "scalar_gate", 0),
-                vector_gate=cfg_get(cfg, "vector_gate", True), frame_gate=cfg_get(cfg, "frame_gate", False),
-                sigma_frame_gate=cfg_get(cfg, "sigma_frame_gate", False), bottleneck=cfg_get(cfg, "bottleneck", 4),
-                vector_residual=cfg_get(cfg, "vector_residual", False),
-                vector_frame_residual=cfg_get(cfg, "vector_frame_residual", False),
-                ablate_frame_updates=cfg_get(cfg, "ablate_frame_updates", False),
-                ablate_scalars=cfg_get(cfg, "ablate_scalars", False), ablate_vectors=cfg_get(cfg, "ablate_vectors", False))
-    args.update(kw)
-    return GCP2(input_dims, output_dims, **args)
-
-
-class GCPEmbedding(nn.Module):
-    def __init__(self, edge_input_dims, node_input_dims, edge_hidden_dims, node_hidden_dims, cfg):
-        super().__init__()
-        nl = cfg_get(cfg, "nonlinearities")
-        self.edge_embedding = _gcp_from_cfg(cfg, edge_input_dims, edge_hidden_dims, nonlinearities=nl, bottleneck=1)
-        self.node_embedding = _gcp_from_cfg(cfg, node_input_dims, node_hidden_dims, nonlinearities=(None, None), bottleneck=1)
-
-    def forward(self, *a, **k):
-        _fused_only("GCPEmbedding")
-
-
-class GCPMessagePassing(nn.Module):
-    def __init__(self, input_dims, output_dims, edge_dims, cfg, mp_cfg):
-        super().__init__()
-        s_in, v_in = input_dims
-        e_s, e_v = edge_dims
-        n_msg = cfg_get(mp_cfg, "num_message_layers", 4)
-        if n_msg != 4 or not cfg_get(mp_cfg, "use_residual_message_gcp", True):
-            raise NotImplementedError("bio-diffusion_amd builds num_message_layers=4 with residual message GCPs")
-        bn = cfg_get(cfg, "default_bottleneck", 4)
-        mods = [_gcp_from_cfg(cfg, (2 * s_in + e_s, 2 * v_in + e_v), output_dims, bottleneck=bn)]
-        for _ in range(n_msg - 2):
-            mods.append(_gcp_from_cfg(cfg, output_dims, output_dims))
-        mods.append(_gcp_from_cfg(cfg, output_dims, output_dims, bottleneck=bn))
-        self.message_fusion = nn.ModuleList(mods)
-        self.scalar_message_attention = nn.Sequential(nn.Linear(output_dims[0], 1), nn.Sigmoid())
-
-    def forward(self, *a, **k):
-        _fused_only("GCPMessagePassing")
-
-
-class GCPInteractions(nn.Module):
-    def __init__(self, node_dims, edge_dims, cfg, layer_cfg):
-        super().__init__()
-        if (cfg_get(layer_cfg, "pre_norm", False) or cfg_get(layer_cfg, "use_gcp_norm", False)
-                or cfg_get(layer_cfg, "use_gcp_dropout", False) or cfg_get(layer_cfg, "num_feedforward_layers", 1) != 1
-                or not cfg_get(layer_cfg, "use_scalar_message_attention", True)):
-            raise NotImplementedError("bio-diffusion_amd builds the production interaction layer only "
-                                      "(no norm / dropout, one feed-forward GCP2, scalar message attention)")
-        if cfg_get(cfg, "update_positions_with_vector_sum", False):
-            raise NotImplementedError("update_positions_with_vector_sum is not built")
-        self.interaction = GCPMessagePassing(node_dims, node_dims, edge_dims, cfg, cfg_get(layer_cfg, "mp_cfg"))
-        s, v = node_dims
-        self.feedforward_network = nn.ModuleList([
-            _gcp_from_cfg(cfg, (2 * s, 2 * v), (s, v), nonlinearities=(None, None), feedforward_out=True, vector_residual=False)])
-        self.node_position_update_gcp = _gcp_from_cfg(cfg, node_dims, (s, 1), vector_residual=False)
-
-    def forward(self, *a, **k):
-        _fused_only("GCPInteractions")
+from .gcp_modules import (GCP, GCP2, GCPDropout, GCPEmbedding, GCPInteractions, GCPLayerNorm, GCPMessagePassing,   # noqa: F401,E402
+                          get_GCP_with_custom_cfg, selected_gcp_class, _embedding_gcp)
 
 
 class F16RangeError(RuntimeError):
@@ -160,20 +59,27 @@ class GCPNetDynamics(nn.Module):
         self.edge_input_dims = (int(cfg_get(model_cfg, "e_input_dim", 1)) * mult, int(cfg_get(model_cfg, "xi_input_dim", 1)) * mult)
         self.node_input_dims = (h_in + (h_diff if self.self_condition else 0), int(cfg_get(model_cfg, "chi_input_dim", 2)) * mult)
         if self.edge_input_dims != (mult, mult) or self.node_input_dims[1] != 2 * mult:
-            raise NotImplementedError("only e_input_dim = xi_input_dim = 1, chi_input_dim = 2 are built")
+            raise NotImplementedError("e_input_dim = xi_input_dim = 1 and chi_input_dim = 2 are what the featuriser of the dynamics produces "
+                                      "(squared distance, unit vector, two orientation vectors: gcpnet.py:1105-1109)")
         self.edge_dims = (int(cfg_get(model_cfg, "e_hidden_dim")), int(cfg_get(model_cfg, "xi_hidden_dim")))
         self.node_dims = (int(cfg_get(model_cfg, "h_hidden_dim")), int(cfg_get(model_cfg, "chi_hidden_dim")))
         self.num_layers = int(cfg_get(model_cfg, "num_encoder_layers"))
         self.bottleneck = int(cfg_get(module_cfg, "bottleneck", 4))
         self.node_positions_weight = float(cfg_get(module_cfg, "node_positions_weight", 1.0))
-        if not cfg_get(module_cfg, "norm_x_diff", True):
-            raise NotImplementedError("norm_x_diff=False is not built")
+        self.norm_x_diff = bool(cfg_get(module_cfg, "norm_x_diff", True))
         self._diffusion_cfg = diffusion_cfg
 
-        self.gcp_embedding = GCPEmbedding(self.edge_input_dims, self.node_input_dims, self.edge_dims, self.node_dims, module_cfg)
+        self.gcp_embedding = GCPEmbedding(self.edge_input_dims, self.node_input_dims, self.edge_dims, self.node_dims, num_atom_types=0,
+                                          nonlinearities=cfg_get(module_cfg, "nonlinearities") or ("silu", "silu"), cfg=module_cfg,
+                                          use_gcp_norm=cfg_get(layer_cfg, "use_gcp_norm", False))
         self.interaction_layers = nn.ModuleList(
-            GCPInteractions(self.node_dims, self.edge_dims, module_cfg, layer_cfg) for _ in range(self.num_layers))
-        self.scalar_node_projection_gcp = _gcp_from_cfg(module_cfg, self.node_dims, (h_in, 0), nonlinearities=(None, None), bottleneck=1)
+            GCPInteractions(self.node_dims, self.edge_dims, cfg=module_cfg, layer_cfg=layer_cfg, dropout=float(cfg_get(model_cfg, "dropout", 0.0)),
+                            update_node_positions=True) for _ in range(self.num_layers))
+        self.scalar_node_projection_gcp = _embedding_gcp(module_cfg, self.node_dims, (h_in, 0), (None, None))
+        # Which path evaluates forward(): "auto" = the fused sampling kernels when the configuration is the one they are built for and no
+        # gradient is recorded, the module graph (HIP operators, autograd) otherwise; "fused" / "modules" force one.
+        self.path = "auto"
+        self.fused_unsupported = self._why_not_fused(model_cfg, module_cfg, layer_cfg)
 
         # native state (created lazily on the first forward, on the tensors' device)
         self._lib = None
@@ -195,6 +101,98 @@ class GCPNetDynamics(nn.Module):
         self._flags_event = None
 
     # ------------------------------------------------------------------------------------------
+    def _why_not_fused(self, model_cfg, module_cfg, layer_cfg):
+        """None if libgcdm_hip.so's fused kernels implement this configuration (the reference's production YAMLs and what varies between
+        its datasets), else the first reason they do not -- such models run on the module path."""
+        mp = cfg_get(layer_cfg, "mp_cfg")
+        nl = cfg_get(module_cfg, "nonlinearities") or (None, None)
+        checks = [
+            (selected_gcp_class(module_cfg) is GCP2, "module_cfg.selected_GCP is not GCP2"),
+            (bool(cfg_get(module_cfg, "vector_gate", True)) and not cfg_get(module_cfg, "frame_gate", False), "vector_gate / frame_gate"),
+            (not cfg_get(module_cfg, "vector_residual", False) and not cfg_get(module_cfg, "default_vector_residual", False), "vector residuals"),
+            (not (cfg_get(module_cfg, "ablate_frame_updates", False) or cfg_get(module_cfg, "ablate_scalars", False) or cfg_get(module_cfg, "ablate_vectors", False)),
+             "ablation flags"),
+            (tuple(str(n).lower() for n in nl) == ("silu", "silu"), "nonlinearities other than silu"),
+            (int(cfg_get(module_cfg, "bottleneck", 4)) == 4 and int(cfg_get(module_cfg, "default_bottleneck", 4)) == 4, "bottleneck != 4"),
+            (self.norm_x_diff, "norm_x_diff = False"),
+            (not cfg_get(module_cfg, "update_positions_with_vector_sum", False), "update_positions_with_vector_sum"),
+            (int(cfg_get(mp, "num_message_layers", 4)) == 4 and bool(cfg_get(mp, "use_residual_message_gcp", True)), "mp_cfg: 4 residual message GCPs"),
+            (bool(cfg_get(layer_cfg, "use_scalar_message_attention", True)), "no scalar message attention"),
+            (int(cfg_get(layer_cfg, "num_feedforward_layers", 1)) == 1, "num_feedforward_layers != 1"),
+            (not cfg_get(layer_cfg, "use_gcp_norm", False), "use_gcp_norm"),
+            (self.node_dims == (256, 32) and self.edge_dims in ((64, 16), (16, 8)), f"hidden sizes {self.node_dims} / {self.edge_dims}"),
+        ]
+        for ok, why in checks:
+            if not ok:
+                return why
+        return None
+
+    def _dropout_active(self) -> bool:
+        return self.training and any(l.gcp_dropout[0].use_gcp_dropout and l.gcp_dropout[0].drop_rate > 0 for l in self.interaction_layers)
+
+    def _use_modules(self, xh: torch.Tensor) -> bool:
+        if self.path == "modules":
+            return True
+        recording = torch.is_grad_enabled() and (xh.requires_grad or (self.training and any(p.requires_grad for p in self.parameters())))
+        if self.path == "fused":
+            if self.fused_unsupported is not None:
+                raise NotImplementedError(f"path='fused': the fused kernels do not implement this configuration ({self.fused_unsupported})")
+            if recording:
+                raise RuntimeError("path='fused' has no backward pass; use path='auto' or 'modules' for training")
+            return False
+        return self.fused_unsupported is not None or recording or self._dropout_active()
+
+    def forward_modules(self, batch: Any, xh: torch.Tensor, t: torch.Tensor, xh_self_cond: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """atom_types_and_coords_forward (gcpnet.py:1069-1232) as the reference evaluates it -- module by module -- on this repository's HIP
+        operators (ops.py), differentiable.  Any configuration; ~10^2 launches per layer, so sampling prefers the fused path."""
+        from . import ops
+        from .config import AttrDict
+        nx = self.num_x_dims
+        bi = cfg_get(batch, "batch")
+        mask = cfg_get(batch, "mask")
+        if mask is None:
+            mask = torch.ones_like(bi, dtype=torch.bool)
+        mf = mask.to(torch.float32).unsqueeze(-1)
+        xh = xh.to(torch.float32) * mf
+        x_init, h = xh[:, :nx].contiguous(), xh[:, nx:]
+        N = xh.shape[0]
+        counts = torch.unique_consecutive(bi, return_counts=True)[1]
+        edge_index = ops.fully_connected_edge_index(counts.cpu(), xh.device)
+        full_mask = bool(mask.all())
+        if not full_mask:                                        # edges of masked nodes do not exist (gcpnet.py:1062-1065)
+            edge_index = edge_index[:, mask[edge_index[0]] & mask[edge_index[1]]].contiguous()
+        chi = ops.orientations(x_init)
+        e, xi = ops.edge_features(x_init, edge_index)
+        if self.self_condition:
+            sc = torch.zeros_like(xh) if xh_self_cond is None else xh_self_cond.to(torch.float32)
+            x_sc = sc[:, :nx].contiguous()
+            e_sc, xi_sc = ops.edge_features(x_sc, edge_index)
+            h = torch.cat((h, sc[:, nx:]), dim=-1)
+            chi = torch.cat((chi, ops.orientations(x_sc)), dim=1)
+            e, xi = torch.cat((e, e_sc), dim=-1), torch.cat((xi, xi_sc), dim=1)
+        if self.condition_on_time:
+            tt = t.to(torch.float32).reshape(-1, 1)
+            h = torch.cat((h, tt.expand(N, 1) if tt.numel() == 1 else tt), dim=-1)
+        if self.condition_on_context:
+            h = torch.cat((h, cfg_get(batch, "props_context").to(torch.float32).reshape(N, self.num_context_node_features)), dim=-1)
+        x = ops.centralize(x_init, bi, mask)
+        f_ij = ops.localize(x, edge_index, self.norm_x_diff)
+        node_mask = None if full_mask else mask
+        b = AttrDict(h=h, chi=chi, e=e, xi=xi, edge_index=edge_index, f_ij=f_ij, mask=node_mask)
+        (hh, cc), (ee, xx) = self.gcp_embedding(b)
+        for layer in self.interaction_layers:
+            (hh, cc), x = layer((hh, cc), (ee, xx), edge_index, f_ij, node_mask=node_mask, node_pos=x)
+        h_out = self.scalar_node_projection_gcp((hh, cc), edge_index, f_ij, node_inputs=True, node_mask=node_mask)
+        vel = (x - x_init) * mf
+        if self.condition_on_context:
+            h_out = h_out[:, : -self.num_context_node_features]
+        if self.condition_on_time:
+            h_out = h_out[:, :-1]
+        if bool(vel.isnan().any()):                                  # gcpnet.py:1213-1216
+            vel = torch.zeros_like(vel)
+        vel = ops.centralize(vel, bi, mask)
+        return torch.cat((vel, h_out), dim=-1)
+
     def _native_config(self, device_index: int) -> "_native.GcdmConfig":
         dc = self._diffusion_cfg
         nv = list(cfg_get(dc, "norm_values", [1.0, 4.0, 10.0]))
@@ -291,6 +289,10 @@ class GCPNetDynamics(nn.Module):
         sc = kwargs.get("xh_self_cond")
         if sc is not None and not self.self_condition:
             sc = None                  # as the reference: the input is ignored unless diffusion_cfg.self_condition (gcpnet.py:1112)
+        if self._use_modules(xh):
+            if xh.device.type != "cuda":
+                raise RuntimeError("GCPNetDynamics (bio-diffusion_amd) runs on an MI355X only: tensors must be on a HIP ('cuda') device; there is no CPU fallback")
+            return batch, self.forward_modules(batch, xh, t, xh_self_cond=sc)
         self._ensure_handle(xh.device)
         self.sync_weights()
         self._plan_from_batch_index(cfg_get(batch, "batch"), cfg_get(batch, "mask"))

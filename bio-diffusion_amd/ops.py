@@ -1,0 +1,402 @@
+"""Module-level operators of the GCPNet block on MI355X: thin autograd wrappers around libgcdm_ops.so (include/gcdm_ops.h).
+
+Every function here launches HIP kernels -- forward in ``forward``, the backward twin in ``backward`` -- on the tensors' device and the
+current stream; there is no torch / CPU fallback (a CPU tensor raises).  The Python mirrors in ``gcpnet.py`` compose these exactly where
+the reference composes torch ops (src/models/components/gcpnet.py:33-491, 618-930; components/__init__.py:123-286), which is what makes
+``selected_GCP(...)(s_maybe_v, edge_index, frames, ...)`` callable (plug point 3), the non-production configurations loadable, and the
+training objective differentiable.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Tuple
+
+import torch
+
+from . import _native
+
+ACT_KINDS = {None: 0, "none": 0, "identity": 0, "silu": 1, "swish": 1, "relu": 2, "sigmoid": 3, "leakyrelu": 4, "selu": 5}
+
+
+def _lib():
+    return _native.load_ops()
+
+
+def _chk(status: int, what: str) -> None:
+    if status != 0:
+        raise _native.NativeError(f"{what} failed with status {status} (libgcdm_ops.so)")
+
+
+def _dev(t: torch.Tensor) -> None:
+    if t.device.type != "cuda":
+        raise RuntimeError("bio-diffusion_amd operators run on an MI355X only: tensors must be on a HIP ('cuda') device; there is no CPU fallback")
+
+
+def _f(t: torch.Tensor) -> torch.Tensor:
+    _dev(t)
+    return t.detach().to(torch.float32).contiguous()
+
+
+def _p(t: Optional[torch.Tensor]):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _st(t: torch.Tensor):
+    return C.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+
+
+def _gemm(A: torch.Tensor, sam: int, sak: int, B: torch.Tensor, sbk: int, sbn: int, M: int, N: int, K: int, bias: Optional[torch.Tensor] = None,
+          split: bool = False) -> torch.Tensor:
+    out = torch.empty((M, N), dtype=torch.float32, device=A.device)
+    if M == 0 or N == 0:
+        return out
+    if K == 0:
+        out.zero_()
+        if bias is not None:
+            out += bias
+        return out
+    slices = 1
+    if split:                       # contraction over the entities (dW): enough slices to fill the chip, reduced in slice order
+        tiles = ((M + 63) // 64) * ((N + 63) // 64)
+        slices = max(1, min(64, 1024 // max(tiles, 1), (K + 511) // 512))
+    if slices == 1:
+        _chk(_lib().gcdm_op_gemm(_p(A), sam, sak, _p(B), sbk, sbn, _p(out), _p(bias), M, N, K, 1, _st(A)), "gcdm_op_gemm")
+        return out
+    part = torch.empty((slices, M, N), dtype=torch.float32, device=A.device)
+    _chk(_lib().gcdm_op_gemm(_p(A), sam, sak, _p(B), sbk, sbn, _p(part), _p(bias), M, N, K, slices, _st(A)), "gcdm_op_gemm")
+    _chk(_lib().gcdm_op_reduce_slices(_p(part), _p(out), M * N, slices, _st(A)), "gcdm_op_reduce_slices")
+    return out
+
+
+class _Linear(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, b):
+        xs = _f(x).reshape(-1, x.shape[-1])
+        ws = _f(w)
+        bs = None if b is None else _f(b)
+        M, K, N = xs.shape[0], xs.shape[1], ws.shape[0]
+        y = _gemm(xs, K, 1, ws, 1, K, M, N, K, bs)                       # B(k, n) = W[n][k]
+        ctx.save_for_backward(xs, ws)
+        ctx.has_bias = b is not None
+        ctx.lead = x.shape[:-1]
+        return y.reshape(*x.shape[:-1], N)
+
+    @staticmethod
+    def backward(ctx, dy):
+        xs, ws = ctx.saved_tensors
+        M, K, N = xs.shape[0], xs.shape[1], ws.shape[0]
+        g = _f(dy).reshape(M, N)
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = _gemm(g, N, 1, ws, K, 1, M, K, N).reshape(*ctx.lead, K)                 # dx = dy W
+        if ctx.needs_input_grad[1]:
+            dw = _gemm(g, 1, N, xs, K, 1, N, K, M, split=True)                            # dW = dy^T x  (A(n, m) = dy[m][n])
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = torch.empty(N, dtype=torch.float32, device=g.device)
+            _chk(_lib().gcdm_op_colsum(_p(g), _p(db), M, N, _st(g)), "gcdm_op_colsum")
+        return dx, dw, db
+
+
+def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """``nn.Linear`` on the last axis: y = x W^T + b (fp32 MFMA)."""
+    return _Linear.apply(x, weight, bias)
+
+
+class _Act(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, kind):
+        xs = _f(x)
+        y = torch.empty_like(xs)
+        _chk(_lib().gcdm_op_act(kind, _p(xs), _p(y), xs.numel(), _st(xs)), "gcdm_op_act")
+        ctx.save_for_backward(xs)
+        ctx.kind = kind
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (xs,) = ctx.saved_tensors
+        g = _f(dy)
+        dx = torch.empty_like(xs)
+        _chk(_lib().gcdm_op_act_bwd(ctx.kind, _p(xs), _p(g), _p(dx), xs.numel(), _st(xs)), "gcdm_op_act_bwd")
+        return dx, None
+
+
+def act(x: torch.Tensor, name) -> torch.Tensor:
+    """get_nonlinearity(name) of the reference (relu / leakyrelu / selu / silu / swish), 'sigmoid', or None = identity."""
+    key = name.lower() if isinstance(name, str) else name
+    if key not in ACT_KINDS:
+        raise NotImplementedError(f"nonlinearity {name!r}")
+    kind = ACT_KINDS[key]
+    return x if kind == 0 else _Act.apply(x, kind)
+
+
+class _Norm3(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, v, rep_layout):
+        vs = _f(v)
+        M = vs.shape[0]
+        Cn = vs.shape[1] if rep_layout else vs.shape[2]
+        out = torch.empty((M, Cn), dtype=torch.float32, device=vs.device)
+        _chk(_lib().gcdm_op_norm3(_p(vs), _p(out), M, Cn, int(rep_layout), _st(vs)), "gcdm_op_norm3")
+        ctx.save_for_backward(vs, out)
+        ctx.rep = int(rep_layout)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        vs, out = ctx.saved_tensors
+        g = _f(dout)
+        dv = torch.empty_like(vs)
+        M, Cn = out.shape
+        _chk(_lib().gcdm_op_norm3_bwd(_p(vs), _p(out), _p(g), _p(dv), M, Cn, ctx.rep, _st(vs)), "gcdm_op_norm3_bwd")
+        return dv, None
+
+
+def safe_norm_pre(v_pre: torch.Tensor) -> torch.Tensor:
+    """safe_norm(v, dim=-2) of a vector tensor in the "pre" layout [M, 3, C] -> [M, C]."""
+    return _Norm3.apply(v_pre, False)
+
+
+def safe_norm_rep(v_rep: torch.Tensor) -> torch.Tensor:
+    """safe_norm(v, dim=-1) of a vector tensor in the "rep" layout [M, C, 3] -> [M, C]."""
+    return _Norm3.apply(v_rep, True)
+
+
+class _Scalarize(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, u_pre, F):
+        us, Fs = _f(u_pre), _f(F).reshape(-1, 9)
+        M, CH = us.shape[0], us.shape[2]
+        out = torch.empty((M, 3 * CH), dtype=torch.float32, device=us.device)
+        _chk(_lib().gcdm_op_scalarize(_p(us), _p(Fs), _p(out), M, CH, _st(us)), "gcdm_op_scalarize")
+        ctx.save_for_backward(Fs)
+        ctx.CH = CH
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        (Fs,) = ctx.saved_tensors
+        g = _f(dout)
+        M = g.shape[0]
+        du = torch.empty((M, 3, ctx.CH), dtype=torch.float32, device=g.device)
+        _chk(_lib().gcdm_op_scalarize_bwd(_p(g), _p(Fs), _p(du), M, ctx.CH, _st(g)), "gcdm_op_scalarize_bwd")
+        return du, None
+
+
+def scalarize(u_pre: torch.Tensor, entity_frames: torch.Tensor) -> torch.Tensor:
+    """u_pre [M, 3, CH] against one frame per entity [M, 3, 3] -> [M, 3 CH] in the reference's order (3 c + r).  Edge mode: the edge's
+    frame; node mode: the mean of the frames of the node's edges (``mean_frames``)."""
+    return _Scalarize.apply(u_pre, entity_frames)
+
+
+class _Vectorize(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, gate, F):
+        gs, Fs = _f(gate), _f(F).reshape(-1, 9)
+        M, KC = gs.shape[0], gs.shape[1] // 3
+        out = torch.empty((M, KC, 3), dtype=torch.float32, device=gs.device)
+        _chk(_lib().gcdm_op_vectorize(_p(gs), _p(Fs), _p(out), M, KC, _st(gs)), "gcdm_op_vectorize")
+        ctx.save_for_backward(Fs)
+        ctx.KC = KC
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        (Fs,) = ctx.saved_tensors
+        g = _f(dout)
+        M = g.shape[0]
+        dgate = torch.empty((M, 3 * ctx.KC), dtype=torch.float32, device=g.device)
+        _chk(_lib().gcdm_op_vectorize_bwd(_p(g), _p(Fs), _p(dgate), M, ctx.KC, _st(g)), "gcdm_op_vectorize_bwd")
+        return dgate, None
+
+
+def vectorize(gate: torch.Tensor, entity_frames: torch.Tensor) -> torch.Tensor:
+    """gate [M, 3 K] -> vectors [M, K, 3]: gate[3k] a + gate[3k+1] b + gate[3k+2] c with (a, b, c) the rows of the entity's frame."""
+    return _Vectorize.apply(gate, entity_frames)
+
+
+class _RowScale(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, v_rep, g):
+        vs, gs = _f(v_rep), _f(g)
+        M, Cn = vs.shape[0], vs.shape[1]
+        out = torch.empty_like(vs)
+        _chk(_lib().gcdm_op_rowscale(_p(vs), _p(gs), _p(out), M, Cn, _st(vs)), "gcdm_op_rowscale")
+        ctx.save_for_backward(vs, gs)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        vs, gs = ctx.saved_tensors
+        d = _f(dout)
+        dv, dg = torch.empty_like(vs), torch.empty_like(gs)
+        _chk(_lib().gcdm_op_rowscale_bwd(_p(vs), _p(gs), _p(d), _p(dv), _p(dg), vs.shape[0], vs.shape[1], _st(vs)), "gcdm_op_rowscale_bwd")
+        return dv, dg
+
+
+def rowscale(v_rep: torch.Tensor, g: torch.Tensor) -> torch.Tensor:
+    """v_rep [M, C, 3] * g [M, C] (or [M, C, 1])."""
+    return _RowScale.apply(v_rep, g.reshape(g.shape[0], -1))
+
+
+# ---- graph plumbing ---------------------------------------------------------------------------------------------------------------------
+class Graph:
+    """CSR view of a row-sorted edge list (what get_fully_connected_edge_index produces): rowptr on the device, built once per edge_index."""
+
+    def __init__(self, edge_index: torch.Tensor, num_nodes: int):
+        _dev(edge_index)
+        self.row = edge_index[0].to(torch.int64).contiguous()
+        self.col = edge_index[1].to(torch.int64).contiguous()
+        self.N, self.E = int(num_nodes), int(self.row.shape[0])
+        self.rowptr = torch.empty(self.N + 1, dtype=torch.int32, device=self.row.device)
+        flag = torch.zeros(1, dtype=torch.int32, device=self.row.device)
+        _chk(_lib().gcdm_op_rowptr(_p(self.row), self.E, self.N, _p(self.rowptr), _p(flag), _st(self.row)), "gcdm_op_rowptr")
+        if int(flag.item()) & 1:
+            raise ValueError("edge_index must be sorted by its first row (source node), as get_fully_connected_edge_index produces it")
+
+
+_GRAPH_CACHE = {}
+
+
+def graph_of(edge_index: torch.Tensor, num_nodes: int) -> Graph:
+    key = (edge_index.data_ptr(), tuple(edge_index.shape), edge_index._version, int(num_nodes))
+    g = _GRAPH_CACHE.get("g")
+    if g is None or _GRAPH_CACHE.get("key") != key:
+        g = Graph(edge_index, num_nodes)
+        _GRAPH_CACHE["g"], _GRAPH_CACHE["key"], _GRAPH_CACHE["keep"] = g, key, edge_index
+    return g
+
+
+class _Gather(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, graph, by_row):
+        xs = _f(x).reshape(x.shape[0], -1)
+        idx = graph.row if by_row else graph.col
+        out = torch.empty((graph.E, xs.shape[1]), dtype=torch.float32, device=xs.device)
+        _chk(_lib().gcdm_op_gather(_p(xs), _p(idx), _p(out), graph.E, xs.shape[1], _st(xs)), "gcdm_op_gather")
+        ctx.graph, ctx.by_row, ctx.shape = graph, by_row, x.shape
+        return out.reshape(graph.E, *x.shape[1:])
+
+    @staticmethod
+    def backward(ctx, dout):
+        g = _f(dout).reshape(ctx.graph.E, -1)
+        Cn = g.shape[1]
+        if ctx.by_row:           # sorted index: a deterministic segment sum
+            dx = torch.empty((ctx.graph.N, Cn), dtype=torch.float32, device=g.device)
+            _chk(_lib().gcdm_op_segment_sum(_p(g), _p(ctx.graph.rowptr), _p(dx), ctx.graph.N, Cn, 0, _st(g)), "gcdm_op_segment_sum")
+        else:
+            dx = torch.zeros((ctx.graph.N, Cn), dtype=torch.float32, device=g.device)
+            _chk(_lib().gcdm_op_scatter_add(_p(g), _p(ctx.graph.col), _p(dx), ctx.graph.E, Cn, _st(g)), "gcdm_op_scatter_add")
+        return dx.reshape(ctx.shape), None, None
+
+
+def gather_row(x: torch.Tensor, graph: Graph) -> torch.Tensor:
+    return _Gather.apply(x, graph, True)
+
+
+def gather_col(x: torch.Tensor, graph: Graph) -> torch.Tensor:
+    return _Gather.apply(x, graph, False)
+
+
+class _SegmentReduce(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, graph, mean):
+        xs = _f(x).reshape(x.shape[0], -1)
+        out = torch.empty((graph.N, xs.shape[1]), dtype=torch.float32, device=xs.device)
+        _chk(_lib().gcdm_op_segment_sum(_p(xs), _p(graph.rowptr), _p(out), graph.N, xs.shape[1], int(mean), _st(xs)), "gcdm_op_segment_sum")
+        ctx.graph, ctx.mean, ctx.shape = graph, int(mean), x.shape
+        return out.reshape(graph.N, *x.shape[1:])
+
+    @staticmethod
+    def backward(ctx, dout):
+        g = _f(dout).reshape(ctx.graph.N, -1)
+        dx = torch.empty((ctx.graph.E, g.shape[1]), dtype=torch.float32, device=g.device)
+        _chk(_lib().gcdm_op_segment_bwd(_p(g), _p(ctx.graph.row), _p(ctx.graph.rowptr), _p(dx), ctx.graph.E, g.shape[1], ctx.mean, _st(g)),
+             "gcdm_op_segment_bwd")
+        return dx.reshape(ctx.shape), None, None
+
+
+def scatter_rows(x: torch.Tensor, graph: Graph, reduce: str = "sum") -> torch.Tensor:
+    """torch_scatter.scatter(x, row, dim=0, dim_size=N, reduce=sum | mean) for a row-sorted edge list (summation in edge order)."""
+    if reduce not in ("sum", "mean"):
+        raise NotImplementedError(f"reduce={reduce!r}")
+    return _SegmentReduce.apply(x, graph, reduce == "mean")
+
+
+def mean_frames(frames: torch.Tensor, graph: Graph, edge_mask: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Per-node mean of the frames of its edges [N, 3, 3] (masked edges contribute zeros but count, as in the reference's scatter-mean)."""
+    f = _f(frames).reshape(-1, 9)
+    if edge_mask is not None:
+        f = f * edge_mask.to(f.dtype).unsqueeze(-1)
+    out = torch.empty((graph.N, 9), dtype=torch.float32, device=f.device)
+    _chk(_lib().gcdm_op_segment_sum(_p(f), _p(graph.rowptr), _p(out), graph.N, 9, 1, _st(f)), "gcdm_op_segment_sum")
+    return out.reshape(graph.N, 3, 3)
+
+
+# ---- geometry of the network input (no gradients) -----------------------------------------------------------------------------------------
+def localize(x: torch.Tensor, edge_index: torch.Tensor, norm_x_diff: bool = True) -> torch.Tensor:
+    xs = _f(x)
+    row, col = edge_index[0].to(torch.int64).contiguous(), edge_index[1].to(torch.int64).contiguous()
+    E = int(row.shape[0])
+    F = torch.empty((E, 3, 3), dtype=torch.float32, device=xs.device)
+    _chk(_lib().gcdm_op_localize(_p(xs), _p(row), _p(col), _p(F), E, int(norm_x_diff), _st(xs)), "gcdm_op_localize")
+    return F
+
+
+def edge_features(x: torch.Tensor, edge_index: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+    xs = _f(x)
+    row, col = edge_index[0].to(torch.int64).contiguous(), edge_index[1].to(torch.int64).contiguous()
+    E = int(row.shape[0])
+    e = torch.empty((E, 1), dtype=torch.float32, device=xs.device)
+    xi = torch.empty((E, 1, 3), dtype=torch.float32, device=xs.device)
+    _chk(_lib().gcdm_op_edge_features(_p(xs), _p(row), _p(col), _p(e), _p(xi), E, _st(xs)), "gcdm_op_edge_features")
+    return e, xi
+
+
+def orientations(x: torch.Tensor) -> torch.Tensor:
+    xs = _f(x)
+    out = torch.empty((xs.shape[0], 2, 3), dtype=torch.float32, device=xs.device)
+    _chk(_lib().gcdm_op_orientations(_p(xs), _p(out), xs.shape[0], _st(xs)), "gcdm_op_orientations")
+    return out
+
+
+class _Centralize(torch.autograd.Function):
+    """x -> (x - mean over the molecule's unmasked nodes) on unmasked rows, 0 on masked rows: a symmetric projection, so the backward is
+    the same kernel applied to the incoming gradient."""
+
+    @staticmethod
+    def _run(xs, bi, mk):
+        out = torch.empty_like(xs)
+        _chk(_lib().gcdm_op_centralize(_p(xs), _p(bi), _p(mk), _p(out), xs.shape[0], xs.shape[1], _st(xs)), "gcdm_op_centralize")
+        return out
+
+    @staticmethod
+    def forward(ctx, x, bi, mk):
+        ctx.bi, ctx.mk = bi, mk
+        return _Centralize._run(_f(x), bi, mk)
+
+    @staticmethod
+    def backward(ctx, dout):
+        return _Centralize._run(_f(dout), ctx.bi, ctx.mk), None, None
+
+
+def centralize(x: torch.Tensor, batch_index: torch.Tensor, node_mask: Optional[torch.Tensor] = None) -> torch.Tensor:
+    bi = batch_index.to(torch.int64).contiguous()
+    mk = None if node_mask is None else node_mask.to(torch.uint8).contiguous()
+    return _Centralize.apply(x, bi, mk)
+
+
+def fully_connected_edge_index(num_nodes: torch.Tensor, device) -> torch.Tensor:
+    """get_fully_connected_edge_index (gcpnet.py:1054-1066) from the molecule sizes: [2, sum n^2] int64, self-loops included, sorted."""
+    nn_ = torch.as_tensor(num_nodes, dtype=torch.int64, device="cpu")
+    noff = torch.zeros(len(nn_) + 1, dtype=torch.int32)
+    noff[1:] = torch.cumsum(nn_, 0).to(torch.int32)
+    eoff = torch.zeros(len(nn_) + 1, dtype=torch.int64)
+    eoff[1:] = torch.cumsum(nn_ * nn_, 0)
+    E = int(eoff[-1])
+    dev = torch.device(device)
+    noff_d, eoff_d = noff.to(dev), eoff.to(dev)
+    ei = torch.empty((2, E), dtype=torch.int64, device=dev)
+    _chk(_lib().gcdm_op_fc_edges(_p(noff_d), _p(eoff_d), len(nn_), C.c_void_p(ei.data_ptr()), C.c_void_p(ei.data_ptr() + 8 * E), E,
+                                 C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)), "gcdm_op_fc_edges")
+    return ei

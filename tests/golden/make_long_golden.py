@@ -3,7 +3,8 @@ noise tape for the FULL 1000 steps at full width (QM9 production architecture, 4
 once in fp32 and once with the same code in fp64 (the adjudicator).  Stored: the latent z after the step to s = 900, 800, ..., 0 and
 after selected early steps, and the final decode.  -> tests/golden/long_full_qm9.npz   (contract (iii))
 
-    python tests/golden/make_long_golden.py        (build container only; ~10 min of CPU)
+    python tests/golden/make_long_golden.py              (build container only; ~10 min of CPU)
+    python tests/golden/make_long_golden.py ragged16     -> tests/golden/long_ragged16_qm9.npz: 16 molecules of 5 ... 27 atoms (~40 min of CPU)
 
 Only data is stored (inputs = num_nodes + seeds, outputs); the weights are re-created from `synth.make_weights(..., seed=LONG_WEIGHT_SEED,
 scale_2d=0.25)` and the noise from `TapeNoise(LONG_NOISE_SEED)` wherever the fixture is used.
@@ -20,12 +21,18 @@ sys.path[:0] = [HERE, os.path.dirname(HERE), os.path.dirname(os.path.dirname(HER
 import ref_harness as rh  # noqa: E402
 import synth  # noqa: E402
 
-torch.set_num_threads(8)
+torch.set_num_threads(int(os.environ.get("GOLDEN_THREADS", "8")))
 
 LONG_WEIGHT_SEED = 61
 LONG_NOISE_SEED = 4321
 SIZES = [5, 19, 3, 11]
 CHECKPOINTS = [999, 990, 950] + list(range(900, -1, -100))      # z after the step that lands on s
+OUT_NAME = "long_full_qm9.npz"
+if len(sys.argv) > 1 and sys.argv[1] == "ragged16":             # second fixture: a ragged batch of 16 QM9-sized molecules (275 atoms, 5 165 edges)
+    LONG_WEIGHT_SEED, LONG_NOISE_SEED = 67, 9753
+    SIZES = [18, 19, 17, 23, 9, 16, 21, 12, 19, 14, 27, 5, 20, 18, 15, 22]
+    CHECKPOINTS = [999, 900, 500, 100, 0]
+    OUT_NAME = "long_ragged16_qm9.npz"
 
 
 def run(dtype):
@@ -72,7 +79,7 @@ def main():
         gap = (z32[s].double() - z64[s]).abs().max().item()
         print(f"s={s:4d}  max|z| = {z64[s].abs().max().item():.4e}   |ref32 - ref64| = {gap:.3e}")
     print("final: |ref32 - ref64| x =", (x32[:, :3].double() - x64[:, :3]).abs().max().item(), " discrete equal:", bool((x32[:, 3:].double() == x64[:, 3:]).all()))
-    path = os.path.join(HERE, "long_full_qm9.npz")
+    path = os.path.join(HERE, OUT_NAME)
     np.savez_compressed(path, **out)
     print(f"wrote {path} ({os.path.getsize(path) / 1024:.0f} KiB)")
 

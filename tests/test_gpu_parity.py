@@ -168,13 +168,15 @@ def test_edge_list_and_geometry_match_reference_golden(golden_dir):
         net.debug_set_layer_limit(-1)
 
 
+@pytest.mark.parametrize("fixture", ["long_full_qm9.npz", "long_ragged16_qm9.npz"])
 @pytest.mark.parametrize("mode", MODES)
-def test_long_horizon_sampling_matches_reference_golden(mode, golden_dir):
+def test_long_horizon_sampling_matches_reference_golden(mode, fixture, golden_dir):
     """SURVEY section 7 contract (iii): the FULL 1000-step free-running sample on the noise tape of tests/golden/long_full_qm9.npz
     (the reference's own mol_gen_sample, variational_diffusion.py:1282-1412, at full width in fp32 and fp64, make_long_golden.py).
     At every stored checkpoint |hip - ref32| <= 4 |ref32 - ref64| + 1e-4 max|z|; same for the decoded positions; decoded discrete
-    outputs equal the reference's wherever its fp32 and fp64 runs agree.  Both matrix modes (f16x3 must hold this WITHOUT the fp32 re-run)."""
-    g = np.load(os.path.join(golden_dir, "long_full_qm9.npz"))
+    outputs equal the reference's wherever its fp32 and fp64 runs agree.  Both matrix modes (f16x3 must hold this WITHOUT the fp32 re-run).
+    Two fixtures: 4 molecules (n = 5, 19, 3, 11) and a ragged batch of 16 molecules of 5 ... 27 atoms (275 atoms, rows cut by tile boundaries)."""
+    g = np.load(os.path.join(golden_dir, fixture))
     net, W, cfgs = _net("qm9", seed=int(g["weight_seed"]), scale=float(g["weight_scale"]), mode=mode)
     ddpm = pkg.EquivariantVariationalDiffusion(net, cfgs["diffusion_cfg"], cfgs["dataloader_cfg"], pkg.dataset_info("qm9")).cuda()
     nn_ = torch.tensor(g["num_nodes"])
@@ -218,10 +220,13 @@ def test_free_running_sampling_config0_size(mode):
     ddpm = pkg.EquivariantVariationalDiffusion(net, cfgs["diffusion_cfg"], cfgs["dataloader_cfg"], pkg.dataset_info("qm9")).cuda()
     nn_ = torch.tensor([19] * 64)
     N, F, Tp = int(nn_.sum()), ocfg.num_node_scalar_features, 100
-    if "want" not in _CONFIG0_ORACLE:            # the CPU oracle takes ~2 min for these 100 steps: once for both matrix modes
+    if "want" not in _CONFIG0_ORACLE:            # the CPU oracle takes ~2 min for these 100 steps (fp64: ~4): once for both matrix modes
         torch.set_num_threads(min(32, os.cpu_count() or 1))
         _CONFIG0_ORACLE["want"] = O.mol_gen_sample(W, ocfg, nn_, O.TapeNoise(77), num_timesteps=Tp)
+        W64 = {k: v.double() for k, v in W.items()}
+        _CONFIG0_ORACLE["want64"] = O.mol_gen_sample(W64, ocfg, nn_, O.TapeNoise(77), num_timesteps=Tp, dtype=torch.float64)[0]
     want, bi = _CONFIG0_ORACLE["want"]
+    want64 = _CONFIG0_ORACLE["want64"]
     tape = O.TapeNoise(77)
     draws = [torch.cat((tape(N, 3), tape(N, F)), dim=-1) for _ in range(Tp + 2)]
     out, bi2, _ = ddpm.mol_gen_sample(num_samples=len(nn_), num_nodes=nn_, device="cuda", num_timesteps=Tp, noise_fn=lambda k: draws[k])
@@ -229,12 +234,17 @@ def test_free_running_sampling_config0_size(mode):
     assert torch.equal(bi2.cpu(), bi) and (ddpm.last_flags & pkg._native.FLAG_F16_RANGE) == 0
     scale = max(1.0, want[:, :3].abs().max().item())
     assert (out[:, :3] - want[:, :3]).abs().max().item() <= TOL * scale
-    # discrete outputs: untrained weights drive the charge channel to O(1e3) after 100 coarse steps, so a rounding tie can fall either way
-    # within the 1e-4 * scale bar -- require identical atom types / charges on >= 99 % of the 1216 atoms and charges never off by more than 1
+    # discrete outputs, EXACT: atom type and charge of every atom equal the oracle's, skipping only the atoms on which the oracle itself is
+    # undecided -- fp32 and fp64 runs of the same restatement disagree there (untrained weights drive the charge channel to O(1e3) after 100
+    # coarse steps, so a rounding tie can fall either way); the rule test_long_horizon_sampling_matches_reference_golden uses
     nt = ocfg.num_atom_types
-    assert (out[:, 3:3 + nt].argmax(1) == want[:, 3:3 + nt].argmax(1)).float().mean().item() >= 0.99
-    dq = (out[:, 3 + nt] - want[:, 3 + nt]).abs()
-    assert dq.max().item() <= 1.0 and (dq == 0).float().mean().item() >= 0.99
+    ty, ty32, ty64 = out[:, 3:3 + nt].argmax(1), want[:, 3:3 + nt].argmax(1), want64[:, 3:3 + nt].argmax(1)
+    q, q32, q64 = out[:, 3 + nt], want[:, 3 + nt], want64[:, 3 + nt].float()
+    decided_t, decided_q = ty32 == ty64, q32 == q64
+    assert decided_t.float().mean().item() >= 0.98 and decided_q.float().mean().item() >= 0.98, "the oracle itself is undecided on too many atoms"
+    assert torch.equal(ty[decided_t], ty32[decided_t])
+    assert torch.equal(q[decided_q], q32[decided_q])
+    assert (q - q32).abs().max().item() <= 1.0
 
 
 @pytest.mark.parametrize("case,num_nodes", [
@@ -945,6 +955,45 @@ def test_full_size_properties(case, B, n, mode):
         assert (sub[n:2 * n] - out[b * n:(b + 1) * n]).abs().max().item() <= TOL * scale
         ref = O.dynamics_forward(W, _ocfg(case), xh[lo:hi], t[lo:hi], bi[lo:hi] - (b - 1), None, cs)
         assert (sub - ref).abs().max().item() <= TOL * scale
+
+
+@pytest.mark.parametrize("dataset,B,n", [("qm9", 1024, 19), ("geom", 256, 44)])
+def test_full_sample_at_benchmark_size(dataset, B, n):
+    """BASELINE.json configs[1] / configs[3] END TO END: one complete 1000-step sample + decode (Philox noise, the default f16x3 matrix mode, the
+    batch sampled as 2 slices like bench.py does) through `EquivariantVariationalDiffusion.mol_gen_sample` -- what bench.py extrapolates from a few timed
+    steps.  Asserts: no device flag (in particular no f16-range overflow, i.e. no hidden fp32 re-run), finite outputs, one-hot atom types,
+    zero centre of mass per molecule, and a host-clock wall time within 5 % of 1001 x the per-evaluation cost measured in THIS test on a
+    200-step run of the same loop (free-running, untrained SURVEY-8(d) weights: |x| grows to ~1e3, the hardest case for the range guard)."""
+    import time
+    cfgs = pkg.default_cfgs(dataset)
+    torch.manual_seed(0)
+    model = (pkg.GEOMMoleculeGenerationDDPM if dataset == "geom" else pkg.QM9MoleculeGenerationDDPM)(**cfgs)
+    with torch.no_grad():
+        for p in model.ddpm.dynamics_network.parameters():
+            if p.dim() == 2:
+                p.mul_(0.25)
+    model = model.cuda()
+    ddpm = model.ddpm
+    nn_ = torch.full((B,), n)
+    ddpm.mol_gen_sample(num_samples=B, num_nodes=nn_, device="cuda", num_timesteps=5, lanes=2)         # handles, plans, slices
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    ddpm.mol_gen_sample(num_samples=B, num_nodes=nn_, device="cuda", num_timesteps=200, seed=3, lanes=2)
+    torch.cuda.synchronize()
+    per_eval = (time.perf_counter() - t0) / 201
+    t0 = time.perf_counter()
+    xh, bi, _ = ddpm.mol_gen_sample(num_samples=B, num_nodes=nn_, device="cuda", seed=7, lanes=2)
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    assert ddpm.last_flags == 0, f"device flags {ddpm.last_flags}"
+    assert ddpm.dynamics_network.mfma_mode == 1
+    assert torch.isfinite(xh).all()
+    F = model.num_atom_types
+    assert bool((xh[:, 3:3 + F].sum(1) == 1).all()) and bool(((xh[:, 3:3 + F] == 0) | (xh[:, 3:3 + F] == 1)).all())
+    com = torch.zeros(B, 3, device=xh.device).index_add_(0, bi, xh[:, :3]).abs().max().item() / n
+    assert com <= 1e-4 * max(1.0, xh[:, :3].abs().max().item())
+    print(f"full sample {dataset} {B} x {n}: {wall:.2f} s = {B / wall:.1f} molecules/s; 1001 x per-evaluation cost of a 200-step run = {1001 * per_eval:.2f} s")
+    assert abs(wall - 1001 * per_eval) <= 0.05 * 1001 * per_eval, (wall, 1001 * per_eval)
 
 
 NLL_TERMS = ("delta_log_px", "error_t", "SNR_weight", "loss_0_x", "loss_0_h", "neg_log_constants", "kl_prior", "log_pN")
