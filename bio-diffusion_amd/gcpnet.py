@@ -69,9 +69,9 @@ class GCPNetDynamics(nn.Module):
         self.norm_x_diff = bool(cfg_get(module_cfg, "norm_x_diff", True))
         self._diffusion_cfg = diffusion_cfg
 
+        # (as gcpnet.py:1006-1014: the embedding keeps GCPEmbedding's own default nonlinearities ("silu", "silu") whatever module_cfg says)
         self.gcp_embedding = GCPEmbedding(self.edge_input_dims, self.node_input_dims, self.edge_dims, self.node_dims, num_atom_types=0,
-                                          nonlinearities=cfg_get(module_cfg, "nonlinearities") or ("silu", "silu"), cfg=module_cfg,
-                                          use_gcp_norm=cfg_get(layer_cfg, "use_gcp_norm", False))
+                                          cfg=module_cfg, use_gcp_norm=cfg_get(layer_cfg, "use_gcp_norm", False))
         self.interaction_layers = nn.ModuleList(
             GCPInteractions(self.node_dims, self.edge_dims, cfg=module_cfg, layer_cfg=layer_cfg, dropout=float(cfg_get(model_cfg, "dropout", 0.0)),
                             update_node_positions=True) for _ in range(self.num_layers))

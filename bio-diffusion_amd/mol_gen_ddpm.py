@@ -141,16 +141,20 @@ class _MoleculeGenerationDDPM(nn.Module):
             model = model.to(map_location)
         return model
 
-    # ---- likelihood of a data batch (validation / test step), qm9_mol_gen_ddpm.py:184-277, 429-459 -------------------------------
-    @torch.inference_mode()
+    # ---- loss / likelihood of a data batch (training, validation, test step), qm9_mol_gen_ddpm.py:184-277, 340-360, 429-459 --------
     def forward(self, batch: Any, dtype: torch.dtype = torch.float32, t_int: Optional[torch.Tensor] = None,
                 noise: Optional[List[torch.Tensor]] = None) -> Tuple[torch.Tensor, Dict[str, Any]]:
-        """NLL per molecule and the batch means of the monitored loss terms, EVALUATION mode (two evaluations of the network; the training
-        objective needs the backward pass and is not built).  ``batch``: x, one_hot, charges, batch, mask and -- for a conditional model -- the
+        """Loss per molecule and the batch means of the monitored terms.  Evaluation mode: the NLL (two evaluations of the network, fused
+        kernels, inference mode).  Training mode: the L2 or VLB objective of ``diffusion_cfg.loss_type`` with gradients -- the network runs on
+        the module path (HIP operators with autograd).  ``batch``: x, one_hot, charges, batch, mask and -- for a conditional model -- the
         per-node ``props_context`` (the reference derives it from the training set's property statistics, qm9utils.prepare_context; that data
         path is outside this package).  ``t_int`` / ``noise``: see EquivariantVariationalDiffusion.forward."""
         if self.training:
-            raise NotImplementedError("training step: the backward pass of the network is not built (SURVEY 8 f4); call .eval()")
+            return self._forward_impl(batch, dtype, t_int, noise)
+        with torch.inference_mode():
+            return self._forward_impl(batch, dtype, t_int, noise)
+
+    def _forward_impl(self, batch, dtype, t_int, noise):
         bi, mask = batch.batch, batch.mask
         B = int(bi.max().item()) + 1
         batch.x = _segment_mean_sub(batch.x, bi, B, mask)                         # centralize(..., edm=True): translation-invariant positions
@@ -166,13 +170,32 @@ class _MoleculeGenerationDDPM(nn.Module):
         batch.num_nodes_present, batch.num_graphs = num_nodes, B
         (delta_log_px, error_t, SNR_weight, loss_0_x, loss_0_h, neg_log_const_0, kl_prior, log_pN, t_int, loss_info) = self.ddpm(
             batch, return_loss_info=True, t_int=t_int, noise=noise)
-        loss_t = self.T * 0.5 * SNR_weight * error_t                             # evaluation always scores the variational bound (:246-250)
-        loss_0 = loss_0_x + loss_0_h + neg_log_const_0
-        nll = loss_t + loss_0 + kl_prior - delta_log_px - log_pN                  # normalisation of x undone, joint with the size prior (:253-262)
+        if self.training and cfg_get(self._init_kwargs["diffusion_cfg"], "loss_type", "l2") == "l2":
+            # L2 training objective (:222-234): the squared error per predicted number, the x part of L_0 normalised the same way
+            eff = num_nodes.max() if cfg_get(self._init_kwargs["diffusion_cfg"], "norm_training_by_max_nodes", False) else num_nodes
+            denom = (self.num_x_dims + self.ddpm.num_node_scalar_features) * eff
+            error_t = error_t / denom
+            loss_t = 0.5 * error_t
+            loss_0_x = loss_0_x / denom
+            loss_0 = loss_0_x + loss_0_h
+        else:
+            loss_t = self.T * 0.5 * SNR_weight * error_t                          # the variational bound (:236-240); evaluation always scores it
+            loss_0 = loss_0_x + loss_0_h + neg_log_const_0
+        nll = loss_t + loss_0 + kl_prior - delta_log_px - log_pN                  # normalisation of x undone, joint with the size prior (:243-252)
         for name, v in (("loss_t", loss_t), ("SNR_weight", SNR_weight), ("loss_0", loss_0), ("kl_prior", kl_prior), ("delta_log_px", delta_log_px),
                         ("neg_log_const_0", neg_log_const_0), ("log_pN", log_pN)):
             loss_info[name] = v.mean(0)
         return nll, loss_info
+
+    def training_step(self, batch: Any, batch_idx: int = 0, **kw) -> Dict[str, Any]:
+        """qm9_mol_gen_ddpm.py:340-360 without the Lightning metric objects: ``metrics["loss"]`` carries the graph (call ``.backward()`` on it),
+        every other entry is detached.  The module must be in training mode."""
+        if not self.training:
+            raise RuntimeError("training_step needs .train() (evaluation mode scores the NLL without gradients)")
+        nll, metrics = self.step(batch, **kw)
+        metrics = {k: v.detach() for k, v in metrics.items()}
+        metrics["loss"] = nll.mean(0)
+        return metrics
 
     def step(self, batch: Any, **kw) -> Tuple[torch.Tensor, Dict[str, Any]]:
         return self.forward(batch, **kw)

@@ -20,6 +20,7 @@ from __future__ import annotations
 
 import ctypes as C
 import logging
+from random import random as _random
 from typing import Any, Callable, Dict, List, Optional, Tuple, Union
 
 import numpy as np
@@ -305,53 +306,88 @@ class EquivariantVariationalDiffusion(nn.Module):
             log_ph = log_ph + psum(mass(h_int - (z_0[:, -1:] * nv[2] + nb[2]), sigma_0 * nv[2]) * m)
         return log_px, log_ph
 
-    @torch.inference_mode()
-    def forward(self, batch, return_loss_info: bool = False, t_int: Optional[torch.Tensor] = None, noise: Optional[List[torch.Tensor]] = None):
-        """Loss / NLL terms of a data batch (:948-1160), EVALUATION mode: (delta_log_px, error_t, SNR_weight, loss_0_x, loss_0_h,
-        neg_log_constants, kl_prior, log_pN, t_int[, loss_info]), each per molecule.  ``batch``: x (CoM-free), h = {categorical, integer},
-        batch, mask, num_graphs, num_nodes_present, props_context (per node or None).  Extensions for reproducible evaluation: ``t_int``
-        [B, 1] instead of the torch.randint draw, ``noise`` = the two raw standard-normal draws [N, 3 + F] for z_t and z_0."""
-        if self.training:
-            raise NotImplementedError("the training objective needs the network's backward pass, which is not built (SURVEY 8 f4); call .eval() for the likelihood terms")
+    def forward(self, batch, return_loss_info: bool = False, t_int: Optional[torch.Tensor] = None, noise: Optional[List[torch.Tensor]] = None,
+                self_conditioning_prob: float = 0.5, fix_self_conditioning_noise: bool = False):
+        """Loss / NLL terms of a data batch (:948-1160): (delta_log_px, error_t, SNR_weight, loss_0_x, loss_0_h, neg_log_constants, kl_prior,
+        log_pN, t_int[, loss_info]), each per molecule.  ``batch``: x (CoM-free), h = {categorical, integer}, batch, mask, num_graphs,
+        num_nodes_present, props_context (per node or None).
+          * evaluation mode: two evaluations of the network (t and 0) on the fused kernels, under inference mode;
+          * TRAINING mode (``.train()``): one evaluation at t >= 0 on the module path (HIP operators with autograd), the t = 0 terms masked
+            in as the reference does (:1078-1101); ``loss_type == "l2"`` drops the weights / constants (:978, 1050-1063).
+        Extensions for reproducible runs: ``t_int`` [B, 1] instead of the torch.randint draw, ``noise`` = the raw standard-normal draws
+        [N, 3 + F] (evaluation: two, for z_t and z_0; training: one)."""
         if self.diffusion_target != "atom_types_and_coords":
             raise NotImplementedError(f"diffusion_target {self.diffusion_target!r}")
+        if self.training:
+            return self._loss_terms(batch, return_loss_info, t_int, noise, self_conditioning_prob, fix_self_conditioning_noise)
+        with torch.inference_mode():
+            return self._loss_terms(batch, return_loss_info, t_int, noise, self_conditioning_prob, fix_self_conditioning_noise)
+
+    def _loss_terms(self, batch, return_loss_info, t_int, noise, self_conditioning_prob, fix_self_conditioning_noise):
+        training = self.training
+        l2 = training and cfg_get(self.diffusion_cfg, "loss_type", "l2") == "l2"
         x, h = self.normalize(batch.x, batch.h, node_mask=batch.mask)
         bi, B, num_nodes, mask = batch.batch, int(batch.num_graphs), batch.num_nodes_present, batch.mask
         dev = x.device
         if t_int is None:
-            t_int = torch.randint(1, self.T + 1, size=(B, 1), device=dev)            # lowest_t = 1 outside training (:988-994)
+            t_int = torch.randint(0 if training else 1, self.T + 1, size=(B, 1), device=dev)     # lowest_t (:982-990)
         t_int = t_int.to(dev).reshape(B, 1)
+        t_is_zero = (t_int == 0).float().squeeze(-1)
         s, t = (t_int - 1) / self.T, t_int / self.T
         gamma_s, gamma_t = inflate_batch_array(self.gamma(s), x), inflate_batch_array(self.gamma(t), x)
         xh = torch.cat([x, h["categorical"]] + ([h["integer"].reshape(-1, 1)] if self.include_charges else []), dim=-1)
         z_t, eps_t = self.compute_noised_representation(xh, bi, mask, gamma_t, eps=None if noise is None else noise[0].to(dev))
-        # L_0 from its own draw at t = 0 (second evaluation of the network, :1107-1128)
-        t_zeros = torch.zeros_like(s)
-        gamma_0 = inflate_batch_array(self.gamma(t_zeros), x)
-        z_0, eps_0 = self.compute_noised_representation(xh, bi, mask, gamma_0, eps=None if noise is None else noise[1].to(dev))
-
-        def two_evaluations():          # no host sync between them; ONE check of the range guard after both (one sync per batch)
-            a = self.dynamics_network(batch, z_t, t[bi], xh_self_cond=None, _range_check="deferred")[1]
-            b = self.dynamics_network(batch, z_0, t_zeros[bi], xh_self_cond=None, _range_check="deferred")[1]
-            self._final_range_check()
-            return a, b
-        try:
-            net_out, net_out_0 = two_evaluations()
-        except F16RangeError:           # an activation left the f16 images: the handle now runs fp32 MFMA, same inputs again
-            net_out, net_out_0 = two_evaluations()
-        error_t = self.sum_node_features_except_batch((eps_t - net_out) ** 2, bi, B)
-        SNR_weight = (self.SNR(gamma_s - gamma_t) - 1).squeeze(-1)
-        neg_log_constants = -self.log_constants_p_x_given_z0(num_nodes.to(dev), dev)
-        kl_prior = self.compute_kl_prior(xh, batch_index=bi, node_mask=mask, num_nodes=num_nodes.to(dev), device=dev)
-        log_px, log_ph = self.log_pxh_given_z0_without_constants(h=h, z_0=z_0, eps=eps_0, net_out=net_out_0, gamma_0=gamma_0, batch_index=bi,
-                                                                 node_mask=mask, device=dev)
         num_nodes = num_nodes.to(dev)
-        terms = (self.delta_log_px(num_nodes), error_t, SNR_weight, -log_px, -log_ph, neg_log_constants, kl_prior, self.log_pN(num_nodes), t_int.squeeze(-1))
+        delta_log_px = self.delta_log_px(num_nodes)
+        neg_log_constants = -self.log_constants_p_x_given_z0(num_nodes, dev)
+        kl_prior = self.compute_kl_prior(xh, batch_index=bi, node_mask=mask, num_nodes=num_nodes, device=dev)
+        if training:
+            self_cond = None
+            if bool(cfg_get(self.diffusion_cfg, "self_condition", False)) and not bool((t_int == self.T).any()) and _random() < self_conditioning_prob:
+                with torch.no_grad():                       # the estimate the network is conditioned on: a jump from t + 1 to 0 (:1016-1035)
+                    t_sc = (t_int + 1) / self.T
+                    z_sc, _ = self.compute_noised_representation(xh, bi, mask, inflate_batch_array(self.gamma(t_sc), x))
+                    self_cond = self.sample_p_zs_given_zt(s=torch.zeros_like(t_sc), t=t_sc, z=z_sc, batch_index=bi, node_mask=mask,
+                                                          context=getattr(batch, "props_context", None), fix_noise=fix_self_conditioning_noise,
+                                                          self_condition=True).detach()
+            _, net_out = self.dynamics_network(batch, z_t, t[bi], xh_self_cond=self_cond)
+            error_t = self.sum_node_features_except_batch((eps_t - net_out) ** 2, bi, B)
+            if l2:
+                delta_log_px, neg_log_constants = torch.zeros_like(delta_log_px), torch.zeros_like(neg_log_constants)
+                SNR_weight = torch.ones_like(error_t)
+            else:
+                SNR_weight = (self.SNR(gamma_s - gamma_t) - 1).squeeze(-1)
+            log_px, log_ph = self.log_pxh_given_z0_without_constants(h=h, z_0=z_t, eps=eps_t, net_out=net_out, gamma_0=gamma_t, batch_index=bi,
+                                                                     node_mask=mask, device=dev)
+            loss_0_x, loss_0_h = -log_px * t_is_zero, -log_ph * t_is_zero
+            error_t = error_t * (1 - t_is_zero)
+        else:
+            # L_0 from its own draw at t = 0 (second evaluation of the network, :1107-1128)
+            t_zeros = torch.zeros_like(s)
+            gamma_0 = inflate_batch_array(self.gamma(t_zeros), x)
+            z_0, eps_0 = self.compute_noised_representation(xh, bi, mask, gamma_0, eps=None if noise is None else noise[1].to(dev))
+
+            def two_evaluations():          # no host sync between them; ONE check of the range guard after both (one sync per batch)
+                a = self.dynamics_network(batch, z_t, t[bi], xh_self_cond=None, **self._deferred())[1]
+                b = self.dynamics_network(batch, z_0, t_zeros[bi], xh_self_cond=None, **self._deferred())[1]
+                self._final_range_check()
+                return a, b
+            try:
+                net_out, net_out_0 = two_evaluations()
+            except F16RangeError:           # an activation left the f16 images: the handle now runs fp32 MFMA, same inputs again
+                net_out, net_out_0 = two_evaluations()
+            error_t = self.sum_node_features_except_batch((eps_t - net_out) ** 2, bi, B)
+            SNR_weight = (self.SNR(gamma_s - gamma_t) - 1).squeeze(-1)
+            log_px, log_ph = self.log_pxh_given_z0_without_constants(h=h, z_0=z_0, eps=eps_0, net_out=net_out_0, gamma_0=gamma_0, batch_index=bi,
+                                                                     node_mask=mask, device=dev)
+            loss_0_x, loss_0_h = -log_px, -log_ph
+        terms = (delta_log_px, error_t, SNR_weight, loss_0_x, loss_0_h, neg_log_constants, kl_prior, self.log_pN(num_nodes), t_int.squeeze(-1))
         if not return_loss_info:
             return terms
         cnt = torch.zeros(B, dtype=x.dtype, device=dev).index_add_(0, bi, torch.ones_like(bi, dtype=x.dtype)).clamp(min=1)
         gmean = lambda v: (torch.zeros(B, dtype=x.dtype, device=dev).index_add_(0, bi, v) / cnt).mean()
-        info = {"eps_hat_x": gmean(net_out[:, : self.num_x_dims].abs().mean(-1)), "eps_hat_h": gmean(net_out[:, self.num_x_dims:].abs().mean(-1))}
+        no = net_out.detach()
+        info = {"eps_hat_x": gmean(no[:, : self.num_x_dims].abs().mean(-1)), "eps_hat_h": gmean(no[:, self.num_x_dims:].abs().mean(-1))}
         return (*terms, info)
 
     # ---- one step with the reference's signature (:1204-1278) --------------------------------------
@@ -367,7 +403,7 @@ class EquivariantVariationalDiffusion(nn.Module):
             batch = _Batch(batch=batch_index, mask=node_mask, props_context=context)
         # deferred range guard: the reference's loop calls this T times; call k looks at the flag word of call k-1 (no host sync), and
         # sample_p_xh_given_z0 -- the call that ends every one of the reference's loops -- checks the last one before it returns samples
-        _, eps_t = self.dynamics_network(batch, z, t[batch_index], x_self_cond=xh_self_cond, xh_self_cond=xh_self_cond, _range_check="deferred")
+        _, eps_t = self.dynamics_network(batch, z, t[batch_index], x_self_cond=xh_self_cond, xh_self_cond=xh_self_cond, **self._deferred())
         mu = z / alpha_t_given_s[batch_index] - (sigma2_t_given_s[batch_index] / alpha_t_given_s[batch_index] / sigma_t[batch_index]) * eps_t
         sigma = sigma_t_given_s * sigma_s / sigma_t
         if noise is not None:  # raw standard-normal draws [N,3+F] (x-part gets CoM-projected like the reference's sampler)
@@ -405,7 +441,7 @@ class EquivariantVariationalDiffusion(nn.Module):
         sigma_x = self.SNR(-0.5 * gamma_0)
         if batch is None:
             batch = _Batch(batch=batch_index, mask=node_mask, props_context=context)
-        _, net_out = self.dynamics_network(batch, z_0, t_zeros[batch_index], x_self_cond=xh_self_cond, xh_self_cond=xh_self_cond, _range_check="deferred")
+        _, net_out = self.dynamics_network(batch, z_0, t_zeros[batch_index], x_self_cond=xh_self_cond, xh_self_cond=xh_self_cond, **self._deferred())
         mu_x = self.compute_x_pred(z_0, net_out, gamma_0, batch_index)
         if noise is not None:
             m = node_mask.float().unsqueeze(-1)
@@ -419,6 +455,11 @@ class EquivariantVariationalDiffusion(nn.Module):
         h_int = torch.round(h_int).long() * node_mask.long().unsqueeze(-1)
         self._final_range_check()
         return x, {"integer": h_int, "categorical": h_cat}
+
+    def _deferred(self) -> Dict[str, Any]:
+        """Keyword that selects the deferred range guard for one module-level call -- only for this package's GCPNetDynamics (a foreign
+        dynamics network gets no extra keyword)."""
+        return {"_range_check": "deferred"} if hasattr(self.dynamics_network, "check_deferred_flags") else {}
 
     def _final_range_check(self) -> None:
         """Deferred range guard of the module-level calls (GCPNetDynamics.check_f16_range): the flag word of the LAST network evaluation is

@@ -65,9 +65,11 @@ def make_weights(shapes: Dict[str, Tuple[int, ...]], seed: int = 0, scale_2d: fl
             w = rng.uniform(-bound, bound, size=shp) * scale_2d
         else:
             wkey = key.replace(".bias", ".weight")
-            fan_in = shapes[wkey][1] if wkey in shapes else shp[0]
+            fan_in = shapes[wkey][1] if wkey in shapes and len(shapes[wkey]) == 2 else shp[0]
             bound = 1.0 / np.sqrt(fan_in)
             w = rng.uniform(-bound, bound, size=shp)
+            if len(shp) == 1 and key.endswith(".weight"):        # LayerNorm scale (GCPLayerNorm.scalar_norm): around 1
+                w = 1.0 + w
         out[key] = torch.tensor(w, dtype=torch.float32)
     return out
 
@@ -107,3 +109,43 @@ def dims_h_in(d) -> int:
 
 def dims_feat(d) -> int:
     return d["num_atom_types"] + int(d["include_charges"])
+
+
+# ---- non-production configurations of the path's Hydra surface (module path; tests/golden/make_variant_golden.py) ---------------------------------
+# group -> {key: value}; "mp_cfg" is layer_cfg.mp_cfg.  selected_GCP is given by NAME and resolved by the user (the reference's class / ours).
+VARIANTS = {
+    "gcp1": dict(module_cfg=dict(selected_GCP="GCP")),
+    "gcp1_frame_gate": dict(module_cfg=dict(selected_GCP="GCP", frame_gate=True, vector_frame_residual=True)),
+    "gcp1_sigma_gate": dict(module_cfg=dict(selected_GCP="GCP", sigma_frame_gate=True, vector_gate=False)),
+    "frame_gate": dict(module_cfg=dict(frame_gate=True)),
+    "no_vector_gate": dict(module_cfg=dict(vector_gate=False, vector_residual=True)),
+    "ablate_frames": dict(module_cfg=dict(ablate_frame_updates=True)),
+    "gcp_norm": dict(layer_cfg=dict(use_gcp_norm=True, pre_norm=True)),
+    "gcp_norm_post": dict(layer_cfg=dict(use_gcp_norm=True, pre_norm=False)),
+    "vector_sum": dict(module_cfg=dict(update_positions_with_vector_sum=True, node_positions_weight=0.5)),
+    "two_messages": dict(mp_cfg=dict(num_message_layers=2, use_residual_message_gcp=False), layer_cfg=dict(use_scalar_message_attention=False)),
+    "three_ff": dict(layer_cfg=dict(num_feedforward_layers=3)),
+    "relu_widths": dict(module_cfg=dict(scalar_nonlinearity="relu", vector_nonlinearity="leakyrelu", nonlinearities=["relu", "leakyrelu"], bottleneck=2,
+                                        default_bottleneck=2),
+                        model_cfg=dict(h_hidden_dim=48, chi_hidden_dim=12, e_hidden_dim=24, xi_hidden_dim=6, num_encoder_layers=3)),
+}
+SHRINK = dict(h_hidden_dim=32, chi_hidden_dim=8, e_hidden_dim=16, xi_hidden_dim=4, num_encoder_layers=2)      # ref_harness.shrink_cfgs
+
+
+def apply_variant(cfgs, name: Optional[str], gcp_classes=None, shrink: bool = True):
+    """Applies SHRINK and VARIANTS[name] in place to a dict of five config groups (attribute- or item-style containers both work)."""
+    def put(group, key, value):
+        try:
+            group[key] = value
+        except Exception:
+            setattr(group, key, value)
+    if shrink:
+        for k, v in SHRINK.items():
+            put(cfgs["model_cfg"], k, v)
+    for grp, kv in (VARIANTS[name] if name else {}).items():
+        target = cfgs["layer_cfg"]["mp_cfg"] if grp == "mp_cfg" else cfgs[grp]
+        for k, v in kv.items():
+            if k == "selected_GCP" and gcp_classes is not None:
+                v = gcp_classes[v]
+            put(target, k, v)
+    return cfgs

@@ -106,6 +106,22 @@ def test_cabi_exports_every_declared_symbol():
         assert hasattr(lib, name), name
 
 
+def test_ops_cabi_exports_every_declared_symbol():
+    """include/gcdm_ops.h (module-level operators) <-> libgcdm_ops.so <-> the ctypes signatures."""
+    native = pkg._native
+    if not os.path.exists(native.OPS_LIB_PATH):
+        pytest.skip("libgcdm_ops.so not built (run __graft_entry__.build())")
+    lib = ctypes.CDLL(native.OPS_LIB_PATH)
+    hdr = open(os.path.join(ROOT, "include", "gcdm_ops.h")).read()
+    hdr = hdr[hdr.index("#ifndef GCDM_OPS_H"):]
+    declared = set(re.findall(r"\b(gcdm_op_[a-z_0-9]+)\s*\(", hdr))
+    assert declared == set(native.OPS_EXPORTS)
+    for name in declared:
+        assert hasattr(lib, name), name
+        n_args = hdr[hdr.index(name + "("):].split(")")[0].count(",") + 1
+        assert n_args == len(native.OPS_SIGNATURES[name]), name
+
+
 def test_mfma_operand_mapping_of_the_packing():
     """Emulates v_mfma_f32_32x32x2_f32 lane semantics (cdna guide section 3) on the host-side packing formula:
     D[i][j] = sum_k A[i][k] B[k][j], A: lane l holds A[l&31][l>>5], B: lane l holds B[l>>5][l&31],
@@ -384,8 +400,9 @@ def test_checkpoint_unpickler_resolves_names_not_modules(tmp_path):
     assert torch.equal(got["ddpm.x"], sd["ddpm.x"]) and torch.equal(got["ddpm.y"].data, sd["ddpm.y"].data) and int(got["n"]) == 3
 
 
-def test_config_tree_refuses_gcp_v1(tmp_path):
-    """module_cfg.selected_GCP other than GCP2 raises like every other unsupported flag (it used to be dropped silently)."""
+def test_config_tree_loads_gcp_v1(tmp_path):
+    """module_cfg.selected_GCP = GCP (the first-generation module, gcpnet.py:33-262) loads and builds the module-path network (it used to be
+    refused); anything else still raises."""
     import shutil
     import yaml
     src = "/root/reference/configs"
@@ -396,34 +413,53 @@ def test_config_tree_refuses_gcp_v1(tmp_path):
     path = dst / "model" / "module_cfg" / "qm9_mol_gen_ddpm_gcp_module.yaml"
     d = yaml.safe_load(open(path))
     assert d["selected_GCP"]["_target_"].endswith(".GCP2")
-    pkg.load_cfg_tree(str(dst), "qm9", ())                       # the production tree loads
+    assert pkg.GCPNetDynamics(**pkg.load_cfg_tree(str(dst), "qm9", ())).fused_unsupported is None       # the production tree: fused kernels
     d["selected_GCP"]["_target_"] = "src.models.components.gcpnet.GCP"
+    yaml.safe_dump(d, open(path, "w"))
+    net = pkg.GCPNetDynamics(**pkg.load_cfg_tree(str(dst), "qm9", ()))
+    assert isinstance(net.gcp_embedding.edge_embedding, pkg.GCP) and "selected_GCP" in net.fused_unsupported
+    d["selected_GCP"]["_target_"] = "src.models.components.gcpnet.GVP"
     yaml.safe_dump(d, open(path, "w"))
     with pytest.raises(NotImplementedError, match="selected_GCP"):
         pkg.load_cfg_tree(str(dst), "qm9", ())
 
 
-def test_likelihood_forward_is_evaluation_only():
-    """EquivariantVariationalDiffusion.forward / the module's forward are built for evaluation mode (validation / test NLL); in training mode
-    they raise instead of returning a loss nobody can back-propagate (no CPU fallback, no silent approximation)."""
+@pytest.mark.parametrize("name", list(synth.VARIANTS))
+def test_variant_state_dict_layout_equals_the_reference(name, golden_dir):
+    """Keys, shapes and registration order of every non-production variant equal what the REFERENCE's GCPNetDynamics registered when the
+    fixture was made (tests/golden/dyn_variant_<name>.npz stores them), so its checkpoints load."""
+    g = np.load(os.path.join(golden_dir, f"dyn_variant_{name}.npz"))
+    net = pkg.GCPNetDynamics(**synth.apply_variant(pkg.default_cfgs("qm9"), name))
+    want = {k: tuple(int(x) for x in s.split(",")) if s else () for k, s in zip(g["keys"].tolist(), g["shapes"].tolist())}
+    got = {k: tuple(v.shape) for k, v in net.state_dict().items()}
+    assert got == want and list(got) == list(want)
+    assert net.fused_unsupported is not None
+
+
+@pytest.mark.needs_reference
+@pytest.mark.parametrize("name", ["gcp1_frame_gate", "three_ff", "gcp_norm"])
+def test_variant_state_dict_matches_imported_reference(name):
+    import ref_harness as rh
+    gcp, _, _ = rh.import_reference()
+    ref = rh.build_reference_dynamics(synth.apply_variant(rh.load_reference_cfgs("qm9", ()), name, gcp_classes={"GCP": gcp.GCP, "GCP2": gcp.GCP2}))
+    net = pkg.GCPNetDynamics(**synth.apply_variant(pkg.default_cfgs("qm9"), name))
+    a = {k: tuple(v.shape) for k, v in ref.state_dict().items()}
+    b = {k: tuple(v.shape) for k, v in net.state_dict().items()}
+    assert a == b and list(a) == list(b)
+
+
+def test_training_forward_needs_the_gpu():
+    """Training mode routes the network through the module path (HIP operators with autograd); like every other path it has no CPU fallback."""
     cfgs = pkg.default_cfgs("qm9")
     model = pkg.QM9MoleculeGenerationDDPM(**cfgs)
     batch = pkg.config.AttrDict(x=torch.zeros(3, 3), one_hot=torch.zeros(3, 5), charges=torch.zeros(3), batch=torch.zeros(3, dtype=torch.long),
                                 mask=torch.ones(3, dtype=torch.bool))
     model.train()
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
         model(batch)
-    with pytest.raises(NotImplementedError):
-        model.ddpm(batch)
-    # the pieces that need no network: schedule-only terms on the CPU
-    ddpm = model.ddpm.eval()
-    nn_ = torch.tensor([5, 19])
-    assert torch.allclose(ddpm.delta_log_px(nn_), torch.zeros(2))                                   # norm_values[0] = 1
-    assert ddpm.subspace_dimensionality(nn_).tolist() == [12, 54]
-    c = ddpm.log_constants_p_x_given_z0(nn_)
-    g0 = ddpm.gamma.gamma[0].item()
-    assert torch.allclose(c, torch.tensor([12.0, 54.0]) * (-0.5 * g0 - 0.5 * math.log(2 * math.pi)), rtol=1e-6)
-    assert torch.isfinite(ddpm.log_pN(nn_)).all()
+    model.eval()
+    with pytest.raises(RuntimeError, match="training_step needs"):
+        model.training_step(batch)
 
 
 @pytest.mark.parametrize("case", ["qm9", "qm9cond", "geom"])
