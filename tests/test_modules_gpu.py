@@ -159,3 +159,100 @@ def test_module_path_gradients_match_oracle_autograd():
 def test_operators_refuse_cpu_tensors():
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         pkg.ops.linear(torch.zeros(2, 3), torch.zeros(4, 3))
+
+
+TRAIN_TERMS = ("delta_log_px", "error_t", "SNR_weight", "loss_0_x", "loss_0_h", "neg_log_constants", "kl_prior", "log_pN")
+
+
+@pytest.mark.parametrize("case", ["qm9", "geom"])
+def test_training_loss_and_gradients_match_reference_autograd(case, golden_dir):
+    """the TRAINING objective and its backward pass.  `model.train(); model.training_step(batch)["loss"].backward()` -- the
+    mirror of qm9_mol_gen_ddpm.py:340-360 over EquivariantVariationalDiffusion.forward in training mode (variational_diffusion.py:948-1160) --
+    on a ragged data-like batch at full width, against the REFERENCE's own loss terms, loss and torch-autograd gradients on the same batch,
+    timesteps (one of them 0: the masked-in L_0 branch) and noise tape (tests/golden/train_full_{qm9,geom}.npz, fp32 + fp64):
+    every term and the loss within 4 x |ref32 - ref64| + 1e-4 relative; for EVERY parameter tensor the gradient norm and absolute maximum within
+    1e-4 relative (+ 4 x the reference's own fp32-vs-fp64 gap); eight tensors compared element by element."""
+    g = np.load(os.path.join(golden_dir, f"train_full_{case}.npz"), allow_pickle=False)
+    d = synth.DATASET_DIMS[case]
+    cfgs = pkg.default_cfgs(case)
+    cls = pkg.GEOMMoleculeGenerationDDPM if case == "geom" else pkg.QM9MoleculeGenerationDDPM
+    model = cls(**cfgs)
+    shapes = synth.dynamics_shapes(d["S"], d["V"], d["Se"], d["Ve"], d["L"], synth.dims_h_in(d))
+    assert list(shapes) == g["keys"].tolist()
+    model.ddpm.dynamics_network.load_state_dict(synth.make_weights(shapes, seed=int(g["weight_seed"]), scale_2d=float(g["weight_scale"])))
+    model = model.to(DEV).train()
+    nn_ = torch.tensor(g["num_nodes"])
+    bi = torch.repeat_interleave(torch.arange(len(nn_)), nn_).to(DEV)
+    N, F = int(nn_.sum()), synth.dims_feat(d)
+    tape = O.TapeNoise(int(g["noise_seed"]))
+    noise = [torch.cat((tape(N, 3), tape(N, F)), dim=-1)]
+    t_int = torch.tensor(g["t_int"]).view(-1, 1)
+
+    def batch():
+        return pkg.config.AttrDict(x=torch.tensor(g["x"]).to(DEV), one_hot=torch.tensor(g["one_hot"]).to(DEV), charges=torch.tensor(g["charges"]).to(DEV),
+                                   batch=bi, mask=torch.ones(N, dtype=torch.bool, device=DEV), props_context=None)
+
+    # the terms of the diffusion model in training mode
+    b = batch()
+    b.h = {"categorical": b.one_hot, "integer": b.charges}
+    b.num_graphs, b.num_nodes_present = len(nn_), nn_.to(DEV)
+    terms = model.ddpm(b, return_loss_info=True, t_int=t_int, noise=noise)
+    for name, got in zip(TRAIN_TERMS, terms[:8]):
+        w32, w64 = torch.tensor(g[f"{name}_32"]).double(), torch.tensor(g[f"{name}_64"]).double()
+        bar = 4 * (w32 - w64).abs() + 1e-4 * w64.abs().clamp(min=1.0)
+        assert ((got.detach().double().cpu() - w64).abs() <= bar).all(), name
+    # the training step and its backward pass
+    model.zero_grad()
+    metrics = model.training_step(batch(), t_int=t_int, noise=noise)
+    loss = metrics["loss"]
+    l32, l64 = float(g["loss_32"]), float(g["loss_64"])
+    assert abs(loss.item() - l64) <= 4 * abs(l32 - l64) + 1e-4 * abs(l64), (loss.item(), l64)
+    assert all(not v.requires_grad for k, v in metrics.items() if k != "loss")
+    loss.backward()
+    params = dict(model.ddpm.dynamics_network.named_parameters())
+    worst = 0.0
+    for i, k in enumerate(shapes):
+        gr = params[k].grad
+        assert gr is not None and torch.isfinite(gr).all(), k
+        for stat, fn in (("grad_norm", lambda v: float(v.double().norm())), ("grad_absmax", lambda v: float(v.double().abs().max()))):
+            w32, w64 = float(g[f"{stat}_32"][i]), float(g[f"{stat}_64"][i])
+            rel = abs(fn(gr) - w64) / max(w64, 1e-30)
+            worst = max(worst, rel)
+            assert abs(fn(gr) - w64) <= 4 * abs(w32 - w64) + 1e-4 * w64, (k, stat, fn(gr), w64)
+    full = [k[len("grad_64::"):] for k in g.files if k.startswith("grad_64::")]
+    assert len(full) >= 6
+    for k in full:
+        w32, w64 = torch.tensor(g[f"grad_32::{k}"]).double(), torch.tensor(g[f"grad_64::{k}"])
+        bar = 4 * (w32 - w64).abs().max().item() + 1e-4 * w64.abs().max().item()
+        assert (params[k].grad.double().cpu() - w64).abs().max().item() <= bar, k
+    print(f"training step {case}: loss {loss.item():.6f} (reference {l64:.6f}); worst relative error of a gradient norm / abs-max over {len(shapes)} tensors: {worst:.2e}")
+
+
+def test_training_step_updates_the_weights_the_sampler_uses():
+    """One optimiser step on the module path is seen by the fused sampling kernels (the packed weights are re-uploaded when a parameter's
+    version changes): the evaluation-mode forward before and after the step differ, and the new one equals the module path's."""
+    cfgs = pkg.default_cfgs("qm9")
+    model = pkg.QM9MoleculeGenerationDDPM(**cfgs)
+    d = synth.DATASET_DIMS["qm9"]
+    model.ddpm.dynamics_network.load_state_dict(synth.make_weights(synth.dynamics_shapes(d["S"], d["V"], d["Se"], d["Ve"], d["L"], synth.dims_h_in(d)), seed=5, scale_2d=0.5))
+    model = model.to(DEV)
+    net = model.ddpm.dynamics_network
+    xh, t, bi, nn_, _ = synth.make_inputs([6, 11, 4], synth.dims_feat(d), seed=4)
+    batch = dict(batch=bi.to(DEV), mask=torch.ones(len(bi), dtype=torch.bool, device=DEV), props_context=None)
+    model.eval()
+    with torch.no_grad():
+        before = net(batch, xh.to(DEV), t.to(DEV))[1].clone()
+    model.train()
+    opt = torch.optim.SGD(net.parameters(), lr=0.05)
+    N = len(bi)
+    data = pkg.config.AttrDict(x=xh[:, :3].to(DEV), one_hot=torch.nn.functional.one_hot(torch.arange(N) % 5, 5).float().to(DEV),
+                               charges=torch.ones(N, device=DEV), batch=bi.to(DEV), mask=torch.ones(N, dtype=torch.bool, device=DEV))
+    model.training_step(data, t_int=torch.tensor([[500], [20], [900]]))["loss"].backward()
+    opt.step()
+    model.eval()
+    with torch.no_grad():
+        after = net(batch, xh.to(DEV), t.to(DEV))[1]
+        net.path = "modules"
+        after_m = net(batch, xh.to(DEV), t.to(DEV))[1]
+    assert (after - before).abs().max().item() > 1e-5
+    assert (after - after_m).abs().max().item() <= 1e-5 * max(1.0, after.abs().max().item())
