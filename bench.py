@@ -411,7 +411,7 @@ def main():
 
     # plug point 1: what the reference's UNCHANGED mol_gen_sample loop costs after the one-line registry swap -- per step one
     # reference-signature sample_p_zs_given_zt (torch algebra on the device + GCPNetDynamics.forward, deferred range guard: no host sync)
-    plug1_ms = nll_ms = None
+    plug1_ms = nll_ms = train_ms = None
     if world == 1 and args.streams == 1:
         ddpm.to(dev)                                   # the reference-signature method does its schedule algebra with torch ops on the device
         bidx = torch.repeat_interleave(torch.arange(B, device=dev), num_nodes.to(dev).long())
@@ -448,6 +448,37 @@ def main():
         torch.cuda.synchronize(dev)
         nll_ms = (time.perf_counter() - tq) / 6 * 1e3
         dyn.check_deferred_flags()
+        # one TRAINING step of the reference's batch size (forward in training mode + loss + backward through the module path:
+        # libgcdm_ops.so operators with autograd; no optimiser) -- not the sampling path, reported for completeness
+        try:
+            Bt = 64
+            nt_ = num_nodes[:Bt].to(dev).long()
+            Nt = int(nt_.sum())
+            bt = torch.repeat_interleave(torch.arange(Bt, device=dev), nt_)
+            tb = pkg.config.AttrDict(x=z[:Nt, :3].clone(), batch=bt, mask=torch.ones(Nt, dtype=torch.bool, device=dev),
+                                     props_context=None if ctx_b1 is None else ctx_b1[:Bt][bt],
+                                     h={"categorical": vb.h["categorical"][:Nt], "integer": vb.h["integer"][:Nt]}, num_graphs=Bt, num_nodes_present=nt_)
+            ddpm.train()
+
+            def train_once():
+                for p_ in ddpm.parameters():
+                    p_.grad = None
+                terms = ddpm(tb)
+                (terms[1] + terms[3] + terms[4]).mean().backward()
+
+            for _ in range(2):
+                train_once()
+            torch.cuda.synchronize(dev)
+            tt = time.perf_counter()
+            for _ in range(5):
+                train_once()
+            torch.cuda.synchronize(dev)
+            train_ms = (time.perf_counter() - tt) / 5 * 1e3
+        finally:
+            ddpm.eval()
+            for p_ in ddpm.parameters():
+                p_.grad = None
+            torch.cuda.empty_cache()
 
     # finish the sample properly once (decode) so the path is exercised end to end, and gather like a real run would
     native.check(lib, h, lib.gcdm_sample_final(h, zp, cptr, None, seed, C.c_void_p(out.data_ptr()), fp, stream), "gcdm_sample_final")
@@ -526,6 +557,9 @@ def main():
         res["nll_evaluation"] = {"ms_per_batch": nll_ms, "value": None if nll_ms is None else B / (nll_ms * 1e-3), "unit": "molecules/s",
                                  "what": "likelihood terms of one validation / test batch of the headline shape (EquivariantVariationalDiffusion.forward, evaluation mode: "
                                          "two network evaluations on one handle + the O(N) algebra of the terms in torch, incl. the host-side size-prior lookup)"}
+        res["training_step"] = {"ms_per_batch": train_ms, "batch": 64, "value": None if train_ms is None else 64 / (train_ms * 1e-3), "unit": "molecules/s",
+                                "what": "forward in training mode + loss + backward of one 64-molecule batch on the module path (libgcdm_ops.so operators with "
+                                        "autograd; parity with the reference's autograd: tests/test_modules_gpu.py); outside the sampling path"}
         res["roofline"]["pmc_stale"] = pmc.get("stale")
         res["roofline"]["pmc_collected_at_commit"] = pmc.get("collected_at_commit")
         if other_configs is not None:

@@ -198,6 +198,15 @@ def load() -> C.CDLL:
     return lib
 
 
+def tensor_version(t) -> int:
+    """In-place modification counter of a tensor, -1 for inference tensors (which do not track one; they are created inside
+    torch.inference_mode() and are not modified in place by this package)."""
+    try:
+        return t._version
+    except RuntimeError:
+        return -1
+
+
 class NativeError(RuntimeError):
     pass
 

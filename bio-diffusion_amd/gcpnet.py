@@ -276,8 +276,8 @@ class GCPNetDynamics(nn.Module):
         self._plan_src = None
 
     def _plan_from_batch_index(self, batch_index: torch.Tensor, mask: Optional[torch.Tensor]):
-        src = (batch_index.data_ptr(), batch_index.shape[0], batch_index._version,
-               None if mask is None else (mask.data_ptr(), mask._version))
+        src = (batch_index.data_ptr(), batch_index.shape[0], _native.tensor_version(batch_index),
+               None if mask is None else (mask.data_ptr(), _native.tensor_version(mask)))
         if getattr(self, "_plan_src", None) == src and self._plan_key is not None:
             return
         counts = torch.unique_consecutive(batch_index, return_counts=True)[1]

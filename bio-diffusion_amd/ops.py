@@ -259,7 +259,7 @@ _GRAPH_CACHE = {}
 
 
 def graph_of(edge_index: torch.Tensor, num_nodes: int) -> Graph:
-    key = (edge_index.data_ptr(), tuple(edge_index.shape), edge_index._version, int(num_nodes))
+    key = (edge_index.data_ptr(), tuple(edge_index.shape), _native.tensor_version(edge_index), int(num_nodes))
     g = _GRAPH_CACHE.get("g")
     if g is None or _GRAPH_CACHE.get("key") != key:
         g = Graph(edge_index, num_nodes)

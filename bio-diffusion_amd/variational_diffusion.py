@@ -66,6 +66,16 @@ def polynomial_gamma(num_timesteps: int, noise_precision: float, power: float) -
     return -(np.log(a2) - np.log(1 - a2))
 
 
+def cosine_gamma(num_timesteps: int, s: float = 0.008) -> np.ndarray:
+    """gamma table of the "cosine" schedule in float64 (cosine_beta_schedule + PredefinedNoiseSchedule, variational_diffusion.py:37-58, 220-243)."""
+    steps = num_timesteps + 2
+    x = np.linspace(0, steps, steps)
+    ac = np.cos(((x / steps) + s) / (1 + s) * np.pi * 0.5) ** 2
+    ac = ac / ac[0]
+    a2 = np.cumprod(1.0 - np.clip(1 - (ac[1:] / ac[:-1]), a_min=0, a_max=0.999), axis=0)
+    return -(np.log(a2) - np.log(1 - a2))
+
+
 def slice_cuts(num_nodes: torch.Tensor, K: int) -> List[int]:
     """Molecule indices [c_0 = 0, c_1, ..., c_K = B] that cut a flat batch into K contiguous, non-empty slices of roughly equal work
     (edges, i.e. sum of n^2) -- used when one batch is sampled on K handles / streams."""
@@ -107,11 +117,14 @@ class PredefinedNoiseSchedule(nn.Module):
     def __init__(self, noise_schedule: str, num_timesteps: int, noise_precision: float, verbose: bool = False, **kwargs):
         super().__init__()
         self.timesteps = num_timesteps
-        if "polynomial" not in noise_schedule:
-            raise NotImplementedError(f"noise schedule {noise_schedule!r} is not built (production: polynomial_2)")
-        splits = noise_schedule.split("_")
-        assert len(splits) == 2
-        g = polynomial_gamma(num_timesteps, float(noise_precision), float(splits[1]))
+        if noise_schedule == "cosine":
+            g = cosine_gamma(num_timesteps)
+        elif "polynomial" in noise_schedule:
+            splits = noise_schedule.split("_")
+            assert len(splits) == 2
+            g = polynomial_gamma(num_timesteps, float(noise_precision), float(splits[1]))
+        else:
+            raise ValueError(noise_schedule)
         self.gamma = nn.Parameter(torch.tensor(g).float(), requires_grad=False)
 
     def forward(self, t: torch.Tensor) -> torch.Tensor:
@@ -482,6 +495,65 @@ class EquivariantVariationalDiffusion(nn.Module):
             self._gamma_uploaded = h
         return dyn, lib, h
 
+    def _mol_gen_sample_modules(self, num_samples, num_nodes, device, return_frames, num_timesteps, node_mask, context, fix_noise,
+                                fix_self_conditioning_noise, norm_with_original_timesteps, noise_fn, step_callback):
+        """mol_gen_sample (:1282-1412) step by step through the reference-signature methods of this class -- torch algebra on the device around
+        one network evaluation per step on whichever HIP path the configuration / mask selects.  Serves masked nodes inside the loop and the
+        configurations the fused sampling kernels are not built for; ~10x slower per step than the fused loop.  ``noise_fn(k)``: raw draw k."""
+        num_timesteps = self.T if num_timesteps is None else num_timesteps
+        assert 0 < return_frames <= num_timesteps, "Number of frames cannot be greater than number of timesteps."
+        assert num_timesteps % return_frames == 0, "Number of frames must be evenly divisible by number of timesteps."
+        num_nodes = torch.as_tensor(num_nodes)
+        bi = num_nodes_to_batch_index(num_samples, num_nodes.to(device), device=device)
+        node_mask = torch.ones_like(bi).bool() if node_mask is None else node_mask.to(device)
+        if context is not None:
+            context = context.to(device)[bi] * node_mask.float().unsqueeze(-1)
+        t_norm = self.T if norm_with_original_timesteps else num_timesteps
+        k = [0]
+
+        def draw():
+            if noise_fn is None:
+                return None
+            k[0] += 1
+            return noise_fn(k[0] - 1)
+
+        m = node_mask.float().unsqueeze(-1)
+        raw = draw()
+        if raw is None:
+            z = self.sample_combined_position_feature_noise(torch.zeros_like(bi) if fix_noise else bi, node_mask)
+        else:
+            z = torch.cat((_segment_mean_sub(raw[:, : self.num_x_dims] * m, bi, num_samples, node_mask), raw[:, self.num_x_dims:] * m), dim=-1)
+        self_cond_on = bool(cfg_get(self.diffusion_cfg, "self_condition", False))
+        self_cond = None
+        out = torch.zeros((return_frames,) + tuple(z.shape), device=device)
+        for s in reversed(range(num_timesteps)):
+            s_arr = torch.full((num_samples, 1), s / t_norm, device=device)
+            t_arr = torch.full((num_samples, 1), (s + 1) / t_norm, device=device)
+            z = self.sample_p_zs_given_zt(s=s_arr, t=t_arr, z=z, batch_index=bi, node_mask=node_mask, context=context, fix_noise=fix_noise,
+                                          xh_self_cond=self_cond, noise=draw())
+            if step_callback is not None:
+                step_callback(s, z)
+            if (s * return_frames) % num_timesteps == 0:
+                out[(s * return_frames) // num_timesteps] = self.unnormalize_z(z, node_mask)
+            if self_cond_on:
+                self_cond = self.sample_p_zs_given_zt(s=torch.zeros_like(s_arr), t=s_arr, z=z, batch_index=bi, node_mask=node_mask, context=context,
+                                                      fix_noise=fix_self_conditioning_noise, self_condition=True, noise=draw())
+        x, h = self.sample_p_xh_given_z0(z_0=z, batch_index=bi, node_mask=node_mask, batch_size=num_samples, context=context,
+                                         fix_noise=fix_self_conditioning_noise if self_cond_on else fix_noise, xh_self_cond=self_cond, noise=draw())
+        if return_frames == 1:
+            cog = torch.zeros(num_samples, self.num_x_dims, device=device).index_add_(0, bi, x).abs().max().item()
+            if cog > 5e-2:
+                x = _segment_mean_sub(x, bi, num_samples, node_mask)
+        out[0] = torch.cat([x, h["categorical"].to(x.dtype)] + ([h["integer"].to(x.dtype)] if self.include_charges else []), dim=-1)
+        self.last_flags = 0
+        return out.squeeze(0), bi, node_mask
+
+    def unnormalize_z(self, z, node_mask):
+        """(:761-793)"""
+        nx, nt = self.num_x_dims, self.num_atom_types
+        x, h_cat, h_int = self.unnormalize(z[:, :nx], node_mask, h_cat=z[:, nx:nx + nt], h_int=z[:, nx + nt:])
+        return torch.cat([x, h_cat] + ([h_int] if self.include_charges else []), dim=-1)
+
     @torch.inference_mode()
     def mol_gen_sample(self, num_samples: int, num_nodes: torch.Tensor, device: Union[torch.device, str], return_frames: int = 1,
                        num_timesteps: Optional[int] = None, node_mask: Optional[torch.Tensor] = None,
@@ -495,7 +567,16 @@ class EquivariantVariationalDiffusion(nn.Module):
         (k = 0 for z_T, then one per step, then one for the final decode: the reference's randn call order,
         SURVEY A.5); without it noise comes from on-device Philox(seed)."""
         if generate_x_only:
-            raise NotImplementedError("mol_gen_sample (HIP): generate_x_only is not built")
+            # (the flag is threaded through the reference's sampler for position-only diffusion targets; its only dynamics network,
+            #  GCPNetDynamics, needs the node features and has no such target: gcpnet.py:997-1002)
+            raise NotImplementedError("generate_x_only: the atom_types_and_coords dynamics network always denoises positions AND node features")
+        masked = node_mask is not None and not bool(node_mask.all())
+        if masked or getattr(self.dynamics_network, "fused_unsupported", None) is not None or getattr(self.dynamics_network, "path", "auto") == "modules":
+            # general loop: masked nodes inside the loop, or a configuration the fused sampling kernels are not built for
+            if _init_xh is not None or _t_norm is not None:
+                raise NotImplementedError("property-guided optimisation runs on the fused path only")
+            return self._mol_gen_sample_modules(num_samples, num_nodes, torch.device(device), return_frames, num_timesteps, node_mask, context,
+                                                fix_noise, fix_self_conditioning_noise, norm_with_original_timesteps, noise_fn, step_callback)
         self_cond_on = bool(getattr(self.dynamics_network, "self_condition", False))
         if fix_noise or self_cond_on:
             lanes = 1                  # fix_noise: the noise is centred over the whole flat batch; self-conditioning: not sliced (yet)
@@ -508,11 +589,9 @@ class EquivariantVariationalDiffusion(nn.Module):
         t_norm = _t_norm if _t_norm is not None else (self.T if norm_with_original_timesteps else num_timesteps)
         if num_timesteps > t_norm:
             raise ValueError("num_timesteps exceeds the normalising number of timesteps")
-        if node_mask is not None and not bool(node_mask.all()):
-            raise NotImplementedError("masked nodes are not built (sampling uses an all-True mask)")
-        if lanes > 1 and not _retry_fp32 and len(num_nodes) >= 2 * lanes:
-            if noise_fn is not None or return_frames != 1 or _init_xh is not None or step_callback is not None:
-                raise NotImplementedError("lanes > 1 supports plain sampling with on-device noise only")
+        if lanes > 1 and not _retry_fp32 and len(num_nodes) >= 2 * lanes and not (
+                noise_fn is not None or return_frames != 1 or _init_xh is not None or step_callback is not None):
+            # slices of the flat batch on several handles / streams: plain sampling with on-device noise; anything else runs on one handle
             return self._mol_gen_sample_lanes(num_samples, num_nodes, device, num_timesteps, t_norm, context, seed, lanes)
         device = torch.device(device)
         dyn, lib, h = self._native(device)

@@ -58,6 +58,17 @@ def test_state_dict_matches_imported_reference(ds, cond):
     assert info["atom_decoder"] == rinfo["atom_decoder"] and info["max_n_nodes"] == rinfo["max_n_nodes"]
 
 
+def test_predefined_noise_schedules_equal_the_reference_tables(golden_dir):
+    """cosine, polynomial_2 (production), polynomial_3 at T = 1000 / 250: the gamma lookup tables are BIT-equal to the ones the reference's
+    PredefinedNoiseSchedule built (tests/golden/gamma_tables.npz, make_schedule_golden.py); anything else raises like there."""
+    g = np.load(os.path.join(golden_dir, "gamma_tables.npz"))
+    for key in g.files:
+        name, T = key.split("__")
+        assert np.array_equal(pkg.PredefinedNoiseSchedule(name, int(T), 1e-5).gamma.numpy(), g[key]), key
+    with pytest.raises(ValueError):
+        pkg.PredefinedNoiseSchedule("linear", 1000, 1e-5)
+
+
 def test_forward_refuses_cpu():
     net = pkg.GCPNetDynamics(**pkg.default_cfgs("qm9"))
     bi = torch.zeros(3, dtype=torch.long)

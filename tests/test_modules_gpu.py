@@ -256,3 +256,62 @@ def test_training_step_updates_the_weights_the_sampler_uses():
         after_m = net(batch, xh.to(DEV), t.to(DEV))[1]
     assert (after - before).abs().max().item() > 1e-5
     assert (after - after_m).abs().max().item() <= 1e-5 * max(1.0, after.abs().max().item())
+
+
+@pytest.mark.parametrize("width", ["full", "small"])
+def test_sampling_with_masked_nodes_matches_reference_golden(width, golden_dir):
+    """`mol_gen_sample(..., node_mask=<partial mask>)` -- masked nodes INSIDE the sampling loop (noise, CoM projections, network, decode;
+    variational_diffusion.py:1282-1412) -- against the reference's own 10-step run on the same noise tape (make_masked_sampler_golden.py).
+    "full": production width, the network evaluations run on the fused kernels with the masked plan; "small": reduced width, the module path.
+    z after every step (all rows) within 4 |ref32 - ref64| + 1e-4 max|z|; the decode has exactly zero masked rows and equal discrete outputs."""
+    g = np.load(os.path.join(golden_dir, f"sampler_masked_{width}_qm9.npz"))
+    cfgs = pkg.default_cfgs("qm9")
+    if width == "small":
+        synth.apply_variant(cfgs, None)
+    net = pkg.GCPNetDynamics(**cfgs)
+    assert (net.fused_unsupported is None) == (width == "full")
+    shapes = {k: tuple(v.shape) for k, v in net.state_dict().items()}
+    net.load_state_dict(synth.make_weights(shapes, seed=int(g["weight_seed"]), scale_2d=float(g["weight_scale"])))
+    net = net.to(DEV)
+    ddpm = pkg.EquivariantVariationalDiffusion(net, cfgs["diffusion_cfg"], cfgs["dataloader_cfg"], pkg.dataset_info("qm9")).to(DEV).eval()
+    nn_, mask, steps = torch.tensor(g["num_nodes"]), torch.tensor(g["mask"]), int(g["steps"])
+    N, F = int(nn_.sum()), 6
+    tape = O.TapeNoise(int(g["noise_seed"]))
+    draws = [torch.cat((tape(N, 3), tape(N, F)), dim=-1).to(DEV) for _ in range(steps + 2)]
+    zs = []
+    out, bi, m2 = ddpm.mol_gen_sample(num_samples=len(nn_), num_nodes=nn_, device=DEV, num_timesteps=steps, node_mask=mask.to(DEV),
+                                      noise_fn=lambda k: draws[k], step_callback=lambda s, z: zs.append(z.detach().cpu().clone()))
+    z32, z64 = torch.tensor(g["z32"]).double(), torch.tensor(g["z64"])
+    assert len(zs) == steps
+    for i in range(steps):
+        bound = 4.0 * (z32[i] - z64[i]).abs().max().item() + 1e-4 * z64[i].abs().max().item()
+        assert (zs[i].double() - z32[i]).abs().max().item() <= bound, i        # (masked rows included: the reference's latent is NOT zero there, only its decode)
+    f32, f64 = torch.tensor(g["final32"]).double(), torch.tensor(g["final64"])
+    out = out.cpu()
+    bound = 4.0 * (f32[:, :3] - f64[:, :3]).abs().max().item() + 1e-4 * f64[:, :3].abs().max().item()
+    assert (out[:, :3].double() - f32[:, :3]).abs().max().item() <= bound
+    agree = f32[:, 3:] == f64[:, 3:]
+    assert torch.equal(out[:, 3:].double()[agree], f32[:, 3:][agree]) and bool((out[~mask] == 0).all())
+
+
+def test_module_path_sampling_loop_matches_oracle():
+    """The general sampling loop (reference-signature sample_p_zs_given_zt / sample_p_xh_given_z0 of this package, network on the module
+    path) against the oracle's mol_gen_sample on the same tape: production configuration forced onto the module path, 10 steps."""
+    d = synth.DATASET_DIMS["qm9"]
+    cfgs = pkg.default_cfgs("qm9")
+    net = pkg.GCPNetDynamics(**cfgs)
+    W = synth.make_weights(synth.dynamics_shapes(d["S"], d["V"], d["Se"], d["Ve"], d["L"], synth.dims_h_in(d)), seed=19, scale_2d=0.25)
+    net.load_state_dict(W)
+    net = net.to(DEV)
+    net.path = "modules"
+    ddpm = pkg.EquivariantVariationalDiffusion(net, cfgs["diffusion_cfg"], cfgs["dataloader_cfg"], pkg.dataset_info("qm9")).to(DEV).eval()
+    nn_ = torch.tensor([6, 11, 4])
+    N, F, Tp = int(nn_.sum()), 6, 10
+    want, bi = O.mol_gen_sample(W, O.OracleConfig(num_layers=d["L"]), nn_, O.TapeNoise(5), num_timesteps=Tp)
+    tape = O.TapeNoise(5)
+    draws = [torch.cat((tape(N, 3), tape(N, F)), dim=-1).to(DEV) for _ in range(Tp + 2)]
+    out, bi2, _ = ddpm.mol_gen_sample(num_samples=len(nn_), num_nodes=nn_, device=DEV, num_timesteps=Tp, noise_fn=lambda k: draws[k])
+    out = out.cpu()
+    scale = max(1.0, want[:, :3].abs().max().item())
+    assert torch.equal(bi2.cpu(), bi)
+    assert (out[:, :3] - want[:, :3]).abs().max().item() <= 1e-4 * scale and torch.equal(out[:, 3:], want[:, 3:])
