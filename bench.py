@@ -188,7 +188,11 @@ def quick_config(pkg, name, dev, rank, lanes=2, steps=40, warmup=25):
     net = net.to(dev)
     ddpm = pkg.EquivariantVariationalDiffusion(net, cfgs["diffusion_cfg"], cfgs["dataloader_cfg"], pkg.dataset_info("geom" if wl["dataset"] == "geom" else "qm9"))
     B = wl["B"]
-    num_nodes = torch.full((B,), wl["n"], dtype=torch.int32)
+    if wl["n"] is not None:
+        num_nodes = torch.full((B,), wl["n"], dtype=torch.int32)
+    else:                                  # ragged: sizes from the dataset histogram, as the reference's evaluation driver draws them
+        torch.manual_seed(1 + rank)
+        num_nodes = ddpm.num_nodes_distribution.sample(B).to(torch.int32)
     ctx_b = None
     if d["n_ctx"]:
         ctx_b = torch.randn((B, 1), generator=torch.Generator().manual_seed(2 + rank)).to(dev)
@@ -213,7 +217,42 @@ def quick_config(pkg, name, dev, rank, lanes=2, steps=40, warmup=25):
     ddpm.release_lanes()
     net.release()
     return {"workload": wl["name"], "ms_per_step": ms, "value": B / (ms * 1e-3 * NET_EVALS_PER_SAMPLE), "unit": "molecules/s", "steps": steps,
-            "slices_of_the_batch": lanes, "flags": flags}
+            "slices_of_the_batch": lanes, "flags": flags, "atoms": int(num_nodes.sum()), "edges": int((num_nodes.long() ** 2).sum())}
+
+
+def eval_driver_config(pkg, dev, rank, in_flight, steps=100):
+    """The batch shape of the reference's 10 000-sample evaluation (mol_gen_eval.py:131-137: 100 molecules, sizes from the histogram) through
+    the public sampling entry points, `in_flight` batches at once (each on its own handle / stream): seconds per (steps + 1) evaluations."""
+    wl = WORKLOADS["qm9_eval"]
+    cfgs = pkg.default_cfgs("qm9", ())
+    torch.manual_seed(0)
+    net = pkg.GCPNetDynamics(**cfgs)
+    with torch.no_grad():
+        for p in net.parameters():
+            if p.dim() == 2:
+                p.mul_(0.25)
+    net = net.to(dev).eval()
+    ddpm = pkg.EquivariantVariationalDiffusion(net, cfgs["diffusion_cfg"], cfgs["dataloader_cfg"], pkg.dataset_info("qm9")).to(dev).eval()
+    torch.manual_seed(1 + rank)
+    sizes = [ddpm.num_nodes_distribution.sample(wl["B"]) for _ in range(in_flight)]
+
+    def run(T_):
+        if in_flight == 1:
+            ddpm.mol_gen_sample(num_samples=wl["B"], num_nodes=sizes[0], device=dev, num_timesteps=T_, seed=7 + rank)
+        else:
+            ddpm.mol_gen_sample_concurrent(sizes, dev, num_timesteps=T_, seeds=[7 + rank + b for b in range(in_flight)])
+        torch.cuda.synchronize(dev)
+
+    run(10)
+    ms = float("inf")
+    for _ in range(2):
+        t0 = time.perf_counter()
+        run(steps)
+        ms = min(ms, (time.perf_counter() - t0) / (steps + 1) * 1e3)
+    ddpm.release_lanes()
+    net.release()
+    return {"workload": wl["name"], "batches_in_flight": in_flight, "ms_per_step": ms, "value": in_flight * wl["B"] / (ms * 1e-3 * NET_EVALS_PER_SAMPLE),
+            "unit": "molecules/s", "steps": steps}
 
 
 def log(msg):
@@ -374,6 +413,12 @@ def main():
         c3 = quick_config(pkg, "geom", dev, rank)
         c2 = quick_config(pkg, "qm9cond", dev, rank)
         other_configs = {"configs[2] qm9cond": c2, "configs[3] geom": c3}
+        # the workloads people actually run: ragged batches with sizes from the dataset histogram, and the evaluation driver's
+        # 100-molecule batches, one at a time and four in flight
+        other_configs["qm9_ragged"] = quick_config(pkg, "qm9_ragged", dev, rank)
+        other_configs["geom_ragged"] = quick_config(pkg, "geom_ragged", dev, rank)
+        other_configs["qm9_eval"] = eval_driver_config(pkg, dev, rank, 1)
+        other_configs["qm9_eval_4_in_flight"] = eval_driver_config(pkg, dev, rank, 4)
 
     # Both matrix modes on the same footing: whole batch on ONE handle, wall clock over 8 steps + the dominant kernel's launch time from
     # HIP events recorded by the library on the launch stream (separate un-timed steps).  f16x3 = the default (split-precision MFMA

@@ -82,7 +82,9 @@ struct gcdm_handle {
     // evaluation batches +12 ... 25 %: less round quantisation), fp32 kernels -> 64.  Rows cut by tile boundaries are summed from per-tile
     // partials in tile order (AggSrc), so every choice is bit-reproducible for any molecule size.
     int tile() const { return edge_tile ? edge_tile : 64; }
-    bool x3_weights_ok = true;       // every GEMM weight fits the split-precision images (|W| < 31.9); else mfma_mode 1 is refused
+    bool x3_weights_ok = true;       // every GEMM weight fits the split-precision images at some exponent split k <= X3_MAX_SHIFT; else mfma_mode 1 is refused
+    int x3_shift = 0;                // k: packed weights carry 2^(11-k), activation images 2^(k-11) (X3Const, gcdm_edge_x3.hip.h)
+    X3Const x3c() const { const float w = ldexpf(1.0f, 11 - x3_shift); return X3Const{1.0f / w, w, 1.0f / w, 6.0e4f * w}; }
     int mfma_x3 = 1;                 // requested mode -- 1: split-precision f16 x3 kernels (default; env GCDM_MFMA=f16x3|f32), 0: fp32 MFMA
     bool use_x3() const { return mfma_x3 && x3_weights_ok; }   // effective mode: models whose weights do not fit the split images run fp32 MFMA
     bool attr_set = false;
@@ -158,11 +160,13 @@ std::vector<float> pack_mfma(Dense& W) {
 // gcdm_edge_x3.hip.h), which moves the f16 overflow bound of the activations from 6.5e4 to 1.2e8 at no cost in accuracy (f16
 // denormals are honoured by the MFMA, tools/mfma_denorm.hip); weights stay representable while |W| < 31.9.
 thread_local float g_split_absmax = 0.f;      // largest |W| seen by split_f16 since gcdm_finalize_weights reset it (NaN counts as too large)
+thread_local float g_split_w = 2048.0f;       // 2^(11-k) of the handle being packed
+constexpr int X3_MAX_SHIFT = 6;               // k <= 6: |W| < 2047 and the lo' images of ordinary weights (>= 1e-4) stay normal f16 numbers
 void split_f16(float x, uint16_t& hi, uint16_t& lo) {
     g_split_absmax = (fabsf(x) <= g_split_absmax) ? g_split_absmax : (x == x ? fabsf(x) : INFINITY);
-    x *= 2048.0f;
+    x *= g_split_w;
     const _Float16 h = (_Float16)x;
-    const _Float16 l = (_Float16)((x - (float)h) * 2048.0f);
+    const _Float16 l = (_Float16)((x - (float)h) * g_split_w);
     std::memcpy(&hi, &h, 2);
     std::memcpy(&lo, &l, 2);
 }
@@ -520,6 +524,17 @@ int gcdm_finalize_weights(gcdm_handle* h) {
     const int S = GCDM_S, V = GCDM_V, Se = h->Se, Ve = h->Ve, H0 = h->H0, L = h->L;
     Pool pool;
     g_split_absmax = 0.f;
+    // exponent split of the f16 images: the smallest k whose packed weights 2^(11-k) W stay inside f16 (1.5 x head room for the constants the
+    // host folds into some matrices: X3_C).  Every released / synthetic model so far has k = 0.
+    {
+        float wmax = 0.f;
+        for (const auto& kv : h->host_w)
+            for (float v : kv.second) wmax = (fabsf(v) <= wmax) ? wmax : (v == v ? fabsf(v) : INFINITY);
+        int k = 0;
+        while (k < X3_MAX_SHIFT && 1.5f * wmax * ldexpf(1.0f, 11 - k) >= 65504.0f) ++k;
+        h->x3_shift = k;
+        g_split_w = ldexpf(1.0f, 11 - k);
+    }
     // ---- edge embedding (1,1) -> (Se,Ve), bottleneck 1: H = max(1, Ve) = Ve ------------------------
     size_t o_ws, o_bs, o_wd, o_wdf, o_kap, o_wg, o_bg, o_wd1, o_wdf1, o_kap1, o_exwH, o_exwL, o_exgH, o_exgL;
     {
@@ -763,8 +778,9 @@ int gcdm_finalize_weights(gcdm_handle* h) {
             return -1;
         h->attr_set = true;
     }
-    // split-precision images hold 2^11 W in f16: a checkpoint with a matrix weight of 31.9 or more (or NaN) cannot use them -> fp32 MFMA only
-    h->x3_weights_ok = g_split_absmax < 31.9f;
+    // the packed images hold 2^(11-k) W in f16: if even k = X3_MAX_SHIFT cannot hold the largest packed weight (or one is NaN) -> fp32 MFMA only
+    h->x3_weights_ok = g_split_absmax * g_split_w < 65504.0f;
+    g_split_w = 2048.0f;
     h->finalized = true;
     h->host_w.clear();
     return 0;
@@ -908,7 +924,7 @@ int gcdm_forward_sc(gcdm_handle* h, const float* xh, const float* xh_sc, const f
                      (v4f*)h->EP4, h->AL, h->U, h->FR,
                      h->sc, (h->sc ? 2 : 1) + h->Ve + 9, h->X0SC, h->ee_wd1, h->ee_wdf1, h->ee_kappa1, h->BL, h->USC};
     if (h->use_x3()) {
-        EdgeEmbedX3Args ex{ea, h->ee_xwH, h->ee_xwL, h->ee_xgH, h->ee_xgL};
+        EdgeEmbedX3Args ex{h->x3c(), ea, h->ee_xwH, h->ee_xwL, h->ee_xgH, h->ee_xgL};
         const int egrid = (E + 127) / 128;           // 4 waves x 32 edges
         if (h->Se == 64) hipLaunchKernelGGL((k_edge_embed_x3<64, 16>), dim3(egrid), dim3(256), 0, st, ex);
         else hipLaunchKernelGGL((k_edge_embed_x3<16, 8>), dim3(egrid), dim3(256), 0, st, ex);
@@ -936,6 +952,7 @@ int gcdm_forward_sc(gcdm_handle* h, const float* xh, const float* xh_sc, const f
     };
     const int ngrid = (N + NT_ - 1) / NT_;
     NodeX3Args nx{};
+    nx.x3c = h->x3c();
     bool node_kb_ok = true;
     auto launch_node = [&](bool embed, int next_layer, const LayerDev* cur) {
         if (h->use_x3()) {
@@ -977,6 +994,7 @@ int gcdm_forward_sc(gcdm_handle* h, const float* xh, const float* xh_sc, const f
         if (h->profile) HIP_OK(h, hipEventRecord(h->ev[2 * l], st));
         if (h->use_x3()) {
             EdgeMsgX3Args xa{};
+            xa.x3c = h->x3c();
             xa.base = ma;
             xa.w0H = d.w0H; xa.w0L = d.w0L; xa.KB0 = d.KB0; xa.wg0H = d.wg0H; xa.wg0L = d.wg0L; xa.KB = d.KB;
             for (int k = 0; k < 3; ++k) { xa.wH[k] = d.wH[k]; xa.wL[k] = d.wL[k]; xa.wgH[k] = d.wgH[k]; xa.wgL[k] = d.wgL[k]; }
@@ -1213,7 +1231,7 @@ int gcdm_set_option(gcdm_handle* h, const char* name, int32_t value) {
     const std::string k(name);
     if (k == "mfma_mode") {                 // 0: fp32 MFMA, 1: split-precision f16 x3 (fp32-equivalent, 5.3x the matrix rate)
         if (value != 0 && value != 1) return fail(h, "gcdm_set_option(mfma_mode): 0 or 1");
-        if (value == 1 && !h->x3_weights_ok) return fail(h, "gcdm_set_option(mfma_mode): a weight of this model is >= 31.9 in magnitude, outside the split-precision images; only mode 0 (fp32 MFMA) is available");
+        if (value == 1 && !h->x3_weights_ok) return fail(h, "gcdm_set_option(mfma_mode): a weight of this model is >= 2047 in magnitude (or not finite), outside the split-precision images at every exponent split; only mode 0 (fp32 MFMA) is available");
         h->mfma_x3 = value;
         return 0;
     }
@@ -1240,6 +1258,7 @@ int gcdm_get_option(const gcdm_handle* h, const char* name) {
     if (k == "flat_prev") return h->flat_prev;
     if (k == "flat_next") return h->flat_next;
     if (k == "node_base") return (int)h->node_base;
+    if (k == "x3_shift") return h->x3_shift;
     return -1;
 }
 

@@ -32,11 +32,21 @@ typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef _Float16 h4 __attribute__((ext_vector_type(4)));
 
 #define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16((a), (b), (c), 0, 0, 0)
-#define X3_SCALE 2048.0f
-#define X3_INV_SCALE (1.0f / 2048.0f)
-#define X3_PRE (1.0f / 2048.0f)          // every image holds x * 2^-11, the packed weights carry the 2^11 (gcdm_api.hip: split_f16); with
-                                         // PRE = 1 / SCALE the lo' image is f16(x - hi * 2^11): one mixed FMA, no extra multiply
-#define X3_RANGE (6.0e4f * 2048.0f)      // bound on the un-scaled activation
+// How the 16 exponent bits of an f16 pair are shared between weights and activations is a property of the CHECKPOINT, chosen once per handle
+// (gcdm_finalize_weights): packed weights carry w = 2^(11-k), activation images 1/w, with k the smallest shift that keeps the largest
+// weight inside f16 -- k = 0 (|W| < 31.9, activations up to 1.3e8) for every model seen so far; a checkpoint with larger weights moves the
+// split (k = 5: |W| < 1023, activations up to 4.2e6) instead of losing the split-precision mode.  The three constants are the first
+// member of every split-precision kernel's argument struct and are read from the kernel-argument segment (scalar loads, no plumbing through
+// the device functions):   hi = f16(x * pre),  lo' = f16(x - hi * scale),  result = am + al * inv   (inv = pre; all powers of two, exact).
+struct X3Const {
+    float pre, scale, inv, range;          // 2^(k-11), 2^(11-k), 2^(k-11), 6e4 * scale (bound on the un-scaled activation)
+};
+typedef const X3Const __attribute__((address_space(4))) * x3const_ptr;
+#define X3_KARG ((x3const_ptr)__builtin_amdgcn_kernarg_segment_ptr())
+#define X3_SCALE (X3_KARG->scale)
+#define X3_INV_SCALE (X3_KARG->inv)
+#define X3_PRE (X3_KARG->pre)
+#define X3_RANGE (X3_KARG->range)
 // Range guard.  An activation beyond the images' range becomes inf in its hi image, every product with it is inf / NaN, and -- all state
 // updates of the network being residual -- the non-finite value reaches the network output: the LAST node kernel raises
 // GCDM_FLAG_F16_RANGE when vel or a projected feature is not finite (the caller then re-runs in fp32 mode, which also decides whether a
@@ -53,7 +63,6 @@ typedef _Float16 h4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void split16(float x, _Float16& hi, _Float16& lo) {
     hi = (_Float16)(x * X3_PRE);
     // x - hi * 2^11 (hi holds x * 2^-11), written so that it maps to one mixed-precision FMA (v_fma_mixlo_f16): the product is exact (power of two)
-    static_assert(X3_SCALE * X3_PRE == 1.0f, "lo' = x - hi * 2^11");
     lo = (_Float16)__builtin_fmaf((float)hi, -X3_SCALE, x);
 }
 
@@ -789,6 +798,7 @@ __device__ __forceinline__ void tile_gemm_x3s(f32x16 (&am)[MT][NT], f32x16 (&al)
 }
 
 struct EdgeMsgX3Args {
+    X3Const x3c;                      // MUST stay the first member (X3_KARG)
     EdgeMsgArgs base;                 // everything the fp32 kernel takes (tables, biases, vector weights, attention)
     const h8* w0H; const h8* w0L; int KB0;          // msg0 per-edge part, packed [8][KB0][64] x 8 f16
     const h8* wg0H; const h8* wg0L;                 // msg0 gate, packed [8][2][64]

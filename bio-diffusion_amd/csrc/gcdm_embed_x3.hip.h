@@ -15,6 +15,7 @@
 #include "gcdm_edge_x3.hip.h"
 
 struct EdgeEmbedX3Args {
+    X3Const x3c;            // MUST stay the first member (X3_KARG)
     EdgeEmbedArgs base;
     const h8 *wH, *wL;      // scalar_out as A operands [ceil(Se/32)][2][64]
     const h8 *wgH, *wgL;    // vector_out_scale as A operands [Se/16][64]

@@ -16,6 +16,7 @@ struct GcpX3 {
 };
 
 struct NodeX3Args {
+    X3Const x3c;                   // MUST stay the first member (X3_KARG)
     NodeArgs base;
     GcpX3 emb, ff, pos, proj;
     const h8 *wpqH, *wpqL;         // next layer's msg0 node halves, packed [16][16][64]

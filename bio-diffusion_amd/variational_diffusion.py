@@ -158,6 +158,55 @@ class NumNodesDistribution(nn.Module):
         return torch.log(self.prob + self.eps)[idcs]
 
 
+RANGE_CHECK_EVERY = 25          # steps between two looks at the f16-range flag inside the fused sampling loops
+
+
+class _RangeCheckpoints:
+    """Range guard of the split-precision mode INSIDE a sampling loop.  Every RANGE_CHECK_EVERY steps the loop hands over a snapshot of its
+    state (latent + counters) together with an asynchronous copy of the device flag word; one interval later that copy has long arrived and
+    is looked at without stalling the GPU: clean -> the snapshot becomes the restart point; GCDM_FLAG_F16_RANGE -> the loop resumes from the
+    previous restart point with fp32 MFMA instead of re-running the whole trajectory (an overflow at step 900 of 1000 costs <= 1.3x a
+    clean run; it used to cost 1 + 2.7)."""
+
+    def __init__(self, device):
+        self.device = device
+        self.good = None             # (state, tensors) verified clean
+        self.pend = None             # (state, tensors, event, host flag) waiting for its flag copy
+        self.rewinds = 0
+
+    def snapshot(self, state: Dict[str, Any], tensors: List[torch.Tensor], flags: torch.Tensor):
+        """Called on the stream the latent is valid on.  Returns the restart point to rewind to if the PREVIOUS snapshot's flag is dirty."""
+        rewind = self.resolve()
+        if rewind is not None:
+            return rewind
+        host = torch.zeros(flags.numel(), dtype=torch.int32).pin_memory()
+        copies = [t.clone() for t in tensors]
+        host.copy_(flags, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(self.device))
+        self.pend = (dict(state), copies, ev, host)
+        return None
+
+    def resolve(self, final_flags: Optional[int] = None):
+        """Looks at the pending snapshot's flag copy (or, at the end of the run, at the final flag word).  Returns (state, tensors) to rewind
+        to, or None if the trajectory so far is clean."""
+        if self.pend is not None:
+            st, copies, ev, host = self.pend
+            ev.synchronize()
+            dirty = any(int(v) & _native.FLAG_F16_RANGE for v in host.tolist())
+            self.pend = None
+            if dirty:
+                return self._rewind()
+            self.good = (st, copies)
+        if final_flags is not None and final_flags & _native.FLAG_F16_RANGE:
+            return self._rewind()
+        return None
+
+    def _rewind(self):
+        self.rewinds += 1
+        return self.good
+
+
 class _Batch(AttrDict):
     """Attribute bag with the three fields the dynamics network reads (stand-in for torch_geometric Batch)."""
 
@@ -635,43 +684,73 @@ class EquivariantVariationalDiffusion(nn.Module):
             _native.check(lib, h, lib.gcdm_encode_samples(h, C.c_void_p(xin.data_ptr()), C.c_void_p(z.data_ptr()), fptr, stream),
                           "gcdm_encode_samples")
         self_cond = torch.zeros_like(z) if self_cond_on else None     # the estimate fed back into the next step (:1363-1375)
-        for s in reversed(range(0, num_timesteps)):
-            keep, p = nptr()
+        guard = _RangeCheckpoints(device) if (dyn.mfma_mode == 1 and not _retry_fp32) else None
+        fell_back = False
+
+        def restart(point):
+            """Resume from a clean snapshot with fp32 MFMA (the f16-range flag was raised after it)."""
+            nonlocal k, fell_back
+            st0, (z0, *rest) = point
+            z.copy_(z0)
             if self_cond_on:
-                keep2, p2 = nptr()
-                st = lib.gcdm_sample_step_sc(h, C.c_void_p(z.data_ptr()), C.c_void_p(self_cond.data_ptr()), int(s != num_timesteps - 1), ctx_ptr, s, t_norm,
-                                             p, p2, C.c_uint64(seed), fptr, stream)
-            else:
-                st = lib.gcdm_sample_step(h, C.c_void_p(z.data_ptr()), ctx_ptr, s, t_norm, p, C.c_uint64(seed), fptr, stream)
-            _native.check(lib, h, st, "gcdm_sample_step")
-            if return_frames > 1 and (s * return_frames) % num_timesteps == 0:             # save frame (:1354-1361)
-                fr = frames[(s * return_frames) // num_timesteps]
-                _native.check(lib, h, lib.gcdm_unnormalize_z(h, C.c_void_p(z.data_ptr()), C.c_void_p(fr.data_ptr()), stream), "gcdm_unnormalize_z")
-            if step_callback is not None:
-                step_callback(s, z)
-        keep, p = nptr()
-        _native.check(lib, h, lib.gcdm_set_option(h, b"cog_fix", 1 if return_frames == 1 else 0), "gcdm_set_option")   # :1389
-        if self_cond_on:
-            st = lib.gcdm_sample_final_sc(h, C.c_void_p(z.data_ptr()), C.c_void_p(self_cond.data_ptr()) if num_timesteps > 0 else None, ctx_ptr, p,
-                                          C.c_uint64(seed), C.c_void_p(out.data_ptr()), fptr, stream)
-        else:
-            st = lib.gcdm_sample_final(h, C.c_void_p(z.data_ptr()), ctx_ptr, p, C.c_uint64(seed), C.c_void_p(out.data_ptr()), fptr, stream)
-        lib.gcdm_set_option(h, b"cog_fix", 1)
-        lib.gcdm_set_option(h, b"fix_noise", 0)
-        _native.check(lib, h, st, "gcdm_sample_final")
-        fl = int(flags.item())   # the one host sync of the run
-        if fl & _native.FLAG_F16_RANGE:
-            if _retry_fp32:
-                raise RuntimeError("f16 range flag raised in fp32 mode (internal error)")
-            log.warning("An activation left the f16 range of the split-precision kernels; re-running the sample with fp32 MFMA.")
-            dyn.set_mfma_mode(0)
-            try:
-                return self.mol_gen_sample(num_samples, num_nodes, device, return_frames, num_timesteps, None, context_in, fix_noise,
-                                           generate_x_only, fix_self_conditioning_noise, norm_with_original_timesteps,
-                                           noise_fn=noise_fn, seed=seed, step_callback=step_callback, _retry_fp32=True,
-                                           _init_xh=_init_xh, _t_norm=t_norm)
-            finally:
+                self_cond.copy_(rest[0])
+            k = st0["k"]
+            flags.bitwise_and_(~_native.FLAG_F16_RANGE)
+            if not fell_back:
+                log.warning("An activation left the f16 range of the split-precision kernels; resuming from step %d with fp32 MFMA.", st0["s"])
+                dyn.set_mfma_mode(0)
+                fell_back = True
+            return st0["s"]
+
+        try:
+            s = num_timesteps - 1
+            first = {"s": s, "k": k}
+            if guard is not None:
+                guard.good = (first, [z.clone()] + ([self_cond.clone()] if self_cond_on else []))
+            while True:
+                while s >= 0:
+                    if guard is not None and not fell_back and (num_timesteps - 1 - s) % RANGE_CHECK_EVERY == 0 and s != num_timesteps - 1:
+                        point = guard.snapshot({"s": s, "k": k}, [z] + ([self_cond] if self_cond_on else []), flags)
+                        if point is not None:
+                            s = restart(point)
+                            continue
+                    keep, p = nptr()
+                    if self_cond_on:
+                        keep2, p2 = nptr()
+                        st = lib.gcdm_sample_step_sc(h, C.c_void_p(z.data_ptr()), C.c_void_p(self_cond.data_ptr()), int(s != num_timesteps - 1), ctx_ptr, s, t_norm,
+                                                     p, p2, C.c_uint64(seed), fptr, stream)
+                    else:
+                        st = lib.gcdm_sample_step(h, C.c_void_p(z.data_ptr()), ctx_ptr, s, t_norm, p, C.c_uint64(seed), fptr, stream)
+                    _native.check(lib, h, st, "gcdm_sample_step")
+                    if return_frames > 1 and (s * return_frames) % num_timesteps == 0:             # save frame (:1354-1361)
+                        fr = frames[(s * return_frames) // num_timesteps]
+                        _native.check(lib, h, lib.gcdm_unnormalize_z(h, C.c_void_p(z.data_ptr()), C.c_void_p(fr.data_ptr()), stream), "gcdm_unnormalize_z")
+                    if step_callback is not None:
+                        step_callback(s, z)              # (fires again for the steps a resumed run repeats)
+                    s -= 1
+                keep, p = nptr()
+                _native.check(lib, h, lib.gcdm_set_option(h, b"cog_fix", 1 if return_frames == 1 else 0), "gcdm_set_option")   # :1389
+                if self_cond_on:
+                    st = lib.gcdm_sample_final_sc(h, C.c_void_p(z.data_ptr()), C.c_void_p(self_cond.data_ptr()) if num_timesteps > 0 else None, ctx_ptr, p,
+                                                  C.c_uint64(seed), C.c_void_p(out.data_ptr()), fptr, stream)
+                else:
+                    st = lib.gcdm_sample_final(h, C.c_void_p(z.data_ptr()), ctx_ptr, p, C.c_uint64(seed), C.c_void_p(out.data_ptr()), fptr, stream)
+                lib.gcdm_set_option(h, b"cog_fix", 1)
+                _native.check(lib, h, st, "gcdm_sample_final")
+                fl = int(flags.item())   # the one host sync of a clean run
+                point = guard.resolve(fl) if (guard is not None and not fell_back) else None
+                if point is None:
+                    break
+                s = restart(point)       # an overflow in the last interval (or in the decode): repeat it in fp32
+        finally:
+            lib.gcdm_set_option(h, b"fix_noise", 0)
+            if fell_back:
                 dyn.set_mfma_mode(1)
+        if fl & _native.FLAG_F16_RANGE:
+            raise RuntimeError("f16 range flag raised in fp32 mode (internal error)")
+        if fell_back:
+            fl |= _native.FLAG_F16_RANGE          # reported in last_flags: part of this sample was computed with fp32 MFMA
+        self.last_range_rewinds = 0 if guard is None else guard.rewinds
         if fl & _native.FLAG_MEAN_NOT_ZERO:
             raise AssertionError("Mean is not zero: the supplied samples are not centred (assert_mean_zero_with_mask, relative error >= 1e-2)")
         if fl & _native.FLAG_NAN_VEL:
@@ -1015,24 +1094,67 @@ class EquivariantVariationalDiffusion(nn.Module):
     def _mol_gen_sample_lanes(self, num_samples, num_nodes, device, num_timesteps, t_norm, context, seed, K):
         device = torch.device(device)
         sb = self._SlicedBatch(self, num_nodes, device, context, seed, K)
+        guard = _RangeCheckpoints(device) if sb.dyn.mfma_mode == 1 else None
+        fell_back = False
+        cs = torch.cuda.current_stream(device)
+
+        def fence():                         # the slices continue only after what the caller's stream has just done with their buffers
+            ev = torch.cuda.Event()
+            ev.record(cs)
+            for w in sb.sl:
+                w["lane"].stream.wait_event(ev)
+
+        def restart(point):
+            nonlocal fell_back
+            st0, (z0,) = point
+            sb.wait()
+            sb.bufs[sb.cur].copy_(z0)
+            sb.flags.bitwise_and_(~_native.FLAG_F16_RANGE)
+            if not fell_back:
+                log.warning("An activation left the f16 range of the split-precision kernels; resuming from step %d with fp32 MFMA.", st0["s"])
+                for w in sb.sl:
+                    w["lane"].lib.gcdm_set_option(w["lane"].h, b"mfma_mode", 0)
+                fell_back = True
+            fence()
+            return st0["s"]
+
         try:
             sb.init()
-            for s in reversed(range(num_timesteps)):
-                sb.step(s, t_norm)
-            sb.final()
+            s = num_timesteps - 1
+            if guard is not None:
+                sb.wait()
+                guard.good = ({"s": s}, [sb.bufs[sb.cur].clone()])
+                fence()
+            while True:
+                while s >= 0:
+                    if guard is not None and not fell_back and (num_timesteps - 1 - s) % RANGE_CHECK_EVERY == 0 and s != num_timesteps - 1:
+                        sb.wait()
+                        point = guard.snapshot({"s": s}, [sb.bufs[sb.cur]], sb.flags)
+                        fence()
+                        if point is not None:
+                            s = restart(point)
+                            continue
+                    sb.step(s, t_norm)
+                    s -= 1
+                sb.final()
+                fl_all = sb.flags.cpu().tolist()                 # the one host sync of a clean run
+                fl = 0
+                for v in fl_all:
+                    fl |= int(v)
+                point = guard.resolve(fl) if (guard is not None and not fell_back) else None
+                if point is None:
+                    break
+                s = restart(point)
         finally:
+            if fell_back:
+                for w in sb.sl:
+                    w["lane"].lib.gcdm_set_option(w["lane"].h, b"mfma_mode", 1)
             sb.close()
-        fl_all = sb.flags.cpu().tolist()                         # the one host sync of the run
-        fl = 0
-        for v in fl_all:
-            fl |= int(v)
         if fl & _native.FLAG_F16_RANGE:
-            log.warning("An activation left the f16 range of the split-precision kernels; re-running the sample with fp32 MFMA.")
-            sb.dyn.set_mfma_mode(0)
-            try:
-                return self.mol_gen_sample(num_samples, num_nodes, device, 1, num_timesteps, None, context, seed=seed, _retry_fp32=True, _t_norm=t_norm)
-            finally:
-                sb.dyn.set_mfma_mode(1)
+            raise RuntimeError("f16 range flag raised in fp32 mode (internal error)")
+        if fell_back:
+            fl |= _native.FLAG_F16_RANGE              # reported in last_flags: part of this sample was computed with fp32 MFMA
+        self.last_range_rewinds = 0 if guard is None else guard.rewinds
         drift = [bool(int(v) & _native.FLAG_COG_DRIFT) for v in fl_all]
         if any(drift) and not all(drift):
             sb.recentre_undrifted(drift)

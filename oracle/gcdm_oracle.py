@@ -56,6 +56,21 @@ class OracleConfig:
     norm_values: Sequence[float] = (1.0, 4.0, 10.0)
     norm_biases: Sequence[Optional[float]] = (None, 0.0, 0.0)
     self_condition: bool = False         # diffusion_cfg.self_condition (False in both production configs)
+    # ---- the rest of the path's Hydra surface (production values as defaults; module_cfg / layer_cfg / mp_cfg keys of the same names) ----
+    selected_GCP: str = "GCP2"           # "GCP" = the first-generation module (gcpnet.py:33-262)
+    nonlinearities: Sequence[Optional[str]] = ("silu", "silu")
+    vector_gate: bool = True
+    frame_gate: bool = False
+    sigma_frame_gate: bool = False
+    vector_residual: bool = False
+    vector_frame_residual: bool = False
+    ablate_frame_updates: bool = False
+    use_residual_message_gcp: bool = True
+    use_scalar_message_attention: bool = True
+    num_feedforward_layers: int = 1
+    use_gcp_norm: bool = False
+    pre_norm: bool = False               # layer_cfg.pre_norm (GCPEmbedding.pre_norm is always True, gcpnet.py:504)
+    update_positions_with_vector_sum: bool = False
 
     @property
     def num_node_scalar_features(self) -> int:
@@ -154,12 +169,101 @@ def safe_norm(x: Tensor, dim: int, eps: float = 1e-8) -> Tensor:
 
 
 def _act(name: Optional[str]) -> Callable[[Tensor], Tensor]:
-    """src/models/__init__.py:30-45 (only the two values the production config uses)."""
+    """get_nonlinearity, src/models/__init__.py:30-45."""
     if name is None:
         return lambda t: t
-    if name == "silu":
-        return F.silu
-    raise NotImplementedError(name)
+    table = {"silu": F.silu, "relu": F.relu, "leakyrelu": lambda t: F.leaky_relu(t, negative_slope=1e-2), "selu": F.selu, "sigmoid": torch.sigmoid}
+    if name.lower().strip() not in table:
+        raise NotImplementedError(name)
+    return table[name.lower().strip()]
+
+
+def vectorize(gate: Tensor, row: Tensor, frames: Tensor, node_inputs: bool, dim_size: int) -> Tensor:
+    """components/__init__.py:227-272: gate [M, 9] -> vectors [M, 3, 3], gv[k] = gate[3k] a + gate[3k+1] b + gate[3k+2] c with (a, b, c) the rows of
+    the edge's frame; node mode: gate of the edge's source node, scatter-MEAN over ``row``."""
+    g = (gate[row] if node_inputs else gate).reshape(-1, 3, 3)
+    gv = torch.matmul(g, frames)                                # [E, k, xyz]
+    if not node_inputs:
+        return gv
+    out = torch.zeros(dim_size, 3, 3, dtype=gate.dtype).index_add_(0, row, gv)
+    cnt = torch.zeros(dim_size, dtype=gate.dtype).index_add_(0, row, torch.ones(row.shape[0], dtype=gate.dtype))
+    return out / cnt.clamp(min=1).reshape(-1, 1, 1)
+
+
+def gcp_layernorm(P: Params, pre: str, s: Tensor, v: Optional[Tensor], use_gcp_norm: bool, eps: float = 1e-8):
+    """GCPLayerNorm, components/__init__.py:779-808: LayerNorm on the scalars, vectors / sqrt(mean_c clamp(|v_c|^2, eps)); identity without use_gcp_norm."""
+    if not use_gcp_norm:
+        return s, v
+    s = F.layer_norm(s, (s.shape[-1],), P[pre + "scalar_norm.weight"], P[pre + "scalar_norm.bias"])
+    if v is not None:
+        vn = torch.clamp(torch.sum(v ** 2, dim=-1, keepdim=True), min=eps)
+        v = v / torch.sqrt(torch.mean(vn, dim=-2, keepdim=True))
+    return s, v
+
+
+def gcp_any(P: Params, pre: str, s: Tensor, v: Tensor, row: Tensor, frames: Tensor, node_inputs: bool, acts: Sequence[Optional[str]],
+            vector_out: bool, cfg: "OracleConfig", feedforward_out: bool = False, vector_residual: bool = False):
+    """One GCP / GCP2 with the flags of ``cfg`` (module_cfg): GCP2.forward gcpnet.py:418-491 with process_vector_with_frames :378-408 /
+    process_vector_without_frames :357-375; GCP.forward :190-262 with process_vector :121-140 and process_vector_frames :150-188."""
+    a_s, a_v = _act(acts[0]), _act(acts[1])
+    ident_v = acts[1] is None
+    M = s.shape[0]
+    lin = lambda key, t: F.linear(t, P[pre + key + ".weight"], P.get(pre + key + ".bias"))
+
+    def scalar_out(merged):
+        if feedforward_out:
+            return lin("scalar_out.2", F.silu(lin("scalar_out.0", merged)))
+        return lin("scalar_out", merged)
+
+    def self_gate(vr):
+        return vr if ident_v else vr * a_v(safe_norm(vr, dim=-1).unsqueeze(-1))
+
+    def frame_gate(p, vr):
+        gate = lin("vector_out_scale_frames", a_v(p))
+        gvr = (vectorize(gate, row, frames, node_inputs, M).transpose(-1, -2) @ P[pre + "vector_up_frames.weight"].T).transpose(-1, -2)
+        return vr * a_v(safe_norm(gvr, dim=-1).unsqueeze(-1))
+
+    vt = v.transpose(-1, -2)                                    # [M, 3, V_in]
+    vh = vt @ P[pre + "vector_down.weight"].T
+    merged = torch.cat((s, safe_norm(vh, dim=-2)), dim=-1)
+    if cfg.selected_GCP == "GCP2":
+        if not cfg.ablate_frame_updates:
+            u = (vt @ P[pre + "vector_down_frames.weight"].T).transpose(-1, -2)
+            merged = torch.cat((merged, scalarize(u, row, frames, node_inputs, M)), dim=-1)
+        p = scalar_out(merged)
+        if not vector_out:
+            return a_s(p)
+        up = vh @ P[pre + "vector_up.weight"].T
+        vr = ((up + vt) if vector_residual else up).transpose(-1, -2)
+        if cfg.frame_gate and not cfg.ablate_frame_updates:
+            vr = frame_gate(p, vr)
+        elif cfg.vector_gate:
+            vr = vr * torch.sigmoid(lin("vector_out_scale", a_v(p))).unsqueeze(-1)
+        else:
+            vr = self_gate(vr)
+        return a_s(p), vr
+    # ---- GCP (v1) ----
+    p = scalar_out(merged)
+    vr = v
+    if vector_out:
+        up = vh @ P[pre + "vector_up.weight"].T
+        vr = ((up + vt) if vector_residual else up).transpose(-1, -2)
+        vr = vr * torch.sigmoid(lin("vector_out_scale", a_v(p))).unsqueeze(-1) if cfg.vector_gate else self_gate(vr)
+    p = a_s(p)
+    if cfg.ablate_frame_updates:
+        return (p, vr) if vector_out else p
+    u = (vr.transpose(-1, -2) @ P[pre + "vector_down_frames.weight"].T).transpose(-1, -2)
+    p = lin("scalar_out_frames", torch.cat((p, scalarize(u, row, frames, node_inputs, M)), dim=-1))
+    if not vector_out:
+        return a_s(p)
+    if cfg.sigma_frame_gate:
+        vr = vr * torch.sigmoid(lin("vector_out_scale_sigma_frames", a_v(p))).unsqueeze(-1)
+    elif cfg.frame_gate:
+        gated = frame_gate(p, vr)
+        vr = gated + vr if cfg.vector_frame_residual else gated
+    else:
+        vr = self_gate(vr)
+    return a_s(p), vr
 
 
 # ------------------------------------------------------------------------------------------------
@@ -227,6 +331,77 @@ def interaction_layer(P: Params, pre: str, h: Tensor, chi: Tensor, e: Tensor, xi
     _, pv = gcp2(P, pre + "node_position_update_gcp.", h, chi, row, frames, True, "silu", True)
     x = (x + pv[:, 0, :] * cfg.node_positions_weight) * maskf[:, None]
     return h, chi, x
+
+
+def dynamics_forward_general(P: Params, cfg: OracleConfig, xh: Tensor, t: Tensor, batch_index: Tensor, mask: Optional[Tensor] = None,
+                             context: Optional[Tensor] = None) -> Tensor:
+    """GCPNetDynamics.atom_types_and_coords_forward (gcpnet.py:1069-1232) for ANY setting of the module / layer / mp configuration groups that
+    OracleConfig carries -- GCP or GCP2, gates, residuals, ablated frame updates, GCPLayerNorm, message / feed-forward depths, vector-sum
+    position updates (GCPEmbedding :551-603, GCPMessagePassing :676-737, GCPInteractions :834-930).  ``dynamics_forward`` is the same
+    function specialised to the production flags; pinned by tests/golden/dyn_variant_*.npz."""
+    N = xh.shape[0]
+    mask = torch.ones(N, dtype=torch.bool) if mask is None else mask
+    maskf = mask.to(xh.dtype)
+    B = int(batch_index.max().item()) + 1
+    xh = xh * maskf[:, None]
+    x0, h = xh[:, :3].clone(), xh[:, 3:].clone()
+    row, col = fully_connected_edges(batch_index, mask)
+    chi = orientations(x0)
+    e, xi = edge_features(x0, row, col)
+    if cfg.condition_on_time:
+        h = torch.cat((h, t.view(N, 1)), dim=-1)
+    if cfg.num_context:
+        h = torch.cat((h, context.view(N, cfg.num_context)), dim=-1)
+    x = centralize(x0, batch_index, B, mask)
+    frames = localize(x, row, col)
+    nl = tuple(cfg.nonlinearities)
+    # GCPEmbedding (pre_norm True; its edge GCP keeps ("silu", "silu"), gcpnet.py:502, 1006-1014)
+    e, xi = gcp_layernorm(P, "gcp_embedding.edge_normalization.", e, xi, cfg.use_gcp_norm)
+    h, chi = gcp_layernorm(P, "gcp_embedding.node_normalization.", h, chi, cfg.use_gcp_norm)
+    e, xi = gcp_any(P, "gcp_embedding.edge_embedding.", e, xi, row, frames, False, ("silu", "silu"), True, cfg)
+    h, chi = gcp_any(P, "gcp_embedding.node_embedding.", h, chi, row, frames, True, (None, None), True, cfg)
+    L = cfg.num_layers if cfg.num_layers else infer_num_layers(P)
+    for l in range(L):
+        pre = f"interaction_layers.{l}."
+        if cfg.pre_norm:
+            h, chi = gcp_layernorm(P, pre + "gcp_norm.0.", h, chi, cfg.use_gcp_norm)
+        # message (:676-713): primary GCPs (first / last) use default_bottleneck and no residual, secondary ones module_cfg.vector_residual
+        ms = torch.cat((h[row], e, h[col]), dim=-1)
+        mv = torch.cat((chi[row], xi, chi[col]), dim=1)
+        n_msg = cfg.num_message_layers
+        for k in range(n_msg):
+            res = cfg.vector_residual and 0 < k < n_msg - 1
+            ns, nv = gcp_any(P, pre + f"interaction.message_fusion.{k}.", ms, mv, row, frames, False, nl, True, cfg, vector_residual=res)
+            ms, mv = (ms + ns, mv + nv) if (cfg.use_residual_message_gcp and k > 0) else (ns, nv)
+        if cfg.use_scalar_message_attention:
+            ms = ms * torch.sigmoid(F.linear(ms, P[pre + "interaction.scalar_message_attention.0.weight"], P[pre + "interaction.scalar_message_attention.0.bias"]))
+        flat = torch.cat((ms, mv.reshape(mv.shape[0], -1)), dim=-1)
+        agg = torch.zeros(N, flat.shape[1], dtype=h.dtype).index_add_(0, row, flat)
+        V = chi.shape[1]
+        hs, hv = torch.cat((agg[:, : -3 * V], h), dim=-1), torch.cat((agg[:, -3 * V:].reshape(-1, V, 3), chi), dim=1)
+        # feed-forward GCPs (:789-823): first (no residual; Linear-SiLU-Linear if it is the only one), middle (module_cfg flags), last (no residual, ff out)
+        n_ff = cfg.num_feedforward_layers
+        for k in range(n_ff):
+            first, last = k == 0, k == n_ff - 1 and n_ff > 1
+            acts = (None, None) if (first and n_ff == 1) or last else nl
+            hs, hv = gcp_any(P, pre + f"feedforward_network.{k}.", hs, hv, row, frames, True, acts, True, cfg,
+                             feedforward_out=(first and n_ff == 1) or last, vector_residual=cfg.vector_residual and not first and not last)
+        h, chi = h + hs, chi + hv
+        if not cfg.pre_norm:
+            h, chi = gcp_layernorm(P, pre + "gcp_norm.0.", h, chi, cfg.use_gcp_norm)
+        h, chi = h * maskf[:, None], chi * maskf[:, None, None]
+        _, pv = gcp_any(P, pre + "node_position_update_gcp.", h, chi, row, frames, True, nl, True, cfg)
+        upd = pv.sum(1) if cfg.update_positions_with_vector_sum else pv[:, 0, :]
+        x = (x + upd * cfg.node_positions_weight) * maskf[:, None]
+    hout = gcp_any(P, "scalar_node_projection_gcp.", h, chi, row, frames, True, (None, None), False, cfg)
+    vel = (x - x0) * maskf[:, None]
+    if cfg.num_context:
+        hout = hout[:, : -cfg.num_context]
+    if cfg.condition_on_time:
+        hout = hout[:, :-1]
+    if bool(vel.isnan().any()):
+        vel = torch.zeros_like(vel)
+    return torch.cat((centralize(vel, batch_index, B, mask), hout), dim=-1)
 
 
 def infer_num_layers(P: Params) -> int:

@@ -16,7 +16,7 @@ d = synth.DATASET_DIMS[case]
 n = 44 if case == "geom" else 19
 net = pkg.GCPNetDynamics(**pkg.default_cfgs("geom" if case == "geom" else "qm9"))
 net.load_state_dict(synth.make_weights(synth.dynamics_shapes(d["S"], d["V"], d["Se"], d["Ve"], d["L"], synth.dims_h_in(d)), seed=51, scale_2d=0.5))
-net = net.cuda()
+net = net.cuda().eval()
 dev = torch.device("cuda")
 xh, t, bi, nn_, _ = synth.make_inputs([n] * B, synth.dims_feat(d), seed=77, t_value=0.41)
 xh, t = xh.to(dev), t.to(dev)

@@ -47,7 +47,7 @@ def run_case(case, num_nodes=(5, 19, 3, 11)):
     shapes = synth.dynamics_shapes(d["S"], d["V"], d["Se"], d["Ve"], d["L"], synth.dims_h_in(d))
     W = synth.make_weights(shapes, seed=17)
     net.load_state_dict(W)
-    net = net.cuda()
+    net = net.cuda().eval()
     xh, t, bi, nn_, ctx = synth.make_inputs(num_nodes, synth.dims_feat(d), seed=9, n_ctx=d["n_ctx"])
     ocfg = O.OracleConfig(num_atom_types=d["num_atom_types"], include_charges=d["include_charges"], num_context=d["n_ctx"],
                           num_layers=d["L"], norm_values=d["norm_values"])

@@ -8,7 +8,7 @@ net = pkg.GCPNetDynamics(**cfgs)
 with torch.no_grad():
     for p in net.parameters():
         if p.dim() == 2: p.mul_(0.25)
-net = net.cuda()
+net = net.cuda().eval()
 ddpm = pkg.EquivariantVariationalDiffusion(net, cfgs["diffusion_cfg"], cfgs["dataloader_cfg"], pkg.dataset_info("qm9"))
 dev = torch.device("cuda")
 dyn, lib, h = ddpm._native(dev)

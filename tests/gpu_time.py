@@ -11,7 +11,7 @@ d = synth.DATASET_DIMS[case]
 n = 44 if case == "geom" else 19
 net = pkg.GCPNetDynamics(**pkg.default_cfgs("geom" if case == "geom" else "qm9"))
 net.load_state_dict(synth.make_weights(synth.dynamics_shapes(d["S"], d["V"], d["Se"], d["Ve"], d["L"], synth.dims_h_in(d)), seed=1, scale_2d=0.5))
-net = net.cuda()
+net = net.cuda().eval()
 dev = torch.device("cuda")
 print("cpu_count", os.cpu_count(), torch.cuda.get_device_name(0), flush=True)
 for B in sizes:

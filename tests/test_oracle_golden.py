@@ -329,3 +329,47 @@ def test_nll_terms_match_reference_golden(golden_dir, case):
         want = O.nll_from_terms(ref_terms, cfg.num_timesteps)
         assert (nll - want).abs().max().item() <= 10 * tol * max(1.0, want.abs().max().item())
     assert torch.isfinite(want).all() and want.abs().max().item() > 10.0          # the fixture is not degenerate
+
+
+def _variant_oracle_cfg(name):
+    """OracleConfig of synth.VARIANTS[name] at the reduced width of the variant fixtures."""
+    import dataclasses
+    kw = dict(num_layers=synth.SHRINK["num_encoder_layers"])
+    v = synth.VARIANTS[name]
+    fields = {f.name for f in dataclasses.fields(O.OracleConfig)}
+    for grp in ("module_cfg", "layer_cfg", "mp_cfg"):
+        for k, val in v.get(grp, {}).items():
+            if k in fields:
+                kw[k] = tuple(val) if k == "nonlinearities" else val
+    if "num_encoder_layers" in v.get("model_cfg", {}):
+        kw["num_layers"] = v["model_cfg"]["num_encoder_layers"]
+    return O.OracleConfig(**kw)
+
+
+@pytest.mark.parametrize("name", list(synth.VARIANTS))
+def test_general_forward_matches_reference_variant_golden(golden_dir, name):
+    """The oracle's general forward (GCP v1, frame / sigma gates, residuals, ablated frame updates, GCPLayerNorm, other depths / widths /
+    nonlinearities, vector-sum position updates) against the REFERENCE's own outputs, fp32 and fp64, all-True and partial masks."""
+    g = np.load(os.path.join(golden_dir, f"dyn_variant_{name}.npz"))
+    shapes = {k: tuple(int(x) for x in s.split(",")) if s else () for k, s in zip(g["keys"].tolist(), g["shapes"].tolist())}
+    W = synth.make_weights(shapes, seed=int(g["weight_seed"]), scale_2d=float(g["weight_scale"]))
+    cfg = _variant_oracle_cfg(name)
+    nn_ = torch.tensor(g["num_nodes"])
+    bi = O.num_nodes_to_batch_index(nn_)
+    xh, t = torch.tensor(g["xh"]), torch.tensor(g["t"])
+    for tag, mask in (("full", None), ("part", torch.tensor(g["mask_part"]))):
+        out = O.dynamics_forward_general(W, cfg, xh, t, bi, mask)
+        assert (out.double() - torch.tensor(g[f"out32_{tag}"]).double()).abs().max().item() <= 2e-6, (name, tag)
+        W64 = {k: v.double() for k, v in W.items()}
+        out64 = O.dynamics_forward_general(W64, cfg, xh.double(), t.double(), bi, mask)
+        assert (out64 - torch.tensor(g[f"out64_{tag}"])).abs().max().item() <= 1e-12, (name, tag)
+
+
+def test_general_forward_equals_production_forward(golden_dir):
+    g = load(golden_dir, "dyn_small_qm9")
+    P = weights_of(g)
+    cfg = cfg_for("qm9", O.infer_num_layers(P))
+    bi = O.num_nodes_to_batch_index(g["num_nodes"])
+    a = O.dynamics_forward(P, cfg, g["xh"], g["t"], bi)
+    b = O.dynamics_forward_general(P, cfg, g["xh"], g["t"], bi)
+    assert torch.equal(a, b) or (a - b).abs().max().item() <= 1e-7
