@@ -107,6 +107,7 @@ __global__ __launch_bounds__(256) void k_edge_embed_x3(EdgeEmbedX3Args ax) {
     }
     x3_settle(bh[0], bl[0]);
     x3_settle(bh[1], bl[1]);
+    __builtin_amdgcn_sched_barrier(0);          // both k-blocks' splits complete before the first MFMA: none is scheduled into the MFMA burst
     const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     f32x16 p[MT];
 #pragma unroll
@@ -128,22 +129,29 @@ __global__ __launch_bounds__(256) void k_edge_embed_x3(EdgeEmbedX3Args ax) {
         }
     }
     // vector gate: Wg . e' (channels of block b = (m, jb): registers 8 jb .. 8 jb + 7 of M-tile m)
+    // every split of every block first, fenced off the matrix pipe (sched_barrier): no v_fma_mix is scheduled between two MFMAs of this kernel
+    // (tools/isa_census.py --lint rule 2; the stale-B-operand fault of this kernel appeared exactly when the compiler interleaved them)
     f32x16 gm = zero, gl = zero;
+    h8 xh[GB], xl[GB];
+    __builtin_amdgcn_sched_barrier(0);          // ... nor between the MFMAs of the scalar_out contraction above
 #pragma unroll
     for (int b = 0; b < GB; ++b) {
         const int m = b >> 1, jb = b & 1;
-        h8 xh, xl;
 #pragma unroll
         for (int s = 0; s < 8; s += 2) {
             h2 hi, lo;
             split16x2(p[m][8 * jb + s], p[m][8 * jb + s + 1], hi, lo);
-            xh[s] = hi[0]; xh[s + 1] = hi[1];
-            xl[s] = lo[0]; xl[s + 1] = lo[1];
+            xh[b][s] = hi[0]; xh[b][s + 1] = hi[1];
+            xl[b][s] = lo[0]; xl[b][s + 1] = lo[1];
         }
-        x3_settle(xh, xl);
-        gm = MFMA16(gh[b], xh, gm);
-        gl = MFMA16(gh[b], xl, gl);
-        gl = MFMA16(gl_[b], xh, gl);
+        x3_settle(xh[b], xl[b]);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int b = 0; b < GB; ++b) {
+        gm = MFMA16(gh[b], xh[b], gm);
+        gl = MFMA16(gh[b], xl[b], gl);
+        gl = MFMA16(gl_[b], xh[b], gl);
     }
     if (valid) {
 #pragma unroll

@@ -536,6 +536,18 @@ def test_no_mfma_directly_behind_a_partial_write_of_its_source():
     assert len(isa_census.lint_partial_writes(fake)) == 1
     assert isa_census.lint_partial_writes(fake.replace("\tv_mfma", "\ts_nop 0\n\tv_mfma")) == []
     assert isa_census.lint_partial_writes(fake.replace("v[16:19]", "v[20:23]")) == []
+    # the LAST writer counts, wherever it is: an unrelated instruction in between is one wait state, a full rewrite of the register clears it
+    assert isa_census.lint_partial_writes(fake.replace("\tv_mfma", "\tv_add_f32_e32 v40, v41, v42\n\tv_mfma")) == []
+    assert len(isa_census.lint_partial_writes(fake.replace("\tv_mfma", "\tv_add_f32_e32 v40, v41, v42\n\tv_mfma"), min_states=2)) == 1
+    assert isa_census.lint_partial_writes(fake.replace("\tv_mfma", "\ts_nop 1\n\tv_mfma"), min_states=2) == []
+    assert isa_census.lint_partial_writes(fake.replace("\tv_mfma", "\tv_mov_b32_e32 v17, v3\n\tv_mfma")) == []
+    # rule 2: no split between two MFMAs of k_edge_embed_x3 (an s_nop fence in between makes it a new burst)
+    emb = ("_Z15k_edge_embed_x3ILi64ELi16EEv15EdgeEmbedX3Args:                                  ; @_Z15k_edge_embed_x3ILi64ELi16EEv15EdgeEmbedX3Args\n"
+           "\tv_mfma_f32_32x32x16_f16 a[0:15], v[0:3], v[4:7], 0\n\tv_fma_mixlo_f16 v40, v45, s6, 0 op_sel_hi:[0,0,0]\n"
+           "\tv_mfma_f32_32x32x16_f16 a[0:15], v[0:3], v[8:11], a[0:15]\n\ts_endpgm\n\t.end_amdhsa_kernel\n")
+    assert len(isa_census.lint_partial_writes(emb)) == 1
+    assert isa_census.lint_partial_writes(emb.replace("\tv_fma_mixlo", "\ts_nop 1\n\tv_fma_mixlo")) == []
+    assert isa_census.lint_partial_writes(emb.replace("k_edge_embed_x3", "k_other_kernelx")) == []
     if shutil.which(os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")) is None:
         pytest.skip("hipcc not available")
     assert isa_census.lint_partial_writes() == []

@@ -46,13 +46,13 @@ def _vregs(tok):
     return {int(m.group(1))} if m else set()
 
 
-def lint_partial_writes(text=None):
-    """Measured on gfx950 (tools/mfma_partial_write_hazard.hip): an MFMA issued with NO wait state behind a 16-bit partial write
-    (v_fma_mixlo/hi_f16) of one of its source registers reads the old register; one wait state is enough.  The compiler inserts that
-    wait state between an inline-asm definition and its consumer -- this check fails if a build ever comes out without it.
-    Returns [(kernel, writer, mfma)] violations."""
-    text = text if text is not None else compile_to_asm()
-    bad = []
+def _wait_states(ins):
+    """Issue slots an instruction keeps the wave busy for hazard purposes: s_nop N = N + 1 states, anything else 1."""
+    m = re.match(r"s_nop\s+(\d+)", ins)
+    return int(m.group(1)) + 1 if m else 1
+
+
+def _kernels(text):
     for m in re.finditer(r"^(_Z\w+):\s*; @\1\n(.*?)\.end_amdhsa_kernel", text, re.S | re.M):
         ins = []
         for line in m.group(2).split("\n"):
@@ -60,17 +60,55 @@ def lint_partial_writes(text=None):
             if not t or t.startswith((";", ".")) or t.split()[0].endswith(":"):
                 continue
             ins.append(t)
-        for i in range(1, len(ins)):
-            if not ins[i].startswith("v_mfma"):
-                continue
-            prev = ins[i - 1]
-            if not prev.startswith("v_fma_mix"):
-                continue
-            dst = _vregs(prev.split(None, 1)[1].split(",")[0].strip())
-            ops = [o.strip() for o in ins[i].split(None, 1)[1].split(",")]
-            srcs = set().union(*[_vregs(o) for o in ops[1:]])
-            if dst & srcs:
-                bad.append((m.group(1), prev, ins[i]))
+        yield m.group(1), ins
+
+
+def lint_partial_writes(text=None, min_states=1, embed_rule=True):
+    """Measured on gfx950 (tools/mfma_partial_write_hazard.hip): an MFMA issued with NO wait state behind a 16-bit partial write
+    (v_fma_mixlo/hi_f16) of one of its source registers reads the old register; one wait state is enough.  The compiler inserts that
+    wait state between an inline-asm definition and its consumer, and x3_settle (gcdm_edge_x3.hip.h) adds two more wherever a split feeds
+    an MFMA directly.  Checked per kernel, for every MFMA and every source register (A, B, C operands), in straight-line order:
+      (1) if the register's LAST writer is a v_fma_mix*, at least `min_states` wait states (instructions, s_nop N = N + 1) lie between
+          that write and the MFMA;
+      (2) (`embed_rule`) in k_edge_embed_x3 -- the kernel whose stale-B-operand fault was never pinned to one instruction pair --
+          no v_fma_mix* is scheduled between two MFMAs: its splits must stay fenced off the matrix pipe's bursts (the x3_settle barrier).
+    Returns [(kernel, writer, mfma)] violations."""
+    text = text if text is not None else compile_to_asm()
+    bad = []
+    for name, ins in _kernels(text):
+        last = {}                      # vgpr -> (index of last writer, is a partial write)
+        states = [0]                   # prefix sums of wait states
+        for t in ins:
+            states.append(states[-1] + _wait_states(t))
+        first_mfma = last_mfma = None
+        for i, t in enumerate(ins):
+            op = t.split()[0]
+            if op.startswith("v_mfma"):
+                ops = [o.strip() for o in t.split(None, 1)[1].split(",")]
+                for r in set().union(*[_vregs(o) for o in ops[1:4]]):
+                    w = last.get(r)
+                    if w is not None and w[1] and states[i] - states[w[0] + 1] < min_states:
+                        bad.append((name, ins[w[0]], t))
+                        break
+                first_mfma = i if first_mfma is None else first_mfma
+                last_mfma = i
+            if op.startswith(("v_", "ds_read", "buffer_load", "global_load", "flat_load")) and " " in t:
+                dst = t.split(None, 1)[1].split(",")[0].strip()
+                for r in _vregs(dst):
+                    last[r] = (i, op.startswith("v_fma_mix"))
+        if embed_rule and "k_edge_embed_x3" in name and first_mfma is not None:
+            seen_mfma = False
+            for i in range(first_mfma, last_mfma + 1):
+                op = ins[i].split()[0]
+                if op.startswith("v_mfma"):
+                    seen_mfma = True
+                elif op.startswith("v_fma_mix") and seen_mfma:
+                    nxt = next((j for j in range(i + 1, last_mfma + 1) if ins[j].startswith("v_mfma")), None)
+                    prv = next((j for j in range(i - 1, first_mfma - 1, -1) if ins[j].startswith("v_mfma")), None)
+                    # inside a burst = MFMAs on both sides with no s_nop fence in between
+                    if nxt is not None and prv is not None and not any(ins[j].startswith("s_nop") for j in range(prv, nxt)):
+                        bad.append((name, ins[i], ins[nxt]))
+                        break
     return bad
 
 
@@ -79,7 +117,7 @@ def main():
         bad = lint_partial_writes()
         for k, w, f in bad:
             print(f"{k}:\n    {w}\n    {f}")
-        print(f"{len(bad)} MFMA(s) issued directly behind a partial write of one of their sources")
+        print(f"{len(bad)} violation(s): MFMA issued too close behind a partial write of one of its sources, or a split inside an MFMA burst of k_edge_embed_x3")
         sys.exit(1 if bad else 0)
     want = sys.argv[1:] or ["k_edge_msg_x3", "k_node_x3"]
     text = compile_to_asm()
