@@ -272,6 +272,7 @@ def main():
                                                                    "used when profiling so that the kernel statistics show the default mode only")
     ap.add_argument("--lanes", type=int, default=2, help="sample the ONE flat batch as this many slices of molecules on separate handles / HIP "
                                                          "streams (same semantics, same noise; fills the round-quantisation tails)")
+    ap.add_argument("--no-extras", action="store_true", help="skip plug_point_1 / nll_evaluation / training_step (profile runs: only the sampling kernels)")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the short runs of BASELINE.json configs[2] / configs[3] (extra fields of the JSON line)")
     ap.add_argument("--streams", type=int, default=1, help="independent batches in flight per GPU, each on its own handle and HIP stream "
                                                            "(the evaluation driver's concurrent_batches; for small batches)")
@@ -457,7 +458,7 @@ def main():
     # plug point 1: what the reference's UNCHANGED mol_gen_sample loop costs after the one-line registry swap -- per step one
     # reference-signature sample_p_zs_given_zt (torch algebra on the device + GCPNetDynamics.forward, deferred range guard: no host sync)
     plug1_ms = nll_ms = train_ms = None
-    if world == 1 and args.streams == 1:
+    if world == 1 and args.streams == 1 and not args.no_extras:
         ddpm.to(dev)                                   # the reference-signature method does its schedule algebra with torch ops on the device
         bidx = torch.repeat_interleave(torch.arange(B, device=dev), num_nodes.to(dev).long())
         nmask = torch.ones(N, dtype=torch.bool, device=dev)

@@ -8,11 +8,14 @@ OUT=$ROOT/gpurun_out
 export TMPDIR=/tmp
 cd /tmp
 # --lanes 1: whole-batch launches, i.e. what bench.py's roofline object measures (the timed loop of the default run uses 2 slices)
-B="python $ROOT/bench.py --workload $WL --lanes 1 --steps 6 --warmup 2 --no-cpu-baseline --no-fp32-timing --no-other-configs"
+# GCDM_MFMA=f32 in the environment profiles the exact-fp32 MFMA kernel family instead of the default split-precision one
+B="python $ROOT/bench.py --workload $WL --lanes 1 --steps 6 --warmup 2 --no-cpu-baseline --no-fp32-timing --no-other-configs --no-extras"
 run() { local name=$1; shift; (timeout 280 rocprofv3 --kernel-trace "$@" --output-format csv -d $OUT/${TAG}_$name -- $B > $OUT/${TAG}_$name.log 2>&1; echo "$name exit=$?"); }
 run stats --stats
 run pmc1 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F16 SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS SQ_INSTS_VALU
+if [ "${GCDM_PROFILE_SHORT:-0}" != "1" ]; then
 run pmc2 --pmc FETCH_SIZE
 run pmc3 --pmc WRITE_SIZE
 run pmc4 --pmc TCC_HIT_sum TCC_MISS_sum TCP_TCC_READ_REQ_sum
+fi
 du -sh $OUT/${TAG}_*

@@ -8,16 +8,26 @@ ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out
 mkdir -p $OUT
 cd $ROOT
+# gate: the configuration that exposed the stale-operand fault of k_edge_embed_x3, repeated, before anything is measured
+timeout 200 python -m pytest tests/test_gpu_parity.py -x -q -k "edge_embedding_of_both_modes or ragged_geom_is_bit_reproducible" > $OUT/${TAG}_gate.log 2>&1 || { tail -5 $OUT/${TAG}_gate.log; echo "GATE FAILED"; exit 1; }
 tools/gpu_profile.sh ${TAG} qm9 > $OUT/${TAG}_profile_qm9.log 2>&1
 tools/gpu_profile.sh ${TAG}g geom > $OUT/${TAG}_profile_geom.log 2>&1
+# one pass of the exact-fp32 MFMA kernel family (kernel stats + the SQ counters)
+GCDM_MFMA=f32 GCDM_PROFILE_SHORT=1 tools/gpu_profile.sh ${TAG}f32 qm9 > $OUT/${TAG}_profile_qm9_f32.log 2>&1
+python profiles/pmc_summarize.py $OUT/${TAG}f32_pmc1 > $OUT/${TAG}_pmc_summary_qm9_f32.json
 python profiles/pmc_summarize.py $OUT/${TAG}_pmc1 $OUT/${TAG}_pmc2 $OUT/${TAG}_pmc3 $OUT/${TAG}_pmc4 > $OUT/${TAG}_pmc_summary_qm9_x3.json
 python profiles/pmc_summarize.py $OUT/${TAG}g_pmc1 $OUT/${TAG}g_pmc2 $OUT/${TAG}g_pmc3 $OUT/${TAG}g_pmc4 > $OUT/${TAG}_pmc_summary_geom_x3.json
 cp $OUT/${TAG}_pmc_summary_qm9_x3.json $OUT/${TAG}_pmc_summary_geom_x3.json profiles/
-for d in ${TAG} ${TAG}g; do f=$(ls -t $OUT/${d}_stats/*/*kernel_stats.csv 2>/dev/null | head -1); [ -n "$f" ] && cp "$f" $OUT/${d}_kernel_stats.csv; done
+for d in ${TAG} ${TAG}g ${TAG}f32; do f=$(ls -t $OUT/${d}_stats/*/*kernel_stats.csv 2>/dev/null | head -1); [ -n "$f" ] && cp "$f" $OUT/${d}_kernel_stats.csv; done
 # raw counter dumps are large: keep the summaries and the per-kernel stats only
-rm -rf $OUT/${TAG}_pmc[1-4] $OUT/${TAG}g_pmc[1-4] $OUT/${TAG}_stats $OUT/${TAG}g_stats
+rm -rf $OUT/${TAG}_pmc[1-4] $OUT/${TAG}g_pmc[1-4] $OUT/${TAG}f32_pmc1 $OUT/${TAG}_stats $OUT/${TAG}g_stats $OUT/${TAG}f32_stats
 timeout 280 python bench.py --steps 100 --warmup 5 > $OUT/${TAG}_bench_qm9.json 2> $OUT/${TAG}_bench_qm9.err
 timeout 200 python bench.py --workload geom --steps 100 --warmup 5 --no-cpu-baseline > $OUT/${TAG}_bench_geom.json 2> $OUT/${TAG}_bench_geom.err
 timeout 200 python bench.py --lanes 1 --steps 100 --warmup 5 --no-cpu-baseline --no-other-configs > $OUT/${TAG}_bench_qm9_lanes1.json 2> $OUT/${TAG}_bench_lanes1.err
-timeout 100 python tests/gpu_time.py qm9 1024 > $OUT/${TAG}_phase_stamps_qm9.txt 2>&1
+# in-kernel phase stamps need the -DGCDM_STAMPS build (tools/build_variants.sh stamps:-DGCDM_STAMPS -> build/ab/libgcdm_stamps.so)
+if [ -f build/ab/libgcdm_stamps.so ]; then
+    cp bio-diffusion_amd/libgcdm_hip.so /tmp/libgcdm_keep.so; cp build/ab/libgcdm_stamps.so bio-diffusion_amd/libgcdm_hip.so
+    timeout 100 python tests/gpu_time.py qm9 1024 > $OUT/${TAG}_phase_stamps_qm9.txt 2>&1
+    cp /tmp/libgcdm_keep.so bio-diffusion_amd/libgcdm_hip.so
+fi
 tail -c 600 $OUT/${TAG}_bench_qm9.json; echo; tail -3 $OUT/${TAG}_profile_qm9.log
