@@ -31,7 +31,7 @@ struct LayerDev {
     GcpW ff, pos;
     const v4f* wpq; const float* bpq; const float* wddI; const float* wddJ;
     // split-precision (f16 x3) images of the edge-kernel GEMM weights
-    const h8 *w0H, *w0L, *wg0H, *wg0L, *wH[3], *wL[3], *wgH[3], *wgL[3];
+    const h8 *w0H, *w0L, *wg0H, *wg0L, *wH[3], *wL[3], *wgH[3], *wgL[3], *wbeH, *wbeL;
     const h8 *vpH[3], *vpL[3], *vf1[3], *vf2[3], *vf0H, *vf0L;   // vector path on the matrix pipe (gcdm_edge_x3.hip.h)
     const h8 *vdH, *vdL;
     const float *bpqx, *wax;       // scaled units of the split-precision edge kernel: c * bias of the msg0 node halves, attention weights / c
@@ -425,7 +425,7 @@ struct LayerOff {
     int G0;
     float ba;
     GcpOff mk[3], ff, pos;
-    size_t w0H, w0L, wg0H, wg0L, wH[3], wL[3], wgH[3], wgL[3];
+    size_t w0H, w0L, wg0H, wg0L, wH[3], wL[3], wgH[3], wgL[3], wbeH, wbeL;
     size_t vpH[3], vpL[3], vf1[3], vf2[3], vf0H, vf0L, vdH, vdL;
     size_t wpqH, wpqL;
     int KB0, KB;
@@ -640,6 +640,14 @@ int gcdm_finalize_weights(gcdm_handle* h) {
                 for (int c = 0; c < V; ++c) dJ[(size_t)r * V + c] = src.at(rr, V + Ve + c);
             }
             o.wddI = pool.add(dI); o.wddJ = pool.add(dJ); o.wddE = pool.add(dE);
+            {   // the edge block as ONE split-precision A operand (rows = hidden / frame vectors, padded 32 x 16): beta on the matrix pipe
+                Dense We(32, 16);
+                for (int r = 0; r < H0 + 3; ++r)
+                    for (int c = 0; c < Ve; ++c) We.at(r, c) = dE[(size_t)r * Ve + c];
+                std::vector<float> a, b;
+                pack_x3(We, a, b);
+                o.wbeH = pool.add(a); o.wbeL = pool.add(b);
+            }
             {   // [wddI; wddJ] (2 x (H0 + 3) rows x 32) for the node kernel's matrix-pipe evaluation of VDI / VDJ
                 std::vector<float> dIJ(dI);
                 dIJ.insert(dIJ.end(), dJ.begin(), dJ.end());
@@ -757,6 +765,7 @@ int gcdm_finalize_weights(gcdm_handle* h) {
         d.ffx = resolve_x3(o.ff, base); d.posx = resolve_x3(o.pos, base);
         d.wpqH = (const h8*)(base + o.wpqH); d.wpqL = (const h8*)(base + o.wpqL);
         d.wg0H = (const h8*)(base + o.wg0H); d.wg0L = (const h8*)(base + o.wg0L);
+        d.wbeH = (const h8*)(base + o.wbeH); d.wbeL = (const h8*)(base + o.wbeL);
         d.vf0H = (const h8*)(base + o.vf0H); d.vf0L = (const h8*)(base + o.vf0L);
         d.vdH = (const h8*)(base + o.vdH); d.vdL = (const h8*)(base + o.vdL);
         d.bpqx = base + o.bpqx; d.wax = base + o.wax;
@@ -997,6 +1006,7 @@ int gcdm_forward_sc(gcdm_handle* h, const float* xh, const float* xh_sc, const f
             xa.x3c = h->x3c();
             xa.base = ma;
             xa.w0H = d.w0H; xa.w0L = d.w0L; xa.KB0 = d.KB0; xa.wg0H = d.wg0H; xa.wg0L = d.wg0L; xa.KB = d.KB;
+            xa.wbeH = d.wbeH; xa.wbeL = d.wbeL;
             for (int k = 0; k < 3; ++k) { xa.wH[k] = d.wH[k]; xa.wL[k] = d.wL[k]; xa.wgH[k] = d.wgH[k]; xa.wgL[k] = d.wgL[k]; }
             for (int k = 0; k < 3; ++k) { xa.vpH[k] = d.vpH[k]; xa.vpL[k] = d.vpL[k]; xa.vf1[k] = d.vf1[k]; xa.vf2[k] = d.vf2[k]; }
             xa.vf0H = d.vf0H; xa.vf0L = d.vf0L;

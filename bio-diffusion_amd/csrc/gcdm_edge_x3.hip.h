@@ -809,6 +809,7 @@ struct EdgeMsgX3Args {
     const h8* vpH[3]; const h8* vpL[3];             // msg1..3 [W_down; W_frames] (11 x 32 -> 16 x 32), K permuted to the VV4 lane ownership
     const h8* vf1[3]; const h8* vf2[3];             // msg1..3 vector_up [32 x 8] as two M-tiles: A1 = [W_hi | 0], A2 = [W_lo' | W_hi]
     const h8* vf0H; const h8* vf0L;                 // msg0 vector_up [32 x H0] as two M-tiles, K = hidden channel
+    const h8* wbeH; const h8* wbeL;                 // msg0: the edge block of [W_down; W_frames] ((H0 + 3) x Ve -> 32 x 16) as ONE A operand [64 lanes] x 8 f16
     const float* wax;                               // scalar_message_attention weights / c
     const void* wpool; uint32_t wpool_bytes;        // the whole weight pool (every packed array above lies inside): base of the buffer-load stream
     const void* wspool; uint32_t wspool_bytes;      // the workspace pool (EP4, AL, U, FR, PQ4, VDI, VDJ lie inside)
@@ -872,11 +873,17 @@ __global__ __launch_bounds__(ET * 8) __attribute__((amdgpu_waves_per_eu(2, 2))) 
     const BufView wv = make_view(ax.wpool, ax.wpool_bytes);
     constexpr int EPN = (SE / 4) / PARTS;                // e' float4 groups per thread (QM9 2, GEOM: parts 0..3 one each)
     const uint32_t ve4 = (uint32_t)eid * 4u, ve16 = (uint32_t)eid * 16u, rowE = (uint32_t)E * 4u, rowN = (uint32_t)N * 4u;
+    constexpr int H0_ = (2 * GCDM_V + VE) / 4;
+    // the frame rows of an edge are needed by the thread that stages them in LDS (part 0) and by the threads whose rows of the pre-phase are the
+    // three frame vectors (H0 <= part + PARTS i < H0 + 3): 4 of the 8 threads per edge; the others skip the nine loads
+    bool need_fr = part == 0;
+#pragma unroll
+    for (int i = 0; i < (H0_ + 3 + PARTS - 1) / PARTS; ++i) need_fr |= (part + PARTS * i >= H0_) && (part + PARTS * i < H0_ + 3);
     float fr[9];
     {
         const uint32_t o = ws.off(a.FR);
 #pragma unroll
-        for (int r = 0; r < 9; ++r) fr[r] = ws.ld1(ve4, o + r * rowE);
+        for (int r = 0; r < 9; ++r) fr[r] = need_fr ? ws.ld1(ve4, o + r * rowE) : 0.f;
     }
     v4f epv[EPN > 0 ? EPN : 1];
     {
@@ -885,8 +892,15 @@ __global__ __launch_bounds__(ET * 8) __attribute__((amdgpu_waves_per_eu(2, 2))) 
         for (int i = 0; i < (EPN > 0 ? EPN : 1); ++i)
             epv[i] = ws.ld4(ve16 + (uint32_t)min(part + PARTS * i, SE / 4 - 1) * (rowE * 4u), o);          // the group index depends on the lane's part
     }
+    // beta products of the pre-phase: on the matrix pipe for the 16-channel edge width (QM9: -1.8 % tile cycles), the round-2 VALU form
+    // (every thread loads the edge's alpha and its rows of W_e) for the 8-channel one, where half of the MFMA's K would be padding (GEOM: +0.5 %)
+#ifdef GCDM_X3_BETA_VALU
+    constexpr bool BETA_MFMA = false;
+#else
+    constexpr bool BETA_MFMA = VE == 16;
+#endif
     float al[VE];
-    {
+    if constexpr (!BETA_MFMA) {
         const uint32_t o = ws.off(a.AL);
 #pragma unroll
         for (int c = 0; c < VE; ++c) al[c] = ws.ld1(ve4, o + c * rowE);
@@ -934,6 +948,46 @@ __global__ __launch_bounds__(ET * 8) __attribute__((amdgpu_waves_per_eu(2, 2))) 
     // ---- P1: msg0 pre-phase ---------------------------------------------------------------------------------------------
 #ifndef GCDM_ABL_NOP1
     {
+        float* BETA = PG;                                   // [ET][33]: BETA[e * 33 + h]
+        float* BETA2 = PG + ET * 33;                        // self-conditioning: the second rank (BL)
+        if constexpr (BETA_MFMA) {
+        // beta[h][e] = sum_c W_e[h][c] alpha_c[e] -- the edge block of vector_down / vector_down_frames applied to the rank-1 embedded edge
+        // vectors (gcpnet.py:442-459) -- is a [23 x 16] . [16 x ET] contraction: ONE wave per 32 edges evaluates it on the matrix pipe (3 MFMAs,
+        // 8 alpha loads per lane) and hands it over in LDS, instead of 16 alpha loads + 48 weight loads + 48 FMAs in each of the 8 threads
+        // of an edge.  BETA aliases the gate-partial buffer PG, which is first written after the msg0 GEMM.
+        if (wave < ET / 32) {
+            const int n_ = lane & 31, kh_ = lane >> 5;
+            const uint32_t eg4 = (uint32_t)min(e0 + 32 * wave + n_, E - 1) * 4u;
+            const h8 aH = wp.ld(wp.off(ax.wbeH)), aL = wp.ld(wp.off(ax.wbeL));
+            const f32x16 zero_ = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            auto contract = [&](const float* SRC, float* DST) {
+                const uint32_t o = ws.off(SRC);
+                float av[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) av[j] = (8 * kh_ + j < VE || VE == 16) ? ws.ld1(eg4, o + (uint32_t)min(8 * kh_ + j, VE - 1) * rowE) : 0.f;
+                if (VE < 16 && kh_ == 1) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) av[j] = 0.f;
+                }
+                h8 bh, bl;
+#pragma unroll
+                for (int j = 0; j < 8; j += 2) {
+                    h2 hi, lo;
+                    split16x2(av[j], av[j + 1], hi, lo);
+                    bh[j] = hi[0]; bh[j + 1] = hi[1];
+                    bl[j] = lo[0]; bl[j + 1] = lo[1];
+                }
+                x3_settle(bh, bl);
+                f32x16 am_ = MFMA16(aH, bh, zero_);
+                f32x16 al_ = MFMA16(aH, bl, zero_);
+                al_ = MFMA16(aL, bh, al_);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) DST[(32 * wave + n_) * 33 + (r & 3) + 8 * (r >> 2) + 4 * kh_] = am_[r] + al_[r] * X3_INV_SCALE;
+            };
+            contract(a.AL, BETA);
+            if (a.BL) contract(a.BL, BETA2);
+        }
+        }
         if (part == 0) {
 #pragma unroll
             for (int r = 0; r < 9; ++r) FR[r * ETP + e] = fr[r];
@@ -972,20 +1026,25 @@ __global__ __launch_bounds__(ET * 8) __attribute__((amdgpu_waves_per_eu(2, 2))) 
                 gj[i][x] = ws.ld1(vJ, oJ + x * rowN);
 #endif
             }
-            const uint32_t vW = (uint32_t)(hh * VE) * 4u;
-            float bsum = 0.f;
+            if constexpr (!BETA_MFMA) {
+                const uint32_t vW = (uint32_t)(hh * VE) * 4u;
+                float bsum = 0.f;
 #ifdef GCDM_ABL_NOBETA
-            bsum = al[0];
+                bsum = al[0];
 #else
 #pragma unroll
-            for (int c = 0; c < VE; ++c) bsum += wv.ld1(vW, oW + c * 4) * al[c];
+                for (int c = 0; c < VE; ++c) bsum += wv.ld1(vW, oW + c * 4) * al[c];
 #endif
-            beta[i] = bsum;
+                beta[i] = bsum;
+            }
             beta2[i] = 0.f;
         }
         float s0 = 0.f, s1 = 0.f, s2 = 0.f;
         if (a.BL) {                      // self-conditioning: rank-2 embedded edge vectors, xi'_c = AL_c u + BL_c u_sc (uniform branch)
             s0 = a.USC[eid]; s1 = a.USC[(size_t)E + eid]; s2 = a.USC[2 * (size_t)E + eid];
+        }
+        if constexpr (!BETA_MFMA) {
+        if (a.BL) {
             float bl[VE];
 #pragma unroll
             for (int c = 0; c < VE; ++c) bl[c] = a.BL[(size_t)c * E + eid];
@@ -997,6 +1056,15 @@ __global__ __launch_bounds__(ET * 8) __attribute__((amdgpu_waves_per_eu(2, 2))) 
                 for (int c = 0; c < VE; ++c) bsum += w[c] * bl[c];
                 beta2[i] = bsum;
             }
+        }
+        } else {
+        __syncthreads();                 // BETA complete (the gathers above are in flight across it)
+#pragma unroll
+        for (int i = 0; i < NH0; ++i) {
+            const int hh = min(part + PARTS * i, ROWS0 - 1);
+            beta[i] = BETA[e * 33 + hh];
+            if (a.BL) beta2[i] = BETA2[e * 33 + hh];
+        }
         }
 #pragma unroll
         for (int i = 0; i < NH0; ++i) {
