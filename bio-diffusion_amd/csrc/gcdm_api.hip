@@ -82,6 +82,8 @@ struct gcdm_handle {
     // evaluation batches +12 ... 25 %: less round quantisation), fp32 kernels -> 64.  Rows cut by tile boundaries are summed from per-tile
     // partials in tile order (AggSrc), so every choice is bit-reproducible for any molecule size.
     int tile() const { return edge_tile ? edge_tile : 64; }
+    int cus = 256;                   // compute units of the device (persistent edge-message workgroups: one per CU)
+    int persistent = 1;              // option "persistent" / env GCDM_PERSISTENT=0: one workgroup per tile (round 2 schedule; A/B runs)
     bool x3_weights_ok = true;       // every GEMM weight fits the split-precision images at some exponent split k <= X3_MAX_SHIFT; else mfma_mode 1 is refused
     int x3_shift = 0;                // k: packed weights carry 2^(11-k), activation images 2^(k-11) (X3Const, gcdm_edge_x3.hip.h)
     X3Const x3c() const { const float w = ldexpf(1.0f, 11 - x3_shift); return X3Const{1.0f / w, w, 1.0f / w, 6.0e4f * w}; }
@@ -485,7 +487,12 @@ int gcdm_create(const GcdmConfig* cfg, gcdm_handle** out) {
     h->H0 = (2 * GCDM_V + h->Ve) / 4;
     if (const char* et = getenv("GCDM_EDGE_TILE")) h->edge_tile = (atoi(et) == 32) ? 32 : 64;
     if (const char* mm = getenv("GCDM_MFMA")) h->mfma_x3 = (std::strcmp(mm, "f16x3") == 0) ? 1 : 0;
+    if (const char* pe = getenv("GCDM_PERSISTENT")) h->persistent = atoi(pe) ? 1 : 0;
     DeviceGuard guard(cfg->device);
+    {
+        int n = 0;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, cfg->device) == hipSuccess && n > 0) h->cus = n;
+    }
     HIP_OK(h, hipMalloc(&h->d_flags, 4 * sizeof(uint32_t)));            // [0] flag word, [1..2] statistics of gcdm_encode_samples
     HIP_OK(h, hipMemset(h->d_flags, 0, 4 * sizeof(uint32_t)));
     return 0;
@@ -779,8 +786,8 @@ int gcdm_finalize_weights(gcdm_handle* h) {
     if (!h->attr_set) {
         if (set_lds_attr(h, k_edge_msg<64, 16, 64>, EdgeGeo<64>::LDS_BYTES) || set_lds_attr(h, k_edge_msg<16, 8, 64>, EdgeGeo<64>::LDS_BYTES) ||
             set_lds_attr(h, k_edge_msg<64, 16, 32>, EdgeGeo<32>::LDS_BYTES) || set_lds_attr(h, k_edge_msg<16, 8, 32>, EdgeGeo<32>::LDS_BYTES) ||
-            set_lds_attr(h, k_edge_msg_x3<64, 16, 64>, EdgeGeo<64>::LDS_BYTES) || set_lds_attr(h, k_edge_msg_x3<16, 8, 64>, EdgeGeo<64>::LDS_BYTES) ||
-            set_lds_attr(h, k_edge_msg_x3<64, 16, 32>, EdgeGeo<32>::LDS_BYTES) || set_lds_attr(h, k_edge_msg_x3<16, 8, 32>, EdgeGeo<32>::LDS_BYTES) ||
+            set_lds_attr(h, k_edge_msg_x3<64, 16, 64>, EdgeGeo<64>::LDS_BYTES_X3) || set_lds_attr(h, k_edge_msg_x3<16, 8, 64>, EdgeGeo<64>::LDS_BYTES_X3) ||
+            set_lds_attr(h, k_edge_msg_x3<64, 16, 32>, EdgeGeo<32>::LDS_BYTES_X3) || set_lds_attr(h, k_edge_msg_x3<16, 8, 32>, EdgeGeo<32>::LDS_BYTES_X3) ||
             set_lds_attr(h, k_node_x3<true>, NK_LDS_BYTES) || set_lds_attr(h, k_node_x3<false>, NK_LDS_BYTES) ||
             set_lds_attr(h, k_node<true>, NK_LDS_BYTES) || set_lds_attr(h, k_node<false>, NK_LDS_BYTES) ||
             set_lds_attr(h, k_node_x3<true, 4>, NK_LDS_BYTES) || set_lds_attr(h, k_node<true, 4>, NK_LDS_BYTES))
@@ -1015,12 +1022,16 @@ int gcdm_forward_sc(gcdm_handle* h, const float* xh, const float* xh_sc, const f
             xa.wspool = h->ws; xa.wspool_bytes = (uint32_t)(h->ws_floats * sizeof(float));
             xa.flags_dev = h->d_flags;
             if (d.KB != 18 || d.KB0 != (h->Se == 64 ? 7 : 4)) return fail(h, "internal: k-block counts differ from the kernel's compile-time constants");
+            // persistent workgroups: as many as fit the chip at once (one per CU with 64-edge tiles, two with 32), a multiple of 8 so that every
+            // XCD gets the same number; fewer tiles than that -> one tile per workgroup, as before
+            int wgs = h->cus * (ET == 64 ? 1 : 2) / 8 * 8;
+            if (h->persistent == 0 || tiles <= wgs || wgs < 8) { wgs = tiles; xa.wg_stride = tiles; } else xa.wg_stride = wgs / 8;
             if (ET == 64) {
-                if (h->Se == 64) hipLaunchKernelGGL((k_edge_msg_x3<64, 16, 64>), dim3(tiles), dim3(512), EdgeGeo<64>::LDS_BYTES, st, xa);
-                else hipLaunchKernelGGL((k_edge_msg_x3<16, 8, 64>), dim3(tiles), dim3(512), EdgeGeo<64>::LDS_BYTES, st, xa);
+                if (h->Se == 64) hipLaunchKernelGGL((k_edge_msg_x3<64, 16, 64>), dim3(wgs), dim3(512), EdgeGeo<64>::LDS_BYTES_X3, st, xa);
+                else hipLaunchKernelGGL((k_edge_msg_x3<16, 8, 64>), dim3(wgs), dim3(512), EdgeGeo<64>::LDS_BYTES_X3, st, xa);
             } else {
-                if (h->Se == 64) hipLaunchKernelGGL((k_edge_msg_x3<64, 16, 32>), dim3(tiles), dim3(256), EdgeGeo<32>::LDS_BYTES, st, xa);
-                else hipLaunchKernelGGL((k_edge_msg_x3<16, 8, 32>), dim3(tiles), dim3(256), EdgeGeo<32>::LDS_BYTES, st, xa);
+                if (h->Se == 64) hipLaunchKernelGGL((k_edge_msg_x3<64, 16, 32>), dim3(wgs), dim3(256), EdgeGeo<32>::LDS_BYTES_X3, st, xa);
+                else hipLaunchKernelGGL((k_edge_msg_x3<16, 8, 32>), dim3(wgs), dim3(256), EdgeGeo<32>::LDS_BYTES_X3, st, xa);
             }
         } else if (ET == 64) {
             if (h->Se == 64) hipLaunchKernelGGL((k_edge_msg<64, 16, 64>), dim3(tiles), dim3(EdgeGeo<64>::THREADS), EdgeGeo<64>::LDS_BYTES, st, ma);
@@ -1250,6 +1261,7 @@ int gcdm_set_option(gcdm_handle* h, const char* name, int32_t value) {
     if (k == "flat_prev") { h->flat_prev = value ? 1 : 0; return 0; }
     if (k == "flat_next") { h->flat_next = value ? 1 : 0; return 0; }
     if (k == "node_base") { if (value < 0) return fail(h, "gcdm_set_option(node_base): >= 0"); h->node_base = (uint32_t)value; return 0; }
+    if (k == "persistent") { h->persistent = value ? 1 : 0; return 0; }
     if (k == "edge_tile") {
         if (value != 0 && value != 32 && value != 64) return fail(h, "gcdm_set_option(edge_tile): 0 (automatic), 32 or 64");
         h->edge_tile = value;
@@ -1269,6 +1281,7 @@ int gcdm_get_option(const gcdm_handle* h, const char* name) {
     if (k == "flat_next") return h->flat_next;
     if (k == "node_base") return (int)h->node_base;
     if (k == "x3_shift") return h->x3_shift;
+    if (k == "persistent") return h->persistent;
     return -1;
 }
 

@@ -66,21 +66,37 @@ __device__ __forceinline__ void split16(float x, _Float16& hi, _Float16& lo) {
     lo = (_Float16)__builtin_fmaf((float)hi, -X3_SCALE, x);
 }
 
-// Two values at once, 2 VALU instructions per value: two mixed-precision FMAs -- v_fma_mix{lo,hi}_f16 writes f16(x * 2^-11) resp.
-// f16(x - hi * 2^11) into one half of the destination, reading hi as f16 (the compiler does not form these reliably).  Bit-identical to
-// split16: all products are by powers of two, one rounding to f16 at the end of each.
+// Two values at once.  tools/valu_ubench8.hip (MI355X, two waves per SIMD): a v_fma_mix{lo,hi}_f16 -- the 16-bit-destination form --
+// occupies the SIMD for 6.9 clk, v_fma_mix_f32 / v_cvt_pk_f16_f32 / v_mul_f32 for 3.0-3.8.  So instead of four f16-destination FMAs per
+// pair (round 2) the split is: scale (v_mul x2, or one v_pk_mul_f32 with -DGCDM_X3_PK), v_cvt_pk_f16_f32 (gfx950: round-to-nearest pack),
+// two f32 mixed FMAs that read hi as f16 from the low / high half, v_cvt_pk_f16_f32: 5-6 full-rate instructions instead of 4 half-rate
+// ones (-15 % / -20 % on the state-image phase in the micro-benchmark), every destination a full 32-bit write.  Bit-identical to split16:
+// all products are by powers of two, x - hi * 2^11 is exact in fp32, one rounding to f16 at the end of each half.
 typedef _Float16 h2 __attribute__((ext_vector_type(2)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void split16x2(float x0, float x1, h2& hi, h2& lo) {
     const float pre = X3_PRE, neg = -X3_SCALE;
-    const float s0 = x0, s1 = x1;
     uint32_t hiu, lou;
-    // hi = f16(x * 2^-11) (round to nearest), both halves of one register
+#ifdef GCDM_X3_SPLIT_MIX
+    const float s0 = x0, s1 = x1;
     asm("v_fma_mixlo_f16 %0, %1, %2, 0 op_sel_hi:[0,0,0]" : "=v"(hiu) : "v"(x0), "s"(pre));
     asm("v_fma_mixhi_f16 %0, %1, %2, 0 op_sel_hi:[0,0,0]" : "+v"(hiu) : "v"(x1), "s"(pre));
-    // lo' = f16(x - hi * 2^11): hi is read as f16 from the low / high half
     asm("v_fma_mixlo_f16 %0, %1, %2, %3 op_sel_hi:[1,0,0]" : "=v"(lou) : "v"(hiu), "s"(neg), "v"(s0));
     asm("v_fma_mixhi_f16 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(lou) : "v"(hiu), "s"(neg), "v"(s1));
+#else
+#ifdef GCDM_X3_PK
+    f32x2 t;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(t) : "v"((f32x2){x0, x1}), "s"((f32x2){pre, pre}));
+    const float t0 = t[0], t1 = t[1];
+#else
+    const float t0 = x0 * pre, t1 = x1 * pre;
+#endif
+    float r0, r1;
+    asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(hiu) : "v"(t0), "v"(t1));
+    asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel_hi:[1,0,0]" : "=v"(r0) : "v"(hiu), "s"(neg), "v"(x0));
+    asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r1) : "v"(hiu), "s"(neg), "v"(x1));
+    asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(lou) : "v"(r0), "v"(r1));
+#endif
     __builtin_memcpy(&hi, &hiu, 4);
     __builtin_memcpy(&lo, &lou, 4);
 }
@@ -440,6 +456,24 @@ __device__ __forceinline__ void put_gate_partial(float* PG, const f32x16 (&gm)[N
             v4f* p = (v4f*)(PG + pg_off<ET>(slot, 32 * n + l31, 2 * t + half));      // channels 8t + 4 half + {0..3}
             *p = add ? *p + v : v;
         }
+}
+
+// (-DGCDM_X3_FOLD_SYM, measured and not kept) One N-tile (32 edges) of a wave's partial, for a symmetric fold: waves s and s + 4 share slot s, in the
+// first stage wave s stores its N-tile 0 and wave s + 4 its N-tile 1, after the barrier each adds its other N-tile onto the half the partner
+// stored.  Same sums, every wave busy in both stages -- but waves s and s + 4 share a SIMD, so the "idle" wave of the two-stage fold never
+// cost SIMD time: +0.5 % tile cycles (more address arithmetic).  What does pay is that the barrier between the two stages already says "all
+// waves are done reading the operand images": the barrier behind the fold is gone (-1.0 % QM9, -0.2 % GEOM), see the kernel.
+template <int ET>
+__device__ __forceinline__ void put_gate_half(float* PG, const f32x16& gm, const f32x16& gl, int slot, int n, int lane, bool add) {
+    const int half = lane >> 5, l31 = lane & 31;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        v4f v;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = gm[4 * t + i] + gl[4 * t + i] * X3_INV_SCALE;
+        v4f* p = (v4f*)(PG + pg_off<ET>(slot, 32 * n + l31, 2 * t + half));
+        *p = add ? *p + v : v;
+    }
 }
 
 // (node kernels) gate partials PG[slot][c][e], same two-stage fold
@@ -810,6 +844,7 @@ struct EdgeMsgX3Args {
     const h8* vf1[3]; const h8* vf2[3];             // msg1..3 vector_up [32 x 8] as two M-tiles: A1 = [W_hi | 0], A2 = [W_lo' | W_hi]
     const h8* vf0H; const h8* vf0L;                 // msg0 vector_up [32 x H0] as two M-tiles, K = hidden channel
     const h8* wbeH; const h8* wbeL;                 // msg0: the edge block of [W_down; W_frames] ((H0 + 3) x Ve -> 32 x 16) as ONE A operand [64 lanes] x 8 f16
+    int wg_stride;                                  // persistent schedule: workgroups per XCD (gridDim.x / 8; >= tiles per XCD when every workgroup takes one tile)
     const float* wax;                               // scalar_message_attention weights / c
     const void* wpool; uint32_t wpool_bytes;        // the whole weight pool (every packed array above lies inside): base of the buffer-load stream
     const void* wspool; uint32_t wspool_bytes;      // the workspace pool (EP4, AL, U, FR, PQ4, VDI, VDJ lie inside)
@@ -820,10 +855,15 @@ struct EdgeMsgX3Args {
 // ET = 64: 8 waves, wave w owns M-tile w x both N-tiles (every weight byte is loaded once per CU and tile).
 // ET = 32: 4 waves, wave w owns M-tiles 2w, 2w+1 x one N-tile; half the LDS, so two workgroups share a CU and run out of phase
 //          (one in its GEMM while the other is in a VALU phase) at the price of streaming the weights twice per 64 edges.
+#ifdef GCDM_X3_FOLD_KEEP_BARRIER
+#define X3_FOLD_BARRIER true
+#else
+#define X3_FOLD_BARRIER false
+#endif
 template <int SE, int VE, int ET>
-__global__ __launch_bounds__(ET * 8) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_edge_msg_x3(EdgeMsgX3Args ax) {
+__global__ __launch_bounds__(ET * 8) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_edge_msg_x3(EdgeMsgX3Args ax0) {
     constexpr int NW = ET / 8, MT = 8 / NW, NT = ET / 32;     // waves, M-tiles and N-tiles per wave
-    const EdgeMsgArgs& a = ax.base;
+    const EdgeMsgArgs& a0 = ax0.base;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     using Geo = EdgeGeo<ET>;
     constexpr int ETP = Geo::TP, EK_THREADS = Geo::THREADS, PARTS = Geo::PARTS;
@@ -836,8 +876,8 @@ __global__ __launch_bounds__(ET * 8) __attribute__((amdgpu_waves_per_eu(2, 2))) 
     float* PG = (float*)(smem + Geo::OFF_PG);
     float* FR = (float*)(smem + Geo::OFF_FR);
     int* m_row = (int*)(smem + Geo::OFF_META);
-    int* m_col = m_row + ET;
-    int* m_seg = m_col + ET;
+    int* m_whole = m_row + ET;                          // [segment] 1: whole row of its node (the fp32 kernel keeps the column indices here)
+    int* m_seg = m_whole + ET;
     float* m_att = (float*)(m_seg + ET + 2);
     int* m_misc = (int*)(m_att + ET);
 
@@ -847,51 +887,49 @@ __global__ __launch_bounds__(ET * 8) __attribute__((amdgpu_waves_per_eu(2, 2))) 
     constexpr int H0G8 = (H0 + 7) / 8;
     constexpr int Q8 = N8 + H0G8;
     constexpr int KB0C = (8 * (Q8 + 2) + 15) / 16;       // k-blocks of the msg0 per-edge part (host: gcdm_api.hip, same formula); msg1..3: 18
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int e = (ET == 64) ? lane : (tid & (ET - 1)), part = (ET == 64) ? wave : (tid / ET);
-    const int E = a.E, N = a.N;
-    // XCD-aware tile order: workgroup b runs on XCD b % 8 (round-robin dispatch), so XCD x takes the x-th contiguous eighth of the tiles and
-    // the node rows its tiles gather (PQ4 / VDI / VDJ of consecutive molecules) stay in that XCD's own L2.  Same tiles, same results;
-    // measured -0.5 % (QM9) / -0.2 % (GEOM) step time (tools/ab_variant.py, same box, alternating runs).
-    const int G_ = gridDim.x, xcd_ = blockIdx.x & 7, base_ = G_ >> 3, rem_ = G_ & 7;
-    const int e0 = (xcd_ * base_ + min(xcd_, rem_) + (int)(blockIdx.x >> 3)) * ET;
-    const int nvalid = min(ET, E - e0);
-    const int eid = min(e0 + e, E - 1);
-    const int ni = a.EROW[eid], nj = a.ECOL[eid];
-    const uint64_t t_start = a.prof ? __builtin_amdgcn_s_memtime() : 0;
-    bool over = false;
+    // who am I: recomputed from an opaque copy of the thread index at the top of every tile, so that the compiler does not hoist the dozens of
+    // lane-dependent LDS / buffer offsets of the tile body out of the persistent loop and keep them in registers across the GEMM phases
+    struct Who {
+        int tid, lane, wave, e, part, mt0;
+        bool need_fr;
+    };
+    auto who_am_i = [&](int tid_) {
+        Who w;
+        w.tid = tid_; w.lane = tid_ & 63;
+        w.wave = __builtin_amdgcn_readfirstlane(tid_ >> 6);
+        w.e = (ET == 64) ? w.lane : (tid_ & (ET - 1));
+        w.part = (ET == 64) ? w.wave : (tid_ / ET);
+        w.mt0 = (8 / (ET / 8)) * w.wave;
+        // the frame rows of an edge are needed by the thread that stages them in LDS (part 0) and by the threads whose rows of the pre-phase are
+        // the three frame vectors (H0 <= part + PARTS i < H0 + 3): 4 of the 8 threads per edge; the others skip the nine loads
+        w.need_fr = w.part == 0;
+#pragma unroll
+        for (int i = 0; i < (H0 + 3 + PARTS - 1) / PARTS; ++i) w.need_fr |= (w.part + PARTS * i >= H0) && (w.part + PARTS * i < H0 + 3);
+        return w;
+    };
+    const Who w0 = who_am_i(threadIdx.x);
+    const int E = a0.E, N = a0.N;
+    // Persistent workgroups (one per CU at ET = 64): workgroup b runs on XCD b % 8 (round-robin dispatch) and walks tiles
+    //     start(x) + (b >> 3) + j * wg_stride,   j = 0, 1, ...
+    // of the x-th contiguous eighth of the tile list, so the node rows its tiles gather (PQ4 / VDI / VDJ of consecutive molecules) stay in
+    // that XCD's own L2 (round 2: -0.5 % / -0.2 %).  What the loop buys is the NEXT tile's operands: its index words are requested behind the
+    // last GEMM and its per-edge constants and gathered node rows behind the last state image, into registers that are free there (the
+    // accumulators and the state are dead), so the two dependent round trips that opened every tile (index -> gather -> use, ~4 k cycles
+    // with nothing else to issue: one workgroup per CU) run under the attention + aggregation phase of the tile before.
+    const int G_ = (E + ET - 1) / ET, xcd_ = blockIdx.x & 7, base_ = G_ >> 3, rem_ = G_ & 7;
+    const int cnt_ = base_ + (xcd_ < rem_ ? 1 : 0), start_ = xcd_ * base_ + min(xcd_, rem_), stride_ = ax0.wg_stride;
+    int it_ = blockIdx.x >> 3;
     constexpr int PD = GCDM_X3_PD;
-    const int mt0 = MT * wave;   // first M-tile (32 output channels each) of this wave
     X3Ring<MT, PD> ring;
-    const WPool wp = make_wpool(ax.wpool, ax.wpool_bytes, lane);
-    const uint32_t o0H = wp.off(ax.w0H + (size_t)mt0 * KB0C * 64), o0L = wp.off(ax.w0L + (size_t)mt0 * KB0C * 64);
-    x3_prefetch_b<MT, PD>(ring, wp, o0H, o0L, KB0C);   // flies during P1
-    // per-edge constants of this thread's edge (streamed from HBM, independent of the edge list): requested first.  Buffer loads: the
-    // per-lane offset is the edge (node) index, array base and row stride are scalars -- no 64-bit VALU address arithmetic per load
-    const BufView ws = make_view(ax.wspool, ax.wspool_bytes);
-    const BufView wv = make_view(ax.wpool, ax.wpool_bytes);
+    const WPool wp = make_wpool(ax0.wpool, ax0.wpool_bytes, w0.lane);
+    // per-edge constants (streamed from HBM, independent of the edge list) and gathered node rows.  Buffer loads: the per-lane offset is the
+    // edge (node) index, array base and row stride are scalars -- no 64-bit VALU address arithmetic per load
+    const BufView ws = make_view(ax0.wspool, ax0.wspool_bytes);
+    const BufView wv = make_view(ax0.wpool, ax0.wpool_bytes);
     constexpr int EPN = (SE / 4) / PARTS;                // e' float4 groups per thread (QM9 2, GEOM: parts 0..3 one each)
-    const uint32_t ve4 = (uint32_t)eid * 4u, ve16 = (uint32_t)eid * 16u, rowE = (uint32_t)E * 4u, rowN = (uint32_t)N * 4u;
-    constexpr int H0_ = (2 * GCDM_V + VE) / 4;
-    // the frame rows of an edge are needed by the thread that stages them in LDS (part 0) and by the threads whose rows of the pre-phase are the
-    // three frame vectors (H0 <= part + PARTS i < H0 + 3): 4 of the 8 threads per edge; the others skip the nine loads
-    bool need_fr = part == 0;
-#pragma unroll
-    for (int i = 0; i < (H0_ + 3 + PARTS - 1) / PARTS; ++i) need_fr |= (part + PARTS * i >= H0_) && (part + PARTS * i < H0_ + 3);
-    float fr[9];
-    {
-        const uint32_t o = ws.off(a.FR);
-#pragma unroll
-        for (int r = 0; r < 9; ++r) fr[r] = need_fr ? ws.ld1(ve4, o + r * rowE) : 0.f;
-    }
-    v4f epv[EPN > 0 ? EPN : 1];
-    {
-        const uint32_t o = ws.off(a.EP4);
-#pragma unroll
-        for (int i = 0; i < (EPN > 0 ? EPN : 1); ++i)
-            epv[i] = ws.ld4(ve16 + (uint32_t)min(part + PARTS * i, SE / 4 - 1) * (rowE * 4u), o);          // the group index depends on the lane's part
-    }
+    constexpr int EPN1 = EPN > 0 ? EPN : 1;
+    const uint32_t rowE = (uint32_t)E * 4u, rowN = (uint32_t)N * 4u;
+    constexpr int ROWS0 = H0 + 3, NH0 = (ROWS0 + PARTS - 1) / PARTS;
     // beta products of the pre-phase: on the matrix pipe for the 16-channel edge width (QM9: -1.8 % tile cycles), the round-2 VALU form
     // (every thread loads the edge's alpha and its rows of W_e) for the 8-channel one, where half of the MFMA's K would be padding (GEOM: +0.5 %)
 #ifdef GCDM_X3_BETA_VALU
@@ -899,46 +937,137 @@ __global__ __launch_bounds__(ET * 8) __attribute__((amdgpu_waves_per_eu(2, 2))) 
 #else
     constexpr bool BETA_MFMA = VE == 16;
 #endif
-    float al[VE];
-    if constexpr (!BETA_MFMA) {
-        const uint32_t o = ws.off(a.AL);
-#pragma unroll
-        for (int c = 0; c < VE; ++c) al[c] = ws.ld1(ve4, o + c * rowE);
-    }
-    const uint32_t oU = ws.off(a.U);
-    const float u0 = ws.ld1(ve4, oU), u1 = ws.ld1(ve4, oU + rowE), u2 = ws.ld1(ve4, oU + 2 * rowE);
-    // node-level halves of msg0 (PQ4 rows of this lane's GEMM-layout edges): requested now, consumed after P1
-    v4f pqi[MT][NT][4], pqj[MT][NT][4];
-    {
-        const int half_ = lane >> 5, l31_ = lane & 31;
-        const uint32_t oP = ws.off(a.PQ4), rowP = (uint32_t)N * 16u;
+    struct TileIdx {
+        int ni, nj;                      // this thread's edge (pre-phase layout: edge = lane, part = wave)
+        int ri[NT], cj[NT];              // this lane's GEMM-layout edges (32 n + (lane & 31))
+    };
+    struct TileIn {
+        float fr[9];
+        v4f epv[EPN1];
+        float al[BETA_MFMA ? 1 : VE];
+        float av[8];                     // BETA_MFMA: alpha rows of the contracting waves
+        float u0, u1, u2;
+        v4f pqi[MT][NT][4], pqj[MT][NT][4];          // node-level halves of msg0 (PQ4 rows), consumed after P1
+        float gi[NH0][3], gj[NH0][3];    // vector_down halves of the end nodes (VDI / VDJ rows)
+        int ncnt;                        // wave 0: number of edges of the row of this thread's edge (is a segment of the tile a whole row?)
+    };
+    auto load_idx = [&](const EdgeMsgArgs& a, const Who& w, int tile) {
+        TileIdx ix;
+        const int e0 = tile * ET, eid = min(e0 + w.e, E - 1);
+        ix.ni = a.EROW[eid]; ix.nj = a.ECOL[eid];
 #pragma unroll
         for (int n = 0; n < NT; ++n) {
-            const int eg = min(e0 + 32 * n + l31_, E - 1);
-            const int ri = a.EROW[eg], cj = a.ECOL[eg];
-            const uint32_t vi = ((uint32_t)half_ * N + ri) * 16u, vj = ((uint32_t)half_ * N + cj) * 16u;     // group 2q + half: the half rides in the lane offset
-#pragma unroll
-            for (int m = 0; m < MT; ++m)
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int g = 8 * (mt0 + m) + 2 * q;
-                    pqi[m][n][q] = ws.ld4(vi, oP + (uint32_t)g * rowP);
-                    pqj[m][n][q] = ws.ld4(vj, oP + (uint32_t)(64 + g) * rowP);
-                }
+            const int eg = min(e0 + 32 * n + (w.lane & 31), E - 1);
+            ix.ri[n] = a.EROW[eg]; ix.cj[n] = a.ECOL[eg];
         }
-    }
+        return ix;
+    };
+    auto load_const = [&](const EdgeMsgArgs& a, const Who& w, int tile, TileIn& in) {       // independent of the edge list
+        const int e0 = tile * ET, eid = min(e0 + w.e, E - 1);
+        const uint32_t ve4 = (uint32_t)eid * 4u, ve16 = (uint32_t)eid * 16u;
+        {
+            const uint32_t o = ws.off(a.FR);
+#pragma unroll
+            for (int r = 0; r < 9; ++r) in.fr[r] = w.need_fr ? ws.ld1(ve4, o + r * rowE) : 0.f;
+        }
+        {
+            const uint32_t o = ws.off(a.EP4);
+#pragma unroll
+            for (int i = 0; i < EPN1; ++i)
+                in.epv[i] = ws.ld4(ve16 + (uint32_t)min(w.part + PARTS * i, SE / 4 - 1) * (rowE * 4u), o);          // the group index depends on the lane's part
+        }
+        if constexpr (!BETA_MFMA) {
+            const uint32_t o = ws.off(a.AL);
+#pragma unroll
+            for (int c = 0; c < VE; ++c) in.al[c] = ws.ld1(ve4, o + c * rowE);
+        } else {
+            if (w.wave < ET / 32) {
+                // (the half of K this lane holds rides in the per-lane offset: a lane-dependent scalar offset would cost a waterfall loop per load)
+                const uint32_t eg4 = (uint32_t)min(e0 + 32 * w.wave + (w.lane & 31), E - 1) * 4u + (uint32_t)(8 * (w.lane >> 5)) * rowE, o = ws.off(a.AL);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) in.av[j] = ws.ld1(eg4, o + (uint32_t)j * rowE);
+            }
+        }
+        const uint32_t oU = ws.off(a.U);
+        in.u0 = ws.ld1(ve4, oU); in.u1 = ws.ld1(ve4, oU + rowE); in.u2 = ws.ld1(ve4, oU + 2 * rowE);
+    };
+    // node rows (need the index words), in GCH chunks: the 16 PQ4 rows (16 B per lane each: 16 clk of the L1 path per wave instruction) and the
+    // 18 VDI / VDJ words go through the texture-address path at 64 B/clk/CU -- ~2.6 k cycles per tile, which a wave that issues them back to
+    // back spends waiting at the issue queue (measured: the phase they are issued in grows by just that).  So they are dealt out, a few at a
+    // time, over phases of LDS + VALU work
+    constexpr int GCH = GCDM_SG / PARTS, NPQ = NT * MT * 4 * 2, NVD = NH0 * 3 * 2;
+    // PQ4 rows of the CURRENT tile (its index words were prefetched): dealt out over the steps of the pre-phase, consumed right behind it
+    auto load_pq_part = [&](auto cc, const EdgeMsgArgs& a, const Who& w, const TileIdx& ix, TileIn& in) {
+        constexpr int C = decltype(cc)::value;
+        const uint32_t oP = ws.off(a.PQ4), rowP = (uint32_t)N * 16u;
+        static_for<C * NPQ / GCH, (C + 1) * NPQ / GCH>([&](auto fc) {
+            constexpr int f = decltype(fc)::value, which = f & 1, q = (f >> 1) & 3, m = (f >> 3) % MT, n = (f >> 3) / MT;
+            const int g = 8 * (w.mt0 + m) + 2 * q;
+            const uint32_t v = ((uint32_t)(w.lane >> 5) * N + (which ? ix.cj[n] : ix.ri[n])) * 16u;     // group 2q + half: the half rides in the lane offset
+            if (which) in.pqj[m][n][q] = ws.ld4(v, oP + (uint32_t)(64 + g) * rowP);
+            else in.pqi[m][n][q] = ws.ld4(v, oP + (uint32_t)g * rowP);
+        });
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    // VDI / VDJ words of the NEXT tile: over the steps of the attention dot product
+    auto load_gather_part = [&](auto cc, const EdgeMsgArgs& a, const Who& w, const TileIdx& ix, TileIn& in) {
+        constexpr int C = decltype(cc)::value;
+        const uint32_t oI = ws.off(a.VDI), oJ = ws.off(a.VDJ);
+        static_for<C * NVD / GCH, (C + 1) * NVD / GCH>([&](auto vc) {
+            constexpr int f = decltype(vc)::value, which = f & 1, x = (f >> 1) % 3, i = (f >> 1) / 3;
+            const int hh = min(w.part + PARTS * i, ROWS0 - 1);                                      // the row depends on the lane's part
+#ifdef GCDM_ABL_NOGATHER
+            if (which) in.gj[i][x] = 0.2f; else in.gi[i][x] = 0.1f * x;
+#else
+            const uint32_t v = ((uint32_t)(hh * 3) * N + (which ? ix.nj : ix.ni)) * 4u;
+            if (which) in.gj[i][x] = ws.ld1(v, oJ + x * rowN);
+            else in.gi[i][x] = ws.ld1(v, oI + x * rowN);
+#endif
+        });
+        if (C == GCH - 1) in.ncnt = w.wave == 0 ? a.NCNT[ix.ni] : 0;
+    };
+    v4f* WAX4 = (v4f*)(smem + Geo::OFF_WAX);
+    if (w0.tid < GCDM_SG) WAX4[w0.tid] = *(const v4f*)(ax0.wax + 4 * w0.tid);       // visible after the first tile's barriers
+    TileIdx ix = load_idx(a0, w0, start_ + it_);
+    TileIn in;
+    load_const(a0, w0, start_ + it_, in);
+    static_for<0, GCH>([&](auto cc) { load_gather_part(cc, a0, w0, ix, in); });
+    for (;;) {
+    // ... and the kernel arguments through an opaque copy of the kernel-argument pointer: their scalar loads stay where they are used instead
+    // of being hoisted out of the loop into SGPRs that then spill to VGPR lanes inside the GEMM loops
+    typedef const EdgeMsgX3Args __attribute__((address_space(4)))* karg_ptr;
+    karg_ptr kp_ = (karg_ptr)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(kp_));
+    const EdgeMsgX3Args& ax = *(const EdgeMsgX3Args*)kp_;
+    const EdgeMsgArgs& a = ax.base;
+    int tid_ = threadIdx.x;
+    asm volatile("" : "+v"(tid_));
+    const Who me = who_am_i(tid_);
+    const int tid = me.tid, lane = me.lane, wave = me.wave, e = me.e, part = me.part, mt0 = me.mt0;
+    const uint32_t o0H = wp.off(ax.w0H + (size_t)mt0 * KB0C * 64), o0L = wp.off(ax.w0L + (size_t)mt0 * KB0C * 64);
+    const int prof_tile = start_ + it_;
+    const int e0 = prof_tile * ET;
+    const int nvalid = min(ET, E - e0);
+    const int eid = min(e0 + e, E - 1);
+    const int ni = ix.ni;
+    [[maybe_unused]] const uint64_t t_start = a.prof ? __builtin_amdgcn_s_memtime() : 0;
+    bool over = false;
+    x3_prefetch_b<MT, PD>(ring, wp, o0H, o0L, KB0C);   // flies during P1
+    const float u0 = in.u0, u1 = in.u1, u2 = in.u2;
 
     if (wave == 0) {
         const bool own = lane < ET;
-        if (own) {
-            m_row[e] = ni;
-            m_col[e] = nj;
-        }
+        if (own) m_row[e] = ni;
         const int prev = __shfl_up(ni, 1);
         const bool start = own && (e < nvalid) && (e == 0 || prev != ni);
         const unsigned long long mask = __ballot(start);
         const int sid = __popcll(mask & ((2ull << lane) - 1ull)) - 1;
-        if (start) m_seg[sid] = e;
+        if (start) {
+            m_seg[sid] = e;
+            const unsigned long long rest = lane < 63 ? mask >> (lane + 1) : 0ull;
+            const int next = rest ? lane + 1 + __builtin_ctzll(rest) : nvalid;
+            m_whole[sid] = (next - e) == in.ncnt;          // the segment is the node's whole row (else: a partial for the cut-row fix-up)
+        }
         if (lane == 0) {
             const int ns = __popcll(mask);
             m_seg[ns] = nvalid;
@@ -949,6 +1078,7 @@ __global__ __launch_bounds__(ET * 8) __attribute__((amdgpu_waves_per_eu(2, 2))) 
 #ifndef GCDM_ABL_NOP1
     {
         float* BETA = PG;                                   // [ET][33]: BETA[e * 33 + h]
+        load_pq_part(std::integral_constant<int, 0>{}, a, me, ix, in);
         float* BETA2 = PG + ET * 33;                        // self-conditioning: the second rank (BL)
         if constexpr (BETA_MFMA) {
         // beta[h][e] = sum_c W_e[h][c] alpha_c[e] -- the edge block of vector_down / vector_down_frames applied to the rank-1 embedded edge
@@ -960,15 +1090,7 @@ __global__ __launch_bounds__(ET * 8) __attribute__((amdgpu_waves_per_eu(2, 2))) 
             const uint32_t eg4 = (uint32_t)min(e0 + 32 * wave + n_, E - 1) * 4u;
             const h8 aH = wp.ld(wp.off(ax.wbeH)), aL = wp.ld(wp.off(ax.wbeL));
             const f32x16 zero_ = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-            auto contract = [&](const float* SRC, float* DST) {
-                const uint32_t o = ws.off(SRC);
-                float av[8];
-#pragma unroll
-                for (int j = 0; j < 8; ++j) av[j] = (8 * kh_ + j < VE || VE == 16) ? ws.ld1(eg4, o + (uint32_t)min(8 * kh_ + j, VE - 1) * rowE) : 0.f;
-                if (VE < 16 && kh_ == 1) {
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) av[j] = 0.f;
-                }
+            auto contract = [&](const float (&av)[8], float* DST) {
                 h8 bh, bl;
 #pragma unroll
                 for (int j = 0; j < 8; j += 2) {
@@ -984,19 +1106,26 @@ __global__ __launch_bounds__(ET * 8) __attribute__((amdgpu_waves_per_eu(2, 2))) 
 #pragma unroll
                 for (int r = 0; r < 16; ++r) DST[(32 * wave + n_) * 33 + (r & 3) + 8 * (r >> 2) + 4 * kh_] = am_[r] + al_[r] * X3_INV_SCALE;
             };
-            contract(a.AL, BETA);
-            if (a.BL) contract(a.BL, BETA2);
+            contract(in.av, BETA);
+            if (a.BL) {                  // self-conditioning: the second rank, loaded here (not on the production path)
+                const uint32_t o = ws.off(a.BL), eg4k = eg4 + (uint32_t)(8 * kh_) * rowE;
+                float bv[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) bv[j] = ws.ld1(eg4k, o + (uint32_t)j * rowE);
+                contract(bv, BETA2);
+            }
         }
         }
         if (part == 0) {
 #pragma unroll
-            for (int r = 0; r < 9; ++r) FR[r * ETP + e] = fr[r];
+            for (int r = 0; r < 9; ++r) FR[r * ETP + e] = in.fr[r];
         }
+        load_pq_part(std::integral_constant<int, 1>{}, a, me, ix, in);
 #pragma unroll
-        for (int i = 0; i < (EPN > 0 ? EPN : 1); ++i) {       // e' (fp32 in HBM) -> hi / lo' halves of an 8-group
+        for (int i = 0; i < EPN1; ++i) {       // e' (fp32 in HBM) -> hi / lo' halves of an 8-group
             const int g = part + PARTS * i;
             if (g >= SEG) break;
-            const v4f v = epv[i];
+            const v4f v = in.epv[i];
             h4 vh, vl;
 #pragma unroll
             for (int t = 0; t < 4; t += 2) {
@@ -1010,30 +1139,21 @@ __global__ __launch_bounds__(ET * 8) __attribute__((amdgpu_waves_per_eu(2, 2))) 
             *(h4*)(XH + off) = vh;
             *(h4*)(XL + off) = vl;
         }
-        constexpr int ROWS0 = H0 + 3, NH0 = (ROWS0 + PARTS - 1) / PARTS;
-        float gi[NH0][3], gj[NH0][3], beta[NH0], beta2[NH0];
-        const uint32_t oI = ws.off(a.VDI), oJ = ws.off(a.VDJ), oW = wv.off(a.wddE);
+        load_pq_part(std::integral_constant<int, 2>{}, a, me, ix, in);
+        load_pq_part(std::integral_constant<int, 3>{}, a, me, ix, in);
+        float beta[NH0], beta2[NH0];
+        [[maybe_unused]] const uint32_t oW = wv.off(a.wddE);
 #pragma unroll
         for (int i = 0; i < NH0; ++i) {
-            const int hh = min(part + PARTS * i, ROWS0 - 1);
-            const uint32_t vI = ((uint32_t)(hh * 3) * N + ni) * 4u, vJ = ((uint32_t)(hh * 3) * N + nj) * 4u;   // the row depends on the lane's part
-#pragma unroll
-            for (int x = 0; x < 3; ++x) {
-#ifdef GCDM_ABL_NOGATHER
-                gi[i][x] = 0.1f * x; gj[i][x] = 0.2f;
-#else
-                gi[i][x] = ws.ld1(vI, oI + x * rowN);
-                gj[i][x] = ws.ld1(vJ, oJ + x * rowN);
-#endif
-            }
+            [[maybe_unused]] const int hh = min(part + PARTS * i, ROWS0 - 1);
             if constexpr (!BETA_MFMA) {
                 const uint32_t vW = (uint32_t)(hh * VE) * 4u;
                 float bsum = 0.f;
 #ifdef GCDM_ABL_NOBETA
-                bsum = al[0];
+                bsum = in.al[0];
 #else
 #pragma unroll
-                for (int c = 0; c < VE; ++c) bsum += wv.ld1(vW, oW + c * 4) * al[c];
+                for (int c = 0; c < VE; ++c) bsum += wv.ld1(vW, oW + c * 4) * in.al[c];
 #endif
                 beta[i] = bsum;
             }
@@ -1068,10 +1188,13 @@ __global__ __launch_bounds__(ET * 8) __attribute__((amdgpu_waves_per_eu(2, 2))) 
         }
 #pragma unroll
         for (int i = 0; i < NH0; ++i) {
+            if (i == 0) load_pq_part(std::integral_constant<int, 4>{}, a, me, ix, in);
+            if (i == 1) load_pq_part(std::integral_constant<int, 5>{}, a, me, ix, in);
+            if (i == 2) load_pq_part(std::integral_constant<int, 6>{}, a, me, ix, in);
             const int hh = part + PARTS * i;
-            const float vx = gi[i][0] + beta[i] * u0 + beta2[i] * s0 + gj[i][0];
-            const float vy = gi[i][1] + beta[i] * u1 + beta2[i] * s1 + gj[i][1];
-            const float vz = gi[i][2] + beta[i] * u2 + beta2[i] * s2 + gj[i][2];
+            const float vx = in.gi[i][0] + beta[i] * u0 + beta2[i] * s0 + in.gj[i][0];
+            const float vy = in.gi[i][1] + beta[i] * u1 + beta2[i] * s1 + in.gj[i][1];
+            const float vz = in.gi[i][2] + beta[i] * u2 + beta2[i] * s2 + in.gj[i][2];
 #ifdef GCDM_ABL_NOP1W
             if (vx + vy + vz == 123.456f) VH[e] = vx;
             continue;
@@ -1086,10 +1209,11 @@ __global__ __launch_bounds__(ET * 8) __attribute__((amdgpu_waves_per_eu(2, 2))) 
 #pragma unroll
                 for (int r = 0; r < 3; ++r) {
                     const int idx = 3 * k + r;
-                    over |= put16(XH, XL, ETP, Q8 + (idx >> 3), idx & 7, e, fr[3 * r] * vx + fr[3 * r + 1] * vy + fr[3 * r + 2] * vz);
+                    over |= put16(XH, XL, ETP, Q8 + (idx >> 3), idx & 7, e, in.fr[3 * r] * vx + in.fr[3 * r + 1] * vy + in.fr[3 * r + 2] * vz);
                 }
             }
         }
+        static_for<(NH0 < 3 ? 4 + NH0 : 7), GCH>([&](auto cc) { load_pq_part(cc, a, me, ix, in); });
         if (part == PARTS - 1) {
             for (int hh = H0; hh < 8 * H0G8; ++hh) put16(XH, XL, ETP, N8 + (hh >> 3), hh & 7, e, 0.f);
             for (int idx = 9; idx < 16; ++idx) put16(XH, XL, ETP, Q8 + (idx >> 3), idx & 7, e, 0.f);
@@ -1133,7 +1257,7 @@ __global__ __launch_bounds__(ET * 8) __attribute__((amdgpu_waves_per_eu(2, 2))) 
 #ifdef GCDM_ABL_NOPQ
                     for (int t = 0; t < 4; ++t) am[m][n][4 * q + t] = 0.f;
 #else
-                    for (int t = 0; t < 4; ++t) am[m][n][4 * q + t] = pqi[m][n][q][t] + pqj[m][n][q][t];
+                    for (int t = 0; t < 4; ++t) am[m][n][4 * q + t] = in.pqi[m][n][q][t] + in.pqj[m][n][q][t];
 #endif
         STAMP(3);
         tile_gemm_x3z<MT, NT, PD, KB0C, false, true>(am, al2, ring, wp, o0H, o0L, xh8, xl8, ETP, lane);
@@ -1159,14 +1283,20 @@ __global__ __launch_bounds__(ET * 8) __attribute__((amdgpu_waves_per_eu(2, 2))) 
         if (NW == 4) {               // four partials = the four slots the vector waves sum: no fold needed
             put_gate_partial<NT, ET>(PG, gm, gl, wave, lane, false);
         } else {
+#ifndef GCDM_X3_FOLD_SYM
             if (wave < 4) put_gate_partial<NT, ET>(PG, gm, gl, wave, lane, false);
-            __syncthreads();
+            __syncthreads();         // also: every wave is done reading the msg0 operand images
             if (wave >= 4) put_gate_partial<NT, ET>(PG, gm, gl, wave - 4, lane, true);
+#else
+            if (wave < 4) put_gate_half<ET>(PG, gm[0], gl[0], wave & 3, 0, lane, false); else put_gate_half<ET>(PG, gm[NT - 1], gl[NT - 1], wave & 3, NT - 1, lane, false);
+            __syncthreads();
+            if (wave < 4) put_gate_half<ET>(PG, gm[NT - 1], gl[NT - 1], wave & 3, NT - 1, lane, true); else put_gate_half<ET>(PG, gm[0], gl[0], wave & 3, 0, lane, true);
+#endif
         }
 #endif
         STAMP(6);
     }
-    __syncthreads();
+    if (X3_FOLD_BARRIER || NW == 4) __syncthreads();
     STAMP(7);
     // ---- P3: state images ---------------------------------------------------------------------------------------------------
 #ifndef GCDM_ABL_NOSTORE
@@ -1177,6 +1307,7 @@ __global__ __launch_bounds__(ET * 8) __attribute__((amdgpu_waves_per_eu(2, 2))) 
     STAMP(9);
 
     // ---- residual message GCP2s k = 1..3; the vector part of the previous GCP2 rides in the shadow of each GEMM ------------------
+    constexpr int GPP = GCDM_SG / PARTS;                 // attention: float4 groups of the message scalars per thread
     static_for<0, 3>([&](auto kc) {
         constexpr int k = decltype(kc)::value;
         const GcpW& w = a.mk[k];
@@ -1229,6 +1360,14 @@ __global__ __launch_bounds__(ET * 8) __attribute__((amdgpu_waves_per_eu(2, 2))) 
 #else
         gate_partial_x3<MT, NT, true>(gm, gl, am, ax.wgH[k], ax.wgL[k], mt0, lane);
 #endif
+        // the next tile (clamped to the workgroup's last one: no branch): its index words and per-edge constants are requested behind the last
+        // gate contraction (its operands are dead) and arrive under the fold of the gate partials and the state image; the gathers that need the index words are dealt out
+        // over the attention phase (load_gather_part) and arrive under the aggregation
+        if (k == 2) {
+            const int nxt = start_ + min(it_ + stride_, cnt_ - 1);
+            ix = load_idx(a, me, nxt);
+            load_const(a, me, nxt, in);
+        }
 #ifdef GCDM_ABL_GATE_NOPG
         asm volatile("" ::"v"(gm[0]), "v"(gl[0]));
         if (false) {
@@ -1237,13 +1376,21 @@ __global__ __launch_bounds__(ET * 8) __attribute__((amdgpu_waves_per_eu(2, 2))) 
 #endif
             put_gate_partial<NT, ET>(PG, gm, gl, wave, lane, false);
         } else {
+#ifndef GCDM_X3_FOLD_SYM
             if (wave < 4) put_gate_partial<NT, ET>(PG, gm, gl, wave, lane, false);
-            __syncthreads();
+            __syncthreads();         // also: every wave is done reading the old XH8 / XL8 images
             if (wave >= 4) put_gate_partial<NT, ET>(PG, gm, gl, wave - 4, lane, true);
+#else
+            if (wave < 4) put_gate_half<ET>(PG, gm[0], gl[0], wave & 3, 0, lane, false); else put_gate_half<ET>(PG, gm[NT - 1], gl[NT - 1], wave & 3, NT - 1, lane, false);
+            __syncthreads();
+            if (wave < 4) put_gate_half<ET>(PG, gm[NT - 1], gl[NT - 1], wave & 3, NT - 1, lane, true); else put_gate_half<ET>(PG, gm[0], gl[0], wave & 3, 0, lane, true);
+#endif
         }
 #endif
         if (k == 0) STAMP(14);
-        __syncthreads();                 // every wave is done reading the old XH8 / XL8 images; gate partials complete
+        // 4 waves: every wave is done reading the old images; gate partials complete.  8 waves: the barrier inside the fold said the first, and
+        // the partials are complete at the barrier behind the state images -- except in the last GCP2, whose vector part reads them before that
+        if (X3_FOLD_BARRIER || NW == 4 || k == 2) __syncthreads();
         if (k == 0) STAMP(15);
 #pragma unroll
         for (int m = 0; m < MT; ++m)
@@ -1277,12 +1424,14 @@ __global__ __launch_bounds__(ET * 8) __attribute__((amdgpu_waves_per_eu(2, 2))) 
 #ifndef GCDM_ABL_NOAGG
     {
         float s = 0.f;
-        constexpr int GPP = GCDM_SG / PARTS;
-        for (int g = part * GPP; g < part * GPP + GPP; ++g) {
-            const v4f wv = *(const v4f*)(ax.wax + 4 * g);          // attention weights / c: the image holds c * m.s
-            const v4f x = XS4[g * ETP + e];
+        static_for<0, GPP>([&](auto gc) {
+            constexpr int g = decltype(gc)::value;
+            const v4f wv = WAX4[part * GPP + g];                   // attention weights / c (the image holds c * m.s), staged in LDS once per workgroup
+            const v4f x = XS4[(part * GPP + g) * ETP + e];
             s += wv[0] * x[0] + wv[1] * x[1] + wv[2] * x[2] + wv[3] * x[3];
-        }
+            load_gather_part(gc, a, me, ix, in);                   // next tile's node rows, one chunk per step
+            __builtin_amdgcn_sched_barrier(0);
+        });
         PG[part * ETP + e] = s;
         __syncthreads();
         if (part == 0) {
@@ -1301,7 +1450,7 @@ __global__ __launch_bounds__(ET * 8) __attribute__((amdgpu_waves_per_eu(2, 2))) 
             const int sg = wk / UNITS, un = wk - sg * UNITS;
             const int sb = m_seg[sg], en = m_seg[sg + 1];
             const int node = m_row[sb];
-            const bool whole = (en - sb) == a.NCNT[node];
+            const bool whole = m_whole[sg] != 0;
             float* dst = whole ? a.AGG + (size_t)node * GCDM_AGGW : a.PART + ((size_t)(e0 / ET) * 2 + (sb == 0 ? 0 : 1)) * GCDM_AGGW;
             if (un < GCDM_SG) {
                 // (4 edges per trip: the LDS reads of a trip are independent, the additions keep the edge order -- same bits as the plain loop)
@@ -1331,4 +1480,8 @@ __global__ __launch_bounds__(ET * 8) __attribute__((amdgpu_waves_per_eu(2, 2))) 
     }
 #endif
     STAMP(20);
+    it_ += stride_;
+    if (it_ >= cnt_) break;
+    __syncthreads();                 // every wave is done with this tile's LDS (XS4 / VV4 / segment table) before the next pre-phase rewrites it
+    }
 }

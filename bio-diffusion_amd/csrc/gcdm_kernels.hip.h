@@ -598,7 +598,7 @@ struct EdgeMsgArgs {
 #ifdef GCDM_STAMPS
 #define STAMP(i)                                                                                        \
     do {                                                                                                \
-        if (a.prof && lane == 0) a.prof[((size_t)blockIdx.x * 8 + wave) * 24 + (i)] = (float)(__builtin_amdgcn_s_memtime() - t_start); \
+        if (a.prof && lane == 0) a.prof[((size_t)prof_tile * 8 + wave) * 24 + (i)] = (float)(__builtin_amdgcn_s_memtime() - t_start); \
     } while (0)
 #define GCDM_HAVE_STAMPS 1
 #else
@@ -622,6 +622,8 @@ struct EdgeGeo {
     static constexpr int OFF_META = OFF_FR + 9 * TP * 4;
     static constexpr int OFF_VHB = (OFF_META + (T + T + (T + 2) + T + 4) * 4 + 15) & ~15;   // split-precision kernel: hidden-vector images [3][3][T] x 16 B
     static constexpr int LDS_BYTES = OFF_VHB + 3 * 3 * T * 16;
+    static constexpr int OFF_WAX = LDS_BYTES;                      // split-precision kernel (persistent): attention weights, staged once per workgroup
+    static constexpr int LDS_BYTES_X3 = OFF_WAX + GCDM_S * 4;
 };
 
 template <int SE, int VE, int ET>
@@ -654,6 +656,7 @@ __global__ __launch_bounds__(EdgeGeo<ET>::THREADS) void k_edge_msg(EdgeMsgArgs a
     const int nvalid = min(ET, E - e0);
     const int eid = min(e0 + e, E - 1);
     const int ni = a.EROW[eid], nj = a.ECOL[eid];
+    [[maybe_unused]] const int prof_tile = blockIdx.x;
     const uint64_t t_start = a.prof ? __builtin_amdgcn_s_memtime() : 0;
 
     // ---- P0: tile metadata + row segments (wave 0) -------------------------------------------
