@@ -962,25 +962,27 @@ __global__ __launch_bounds__(ET * 8) __attribute__((amdgpu_waves_per_eu(2, 2))) 
         }
         return ix;
     };
-    auto load_const = [&](const EdgeMsgArgs& a, const Who& w, int tile, TileIn& in) {       // independent of the edge list
+    auto load_const = [&](auto pc, const EdgeMsgArgs& a, const Who& w, int tile, TileIn& in) {       // independent of the edge list; three bursts (P = 0, 1, 2; P < 0: all)
+        constexpr int P = decltype(pc)::value;
         const int e0 = tile * ET, eid = min(e0 + w.e, E - 1);
         const uint32_t ve4 = (uint32_t)eid * 4u, ve16 = (uint32_t)eid * 16u;
-        {
+        if constexpr (P < 0 || P == 0) {
             const uint32_t o = ws.off(a.FR);
 #pragma unroll
             for (int r = 0; r < 9; ++r) in.fr[r] = w.need_fr ? ws.ld1(ve4, o + r * rowE) : 0.f;
         }
-        {
+        if constexpr (P < 0 || P == 1) {
             const uint32_t o = ws.off(a.EP4);
 #pragma unroll
             for (int i = 0; i < EPN1; ++i)
                 in.epv[i] = ws.ld4(ve16 + (uint32_t)min(w.part + PARTS * i, SE / 4 - 1) * (rowE * 4u), o);          // the group index depends on the lane's part
         }
-        if constexpr (!BETA_MFMA) {
+        if constexpr ((P < 0 || P == 2) && !BETA_MFMA) {
             const uint32_t o = ws.off(a.AL);
 #pragma unroll
             for (int c = 0; c < VE; ++c) in.al[c] = ws.ld1(ve4, o + c * rowE);
-        } else {
+        }
+        if constexpr ((P < 0 || P == 1) && BETA_MFMA) {
             if (w.wave < ET / 32) {
                 // (the half of K this lane holds rides in the per-lane offset: a lane-dependent scalar offset would cost a waterfall loop per load)
                 const uint32_t eg4 = (uint32_t)min(e0 + 32 * w.wave + (w.lane & 31), E - 1) * 4u + (uint32_t)(8 * (w.lane >> 5)) * rowE, o = ws.off(a.AL);
@@ -988,8 +990,10 @@ __global__ __launch_bounds__(ET * 8) __attribute__((amdgpu_waves_per_eu(2, 2))) 
                 for (int j = 0; j < 8; ++j) in.av[j] = ws.ld1(eg4, o + (uint32_t)j * rowE);
             }
         }
-        const uint32_t oU = ws.off(a.U);
-        in.u0 = ws.ld1(ve4, oU); in.u1 = ws.ld1(ve4, oU + rowE); in.u2 = ws.ld1(ve4, oU + 2 * rowE);
+        if constexpr (P < 0 || P == 2) {
+            const uint32_t oU = ws.off(a.U);
+            in.u0 = ws.ld1(ve4, oU); in.u1 = ws.ld1(ve4, oU + rowE); in.u2 = ws.ld1(ve4, oU + 2 * rowE);
+        }
     };
     // node rows (need the index words), in GCH chunks: the 16 PQ4 rows (16 B per lane each: 16 clk of the L1 path per wave instruction) and the
     // 18 VDI / VDJ words go through the texture-address path at 64 B/clk/CU -- ~2.6 k cycles per tile, which a wave that issues them back to
@@ -1030,7 +1034,7 @@ __global__ __launch_bounds__(ET * 8) __attribute__((amdgpu_waves_per_eu(2, 2))) 
     if (w0.tid < GCDM_SG) WAX4[w0.tid] = *(const v4f*)(ax0.wax + 4 * w0.tid);       // visible after the first tile's barriers
     TileIdx ix = load_idx(a0, w0, start_ + it_);
     TileIn in;
-    load_const(a0, w0, start_ + it_, in);
+    load_const(std::integral_constant<int, -1>{}, a0, w0, start_ + it_, in);
     static_for<0, GCH>([&](auto cc) { load_gather_part(cc, a0, w0, ix, in); });
     for (;;) {
     // ... and the kernel arguments through an opaque copy of the kernel-argument pointer: their scalar loads stay where they are used instead
@@ -1366,7 +1370,11 @@ __global__ __launch_bounds__(ET * 8) __attribute__((amdgpu_waves_per_eu(2, 2))) 
         if (k == 2) {
             const int nxt = start_ + min(it_ + stride_, cnt_ - 1);
             ix = load_idx(a, me, nxt);
-            load_const(a, me, nxt, in);
+#ifdef GCDM_X3_CONST_BURST
+            load_const(std::integral_constant<int, -1>{}, a, me, nxt, in);
+#else
+            load_const(std::integral_constant<int, 0>{}, a, me, nxt, in);      // (in three bursts with the fold / the residual add between them)
+#endif
         }
 #ifdef GCDM_ABL_GATE_NOPG
         asm volatile("" ::"v"(gm[0]), "v"(gl[0]));
@@ -1390,6 +1398,9 @@ __global__ __launch_bounds__(ET * 8) __attribute__((amdgpu_waves_per_eu(2, 2))) 
         if (k == 0) STAMP(14);
         // 4 waves: every wave is done reading the old images; gate partials complete.  8 waves: the barrier inside the fold said the first, and
         // the partials are complete at the barrier behind the state images -- except in the last GCP2, whose vector part reads them before that
+#ifndef GCDM_X3_CONST_BURST
+        if (k == 2) load_const(std::integral_constant<int, 1>{}, a, me, start_ + min(it_ + stride_, cnt_ - 1), in);
+#endif
         if (X3_FOLD_BARRIER || NW == 4 || k == 2) __syncthreads();
         if (k == 0) STAMP(15);
 #pragma unroll
@@ -1398,6 +1409,9 @@ __global__ __launch_bounds__(ET * 8) __attribute__((amdgpu_waves_per_eu(2, 2))) 
             for (int n = 0; n < NT; ++n)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) st[m][n][r] += am[m][n][r];       // residual add in fp32 (gcpnet.py:701)
+#ifndef GCDM_X3_CONST_BURST
+        if (k == 2) load_const(std::integral_constant<int, 2>{}, a, me, start_ + min(it_ + stride_, cnt_ - 1), in);
+#endif
         if (k < 2) {
 #ifndef GCDM_ABL_NOSTORE
             store_state_x3<MT, NT>(XH, XL, 0, st, ETP, mt0, lane, amax);
@@ -1445,7 +1459,10 @@ __global__ __launch_bounds__(ET * 8) __attribute__((amdgpu_waves_per_eu(2, 2))) 
     STAMP(19);
     {
         const int nseg = m_misc[0];
-        constexpr int UNITS = GCDM_SG + 3 * GCDM_V;
+        // work items: (segment, float4 unit) -- 64 scalar groups + 3 x 8 groups of the message vectors (VV4[x][cg][edge] is already float4 by
+        // channel): 88 per segment, so the 4-5 row segments of a QM9 tile are ONE trip of the 512 threads (round 2: 160 units, the vector
+        // components one float each -> 1.4 trips, the second one on three waves only)
+        constexpr int UNITS = GCDM_SG + 3 * (GCDM_V / 4);
         for (int wk = tid; wk < nseg * UNITS; wk += EK_THREADS) {
             const int sg = wk / UNITS, un = wk - sg * UNITS;
             const int sb = m_seg[sg], en = m_seg[sg + 1];
@@ -1465,16 +1482,17 @@ __global__ __launch_bounds__(ET * 8) __attribute__((amdgpu_waves_per_eu(2, 2))) 
                 for (; x < en; ++x) s += xp[x] * m_att[x];
                 *(v4f*)(dst + 4 * un) = s * (1.0f / X3_C);           // back to true units
             } else {
-                const int r = un - GCDM_SG, c = r / 3, comp = r - 3 * c;      // AGG column S + 3c + comp (reference flatten layout)
-                const float* vp = (const float*)(VV4 + (comp * 8 + (c >> 2)) * ETP) + (c & 3);
-                float s = 0.f;
+                const int r = un - GCDM_SG, comp = r / (GCDM_V / 4), cg = r - comp * (GCDM_V / 4);
+                const v4f* vp = VV4 + (comp * 8 + cg) * ETP;
+                v4f s = {0.f, 0.f, 0.f, 0.f};
                 int x = sb;
                 for (; x + 4 <= en; x += 4) {
-                    const float v0 = vp[4 * x], v1 = vp[4 * x + 4], v2 = vp[4 * x + 8], v3 = vp[4 * x + 12];
+                    const v4f v0 = vp[x], v1 = vp[x + 1], v2 = vp[x + 2], v3 = vp[x + 3];
                     s += v0; s += v1; s += v2; s += v3;
                 }
-                for (; x < en; ++x) s += vp[4 * x];
-                dst[GCDM_S + r] = s;
+                for (; x < en; ++x) s += vp[x];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) dst[GCDM_S + 3 * (4 * cg + j) + comp] = s[j];      // AGG column S + 3c + comp (reference flatten layout)
             }
         }
     }
