@@ -875,9 +875,8 @@ __global__ __launch_bounds__(ET * 8) __attribute__((amdgpu_waves_per_eu(2, 2))) 
     float* VH = (float*)(smem + Geo::OFF_VH);
     float* PG = (float*)(smem + Geo::OFF_PG);
     float* FR = (float*)(smem + Geo::OFF_FR);
-    int* m_row = (int*)(smem + Geo::OFF_META);
-    int* m_whole = m_row + ET;                          // [segment] 1: whole row of its node (the fp32 kernel keeps the column indices here)
-    int* m_seg = m_whole + ET;
+    int2* m_rec = (int2*)(smem + Geo::OFF_META);        // [segment] {node, first edge | end << 8 | whole row << 16}: one LDS read per work item of the aggregation
+    int* m_seg = (int*)(m_rec + ET);                    // (the fp32 kernel's segment-start table; unused here)
     float* m_att = (float*)(m_seg + ET + 2);
     int* m_misc = (int*)(m_att + ET);
 
@@ -1061,22 +1060,17 @@ __global__ __launch_bounds__(ET * 8) __attribute__((amdgpu_waves_per_eu(2, 2))) 
 
     if (wave == 0) {
         const bool own = lane < ET;
-        if (own) m_row[e] = ni;
         const int prev = __shfl_up(ni, 1);
         const bool start = own && (e < nvalid) && (e == 0 || prev != ni);
         const unsigned long long mask = __ballot(start);
         const int sid = __popcll(mask & ((2ull << lane) - 1ull)) - 1;
         if (start) {
-            m_seg[sid] = e;
             const unsigned long long rest = lane < 63 ? mask >> (lane + 1) : 0ull;
             const int next = rest ? lane + 1 + __builtin_ctzll(rest) : nvalid;
-            m_whole[sid] = (next - e) == in.ncnt;          // the segment is the node's whole row (else: a partial for the cut-row fix-up)
+            // (whole: the segment is the node's whole row; else a partial for the cut-row fix-up)
+            m_rec[sid] = make_int2(ni, e | (next << 8) | (((next - e) == in.ncnt ? 1 : 0) << 16));
         }
-        if (lane == 0) {
-            const int ns = __popcll(mask);
-            m_seg[ns] = nvalid;
-            m_misc[0] = ns;
-        }
+        if (lane == 0) m_misc[0] = __popcll(mask);
     }
     // ---- P1: msg0 pre-phase ---------------------------------------------------------------------------------------------
 #ifndef GCDM_ABL_NOP1
@@ -1465,12 +1459,13 @@ __global__ __launch_bounds__(ET * 8) __attribute__((amdgpu_waves_per_eu(2, 2))) 
         constexpr int UNITS = GCDM_SG + 3 * (GCDM_V / 4);
         for (int wk = tid; wk < nseg * UNITS; wk += EK_THREADS) {
             const int sg = wk / UNITS, un = wk - sg * UNITS;
-            const int sb = m_seg[sg], en = m_seg[sg + 1];
-            const int node = m_row[sb];
-            const bool whole = m_whole[sg] != 0;
+            const int2 rec = m_rec[sg];
+            const int node = rec.x, sb = rec.y & 255, en = (rec.y >> 8) & 255;
+            const bool whole = (rec.y >> 16) != 0;
             float* dst = whole ? a.AGG + (size_t)node * GCDM_AGGW : a.PART + ((size_t)(e0 / ET) * 2 + (sb == 0 ? 0 : 1)) * GCDM_AGGW;
             if (un < GCDM_SG) {
-                // (4 edges per trip: the LDS reads of a trip are independent, the additions keep the edge order -- same bits as the plain loop)
+                // (4 edges per trip: the LDS reads of a trip are independent, the additions keep the edge order -- same bits as the plain loop;
+                //  8 per trip with a masked tail, i.e. 3 round trips instead of 7 for a 19-edge row, was measured: +-0, more instructions)
                 v4f s = {0.f, 0.f, 0.f, 0.f};
                 const v4f* xp = XS4 + un * ETP;
                 int x = sb;
