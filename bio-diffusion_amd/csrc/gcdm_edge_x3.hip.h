@@ -1391,11 +1391,11 @@ __global__ __launch_bounds__(ET * 8) __attribute__((amdgpu_waves_per_eu(2, 2))) 
 #endif
         if (k == 0) STAMP(14);
         // 4 waves: every wave is done reading the old images; gate partials complete.  8 waves: the barrier inside the fold said the first, and
-        // the partials are complete at the barrier behind the state images -- except in the last GCP2, whose vector part reads them before that
+        // the partials are complete at the barrier behind the state images (last GCP2: behind the attention partials)
 #ifndef GCDM_X3_CONST_BURST
         if (k == 2) load_const(std::integral_constant<int, 1>{}, a, me, start_ + min(it_ + stride_, cnt_ - 1), in);
 #endif
-        if (X3_FOLD_BARRIER || NW == 4 || k == 2) __syncthreads();
+        if (X3_FOLD_BARRIER || NW == 4) __syncthreads();
         if (k == 0) STAMP(15);
 #pragma unroll
         for (int m = 0; m < MT; ++m)
@@ -1410,15 +1410,61 @@ __global__ __launch_bounds__(ET * 8) __attribute__((amdgpu_waves_per_eu(2, 2))) 
 #ifndef GCDM_ABL_NOSTORE
             store_state_x3<MT, NT>(XH, XL, 0, st, ETP, mt0, lane, amax);
 #endif
-        } else {                          // last GCP2: fp32 image for attention + segment sums (aliases XH8 / XL8), and its vector part
-            store_state<MT, NT, false>(XS4, 0, st, ETP, mt0, lane, 0);
-            if (vhalf == 1) {
+        } else {
+            // last GCP2: scalar message attention (gcpnet.py:703-707) on the registers.  Each wave contracts its 32 channels of the final state
+            // with the attention weights (WAX4, staged once per workgroup; the two lane halves hold different channels of the same edge), the
+            // 8 partial logits of an edge meet in LDS (the frame buffer is dead by now), and behind ONE barrier -- which also completes the gate
+            // partials the vector part reads -- every wave forms the edge's sigmoid itself and scales its channels before they go out as the
+            // fp32 image the segment sums read: no pass over the image, no attention table, two barriers instead of four.
+            float* ATT_P = FR;                                   // [edge][NW] partial logits
+            float pd[NT];
+#pragma unroll
+            for (int n = 0; n < NT; ++n) pd[n] = 0.f;
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                v4f wq[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) wq[q] = WAX4[8 * (mt0 + m) + 2 * q + half];        // channels 32 (mt0 + m) + 8 q + 4 half + {0..3}
+#pragma unroll
+                for (int n = 0; n < NT; ++n)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) pd[n] += wq[r >> 2][r & 3] * st[m][n][r];
+            }
+#pragma unroll
+            for (int n = 0; n < NT; ++n) {
+                pd[n] += __shfl_xor(pd[n], 32);
+                if (half == 0) ATT_P[(32 * n + l31) * NW + wave] = pd[n];
+            }
+            __syncthreads();
+            if (vhalf == 1) {             // the vector part of the last GCP2 (no GEMM left to hide it in)
                 VecStage<ET, H0, false> vs;
                 vs.PG = PG; vs.bg = a.mk[2].bg; vs.FR = FR; vs.VH = VH; vs.VHB = VHB; vs.VV4 = VV4; vs.XH = XH; vs.XL = XL;
                 vs.fA = ax.vf1[2]; vs.fB = ax.vf2[2]; vs.pH = nullptr; vs.pL = nullptr;
                 vs.ve = ve; vs.vq = vq; vs.lane = lane;
                 vs.finish_only();
             }
+            float att[NT];
+#pragma unroll
+            for (int n = 0; n < NT; ++n) {
+                float lg = a.ba;
+#pragma unroll
+                for (int w4 = 0; w4 < NW / 4; ++w4) {
+                    const v4f pp = *(const v4f*)(ATT_P + (32 * n + l31) * NW + 4 * w4);
+                    lg += pp[0]; lg += pp[1]; lg += pp[2]; lg += pp[3];
+                }
+                att[n] = fast_sigmoid(lg);
+            }
+            static_for<0, GCH / 2>([&](auto gc) { load_gather_part(gc, a, me, ix, in); });          // next tile's VDI / VDJ words: first half
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int n = 0; n < NT; ++n)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) st[m][n][r] *= att[n];
+            static_for<GCH / 2, GCH>([&](auto gc) { load_gather_part(gc, a, me, ix, in); });
+            __builtin_amdgcn_sched_barrier(0);
+            store_state<MT, NT, false>(XS4, 0, st, ETP, mt0, lane, 0);
         }
         if (k == 0) STAMP(16);
         __syncthreads();
@@ -1428,28 +1474,8 @@ __global__ __launch_bounds__(ET * 8) __attribute__((amdgpu_waves_per_eu(2, 2))) 
     over |= amax > X3_RANGE;
     if (__any(over) && lane == 0) atomicOr(ax.flags_dev, GCDM_FLAG_F16_RANGE_BIT);
 
-    // ---- scalar message attention + aggregation: identical to the fp32 kernel (fp32 data) ---------------------------------
+    // ---- aggregation: segment sums of the attention-weighted messages (fp32 data) -------------------------------------------------------
 #ifndef GCDM_ABL_NOAGG
-    {
-        float s = 0.f;
-        static_for<0, GPP>([&](auto gc) {
-            constexpr int g = decltype(gc)::value;
-            const v4f wv = WAX4[part * GPP + g];                   // attention weights / c (the image holds c * m.s), staged in LDS once per workgroup
-            const v4f x = XS4[(part * GPP + g) * ETP + e];
-            s += wv[0] * x[0] + wv[1] * x[1] + wv[2] * x[2] + wv[3] * x[3];
-            load_gather_part(gc, a, me, ix, in);                   // next tile's node rows, one chunk per step
-            __builtin_amdgcn_sched_barrier(0);
-        });
-        PG[part * ETP + e] = s;
-        __syncthreads();
-        if (part == 0) {
-            float s2 = a.ba;
-#pragma unroll
-            for (int q = 0; q < PARTS; ++q) s2 += PG[q * ETP + e];
-            m_att[e] = fast_sigmoid(s2);
-        }
-        __syncthreads();
-    }
     STAMP(19);
     {
         const int nseg = m_misc[0];
@@ -1471,10 +1497,9 @@ __global__ __launch_bounds__(ET * 8) __attribute__((amdgpu_waves_per_eu(2, 2))) 
                 int x = sb;
                 for (; x + 4 <= en; x += 4) {
                     const v4f v0 = xp[x], v1 = xp[x + 1], v2 = xp[x + 2], v3 = xp[x + 3];
-                    const float a0 = m_att[x], a1 = m_att[x + 1], a2 = m_att[x + 2], a3 = m_att[x + 3];
-                    s += v0 * a0; s += v1 * a1; s += v2 * a2; s += v3 * a3;
+                    s += v0; s += v1; s += v2; s += v3;
                 }
-                for (; x < en; ++x) s += xp[x] * m_att[x];
+                for (; x < en; ++x) s += xp[x];
                 *(v4f*)(dst + 4 * un) = s * (1.0f / X3_C);           // back to true units
             } else {
                 const int r = un - GCDM_SG, comp = r / (GCDM_V / 4), cg = r - comp * (GCDM_V / 4);
