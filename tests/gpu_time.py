@@ -41,7 +41,7 @@ ph = net.debug_read("phase").view(-1, 8, 24)[:, :nw]
 lib.gcdm_profile_enable(h, 0)
 names = {1: "P1 msg0 pre", 2: "barrier", 3: "PQ add", 4: "GEMM0", 5: "silu", 6: "gate+PG", 7: "barrier", 8: "state store", 9: "barrier",
          12: "k1 GEMM(+vec)+mid barrier", 13: "k1 silu", 14: "k1 gate+PG", 15: "barrier", 16: "k1 state store", 17: "barrier",
-         18: "k2,k3 (all)", 19: "attention", 20: "aggregate"}
+         18: "k2,k3 (all) + attention + fp32 image", 19: "(barrier)", 20: "aggregate"}
 mean = ph.mean(dim=(0, 1))
 print("phase breakdown (shader cycles, mean over tiles x waves; cumulative -> delta); per-wave deltas in brackets:")
 prev, prevw = 0.0, torch.zeros(nw)
