@@ -368,14 +368,14 @@ class GCPDropout(nn.Module):
 
 
 class GCPEmbedding(nn.Module):
-    """gcpnet.py:494-603 (num_atom_types = 0 as GCPNetDynamics builds it: the atom types arrive as floats)."""
+    """gcpnet.py:494-603."""
 
     def __init__(self, edge_input_dims, node_input_dims, edge_hidden_dims, node_hidden_dims, num_atom_types: int = 0,
                  nonlinearities=("silu", "silu"), cfg=None, pre_norm: bool = True, use_gcp_norm: bool = True):
         super().__init__()
-        if num_atom_types > 0:
-            raise NotImplementedError("atom-type embedding tables are not used on the GCDM path (gcpnet.py:1011)")
-        self.atom_embedding = None
+        # integer atom types -> rows of a [num_atom_types, num_atom_types] table (gcpnet.py:540-549); GCPNetDynamics builds the embedding with
+        # num_atom_types = 0 (the atom types arrive as one-hot floats, gcpnet.py:1011)
+        self.atom_embedding = nn.Embedding(num_atom_types, num_atom_types) if num_atom_types > 0 else None
         self.pre_norm = bool(pre_norm)
         # parameter-free when use_gcp_norm is False (nn.Identity inside): the production state dict has no norm keys
         self.edge_normalization = GCPLayerNorm(edge_input_dims if pre_norm else edge_hidden_dims, use_gcp_norm=use_gcp_norm)
@@ -384,7 +384,8 @@ class GCPEmbedding(nn.Module):
         self.node_embedding = _embedding_gcp(cfg, node_input_dims, node_hidden_dims, (None, None))
 
     def forward(self, batch: Any):
-        node_rep = (batch.h, batch.chi)
+        h = ops.embedding(self.atom_embedding.weight, batch.h) if self.atom_embedding is not None else batch.h      # gcpnet.py:569-572
+        node_rep = (h, batch.chi)
         edge_rep = (batch.e, batch.xi)
         edge_rep = edge_rep[0] if not self.edge_embedding.vector_input_dim else edge_rep
         node_rep = node_rep[0] if not self.node_embedding.vector_input_dim else node_rep

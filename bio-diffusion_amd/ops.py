@@ -290,6 +290,34 @@ class _Gather(torch.autograd.Function):
         return dx.reshape(ctx.shape), None, None
 
 
+class _Embedding(torch.autograd.Function):
+    """rows of a table by integer index (nn.Embedding's forward; backward: fp32 atomic adds onto the table's gradient)."""
+
+    @staticmethod
+    def forward(ctx, weight, index):
+        w = _f(weight)
+        idx = index.reshape(-1).to(torch.int64).contiguous()
+        _dev(w)
+        if idx.numel() and (int(idx.min()) < 0 or int(idx.max()) >= w.shape[0]):
+            raise IndexError(f"embedding index out of range [0, {w.shape[0]})")
+        out = torch.empty((idx.numel(), w.shape[1]), dtype=torch.float32, device=w.device)
+        _chk(_lib().gcdm_op_gather(_p(w), _p(idx), _p(out), idx.numel(), w.shape[1], _st(w)), "gcdm_op_gather")
+        ctx.idx, ctx.rows = idx, w.shape[0]
+        return out.reshape(*index.shape, w.shape[1])
+
+    @staticmethod
+    def backward(ctx, dout):
+        g = _f(dout).reshape(ctx.idx.numel(), -1)
+        dw = torch.zeros((ctx.rows, g.shape[1]), dtype=torch.float32, device=g.device)
+        _chk(_lib().gcdm_op_scatter_add(_p(g), _p(ctx.idx), _p(dw), ctx.idx.numel(), g.shape[1], _st(g)), "gcdm_op_scatter_add")
+        return dw, None
+
+
+def embedding(weight: torch.Tensor, index: torch.Tensor) -> torch.Tensor:
+    """`nn.Embedding(num, dim)(index)` (gcpnet.py:540-549, 569-570: the atom-type table of `GCPEmbedding`)."""
+    return _Embedding.apply(weight, index)
+
+
 def gather_row(x: torch.Tensor, graph: Graph) -> torch.Tensor:
     return _Gather.apply(x, graph, True)
 

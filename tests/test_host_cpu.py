@@ -447,6 +447,16 @@ def test_variant_state_dict_layout_equals_the_reference(name, golden_dir):
     assert net.fused_unsupported is not None
 
 
+def test_embedding_with_an_atom_type_table_has_the_reference_layout(golden_dir):
+    """`GCPEmbedding(num_atom_types > 0)` registers the reference's keys and shapes in its order (fixture: the reference's own state dict)."""
+    g = np.load(os.path.join(golden_dir, "fn_atom_embedding.npz"))
+    want = {k[2:]: tuple(g[k].shape) for k in g.files if k.startswith("w_")}
+    T = want["atom_embedding.weight"][0]
+    mod = pkg.GCPEmbedding((1, 1), (T, 2), (8, 4), (16, 4), num_atom_types=T, cfg=pkg.default_cfgs("qm9")["module_cfg"], pre_norm=False, use_gcp_norm=True)
+    got = {k: tuple(v.shape) for k, v in mod.state_dict().items()}
+    assert got == want and list(got) == list(want)
+
+
 @pytest.mark.needs_reference
 @pytest.mark.parametrize("name", ["gcp1_frame_gate", "three_ff", "gcp_norm"])
 def test_variant_state_dict_matches_imported_reference(name):

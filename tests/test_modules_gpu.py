@@ -156,6 +156,35 @@ def test_module_path_gradients_match_oracle_autograd():
     print(f"worst relative gradient error over {len(Wg)} tensors: {worst:.2e}")
 
 
+def test_atom_type_table_of_the_embedding_matches_reference_golden(golden_dir):
+    """`GCPEmbedding(num_atom_types > 0)` (gcpnet.py:509-512, 569-572): integer atom types through an nn.Embedding table, then the embedding GCPs and the
+    GCP layer norms -- outputs and the gradient of a fixed scalar w.r.t. the table against the reference's own (fixture from the imported reference)."""
+    g = np.load(os.path.join(golden_dir, "fn_atom_embedding.npz"))
+    T = int(g["w_atom_embedding.weight"].shape[0])
+    cfg = pkg.default_cfgs("qm9")["module_cfg"]
+    mod = pkg.GCPEmbedding((1, 1), (T, 2), (8, 4), (16, 4), num_atom_types=T, cfg=cfg, pre_norm=False, use_gcp_norm=True)
+    sd = {k[2:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("w_")}
+    assert set(sd) == set(mod.state_dict()), (sorted(set(sd) ^ set(mod.state_dict())))
+    mod.load_state_dict(sd)
+    mod = mod.to(DEV).train()
+
+    class B:
+        pass
+    b = B()
+    b.h = torch.from_numpy(g["types"]).to(DEV)
+    b.chi, b.e, b.xi, b.f_ij = (torch.from_numpy(g[k]).to(DEV) for k in ("chi", "e", "xi", "frames"))
+    b.edge_index = torch.from_numpy(g["edge_index"]).to(DEV)
+    (ns, nv), (es, ev) = mod(b)
+    for got, key in ((ns, "node_s"), (nv, "node_v"), (es, "edge_s"), (ev, "edge_v")):
+        want = torch.from_numpy(g[key])
+        assert (got.detach().cpu() - want).abs().max().item() <= 1e-5 * max(1.0, want.abs().max().item()), key
+    (ns * torch.from_numpy(g["r"]).to(DEV)).sum().backward()
+    want = torch.from_numpy(g["grad_table"])
+    assert (mod.atom_embedding.weight.grad.cpu() - want).abs().max().item() <= 1e-5 * max(1.0, want.abs().max().item())
+    with pytest.raises(IndexError):
+        pkg.ops.embedding(mod.atom_embedding.weight, torch.tensor([T], device=DEV))
+
+
 def test_operators_refuse_cpu_tensors():
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         pkg.ops.linear(torch.zeros(2, 3), torch.zeros(4, 3))
