@@ -121,6 +121,7 @@ class GCPNetDynamics(nn.Module):
             (int(cfg_get(layer_cfg, "num_feedforward_layers", 1)) == 1, "num_feedforward_layers != 1"),
             (not cfg_get(layer_cfg, "use_gcp_norm", False), "use_gcp_norm"),
             (self.node_dims == (256, 32) and self.edge_dims in ((64, 16), (16, 8)), f"hidden sizes {self.node_dims} / {self.edge_dims}"),
+            (self.num_atom_types + int(self.include_charges) > 0, "no node features (position-only diffusion, generate_x_only)"),
         ]
         for ok, why in checks:
             if not ok:

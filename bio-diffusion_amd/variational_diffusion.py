@@ -496,8 +496,6 @@ class EquivariantVariationalDiffusion(nn.Module):
         network evaluation at t = 0 plus O(N) torch algebra; extension: ``noise`` = the raw standard-normal draw [N, 3 + F].  Before the
         samples are returned the deferred range guard of this evaluation AND of the sample_p_zs_given_zt calls in front of it is checked
         (one host sync); F16RangeError means the trajectory has to be re-run (the handle has been switched to fp32 MFMA)."""
-        if generate_x_only:
-            raise NotImplementedError("generate_x_only needs a network built for positions only; the reference's drivers never set it")
         t_zeros = torch.zeros(size=(batch_size, 1), device=batch_index.device)
         gamma_0 = self.gamma(t_zeros)
         sigma_x = self.SNR(-0.5 * gamma_0)
@@ -508,8 +506,12 @@ class EquivariantVariationalDiffusion(nn.Module):
         if noise is not None:
             m = node_mask.float().unsqueeze(-1)
             noise = torch.cat([_segment_mean_sub(noise[:, : self.num_x_dims] * m, batch_index, batch_size, node_mask), noise[:, self.num_x_dims:] * m], dim=-1)
-        xh = self.sample_normal(mu=mu_x, sigma=sigma_x, batch_index=batch_index, node_mask=node_mask, fix_noise=fix_noise, eps=noise)
+        xh = self.sample_normal(mu=mu_x, sigma=sigma_x, batch_index=batch_index, node_mask=node_mask, fix_noise=fix_noise, generate_x_only=generate_x_only, eps=noise)
         x = xh[:, : self.num_x_dims]
+        if generate_x_only:              # positions only (:894-897): no node features to decode
+            x, _, _ = self.unnormalize(x, node_mask, generate_x_only=True)
+            self._final_range_check()
+            return x, {}
         h_cat = xh[:, self.num_x_dims:-1] if self.include_charges else xh[:, self.num_x_dims:]
         h_int = xh[:, -1:] if self.include_charges else torch.zeros(0, device=x.device)
         x, h_cat, h_int = self.unnormalize(x, node_mask, h_cat=h_cat, h_int=h_int)
@@ -545,7 +547,7 @@ class EquivariantVariationalDiffusion(nn.Module):
         return dyn, lib, h
 
     def _mol_gen_sample_modules(self, num_samples, num_nodes, device, return_frames, num_timesteps, node_mask, context, fix_noise,
-                                fix_self_conditioning_noise, norm_with_original_timesteps, noise_fn, step_callback):
+                                fix_self_conditioning_noise, norm_with_original_timesteps, noise_fn, step_callback, generate_x_only: bool = False):
         """mol_gen_sample (:1282-1412) step by step through the reference-signature methods of this class -- torch algebra on the device around
         one network evaluation per step on whichever HIP path the configuration / mask selects.  Serves masked nodes inside the loop and the
         configurations the fused sampling kernels are not built for; ~10x slower per step than the fused loop.  ``noise_fn(k)``: raw draw k."""
@@ -569,7 +571,7 @@ class EquivariantVariationalDiffusion(nn.Module):
         m = node_mask.float().unsqueeze(-1)
         raw = draw()
         if raw is None:
-            z = self.sample_combined_position_feature_noise(torch.zeros_like(bi) if fix_noise else bi, node_mask)
+            z = self.sample_combined_position_feature_noise(torch.zeros_like(bi) if fix_noise else bi, node_mask, generate_x_only=generate_x_only)
         else:
             z = torch.cat((_segment_mean_sub(raw[:, : self.num_x_dims] * m, bi, num_samples, node_mask), raw[:, self.num_x_dims:] * m), dim=-1)
         self_cond_on = bool(cfg_get(self.diffusion_cfg, "self_condition", False))
@@ -579,27 +581,30 @@ class EquivariantVariationalDiffusion(nn.Module):
             s_arr = torch.full((num_samples, 1), s / t_norm, device=device)
             t_arr = torch.full((num_samples, 1), (s + 1) / t_norm, device=device)
             z = self.sample_p_zs_given_zt(s=s_arr, t=t_arr, z=z, batch_index=bi, node_mask=node_mask, context=context, fix_noise=fix_noise,
-                                          xh_self_cond=self_cond, noise=draw())
+                                          generate_x_only=generate_x_only, xh_self_cond=self_cond, noise=draw())
             if step_callback is not None:
                 step_callback(s, z)
             if (s * return_frames) % num_timesteps == 0:
-                out[(s * return_frames) // num_timesteps] = self.unnormalize_z(z, node_mask)
+                out[(s * return_frames) // num_timesteps] = self.unnormalize_z(z, node_mask, generate_x_only=generate_x_only)
             if self_cond_on:
                 self_cond = self.sample_p_zs_given_zt(s=torch.zeros_like(s_arr), t=s_arr, z=z, batch_index=bi, node_mask=node_mask, context=context,
                                                       fix_noise=fix_self_conditioning_noise, self_condition=True, noise=draw())
         x, h = self.sample_p_xh_given_z0(z_0=z, batch_index=bi, node_mask=node_mask, batch_size=num_samples, context=context,
-                                         fix_noise=fix_self_conditioning_noise if self_cond_on else fix_noise, xh_self_cond=self_cond, noise=draw())
+                                         fix_noise=fix_self_conditioning_noise if self_cond_on else fix_noise, generate_x_only=generate_x_only,
+                                         xh_self_cond=self_cond, noise=draw())
         if return_frames == 1:
             cog = torch.zeros(num_samples, self.num_x_dims, device=device).index_add_(0, bi, x).abs().max().item()
             if cog > 5e-2:
                 x = _segment_mean_sub(x, bi, num_samples, node_mask)
-        out[0] = torch.cat([x, h["categorical"].to(x.dtype)] + ([h["integer"].to(x.dtype)] if self.include_charges else []), dim=-1)
+        out[0] = x if generate_x_only else torch.cat([x, h["categorical"].to(x.dtype)] + ([h["integer"].to(x.dtype)] if self.include_charges else []), dim=-1)
         self.last_flags = 0
         return out.squeeze(0), bi, node_mask
 
-    def unnormalize_z(self, z, node_mask):
+    def unnormalize_z(self, z, node_mask, generate_x_only: bool = False):
         """(:761-793)"""
         nx, nt = self.num_x_dims, self.num_atom_types
+        if generate_x_only:
+            return self.unnormalize(z[:, :nx], node_mask, generate_x_only=True)[0]
         x, h_cat, h_int = self.unnormalize(z[:, :nx], node_mask, h_cat=z[:, nx:nx + nt], h_int=z[:, nx + nt:])
         return torch.cat([x, h_cat] + ([h_int] if self.include_charges else []), dim=-1)
 
@@ -616,9 +621,14 @@ class EquivariantVariationalDiffusion(nn.Module):
         (k = 0 for z_T, then one per step, then one for the final decode: the reference's randn call order,
         SURVEY A.5); without it noise comes from on-device Philox(seed)."""
         if generate_x_only:
-            # (the flag is threaded through the reference's sampler for position-only diffusion targets; its only dynamics network,
-            #  GCPNetDynamics, needs the node features and has no such target: gcpnet.py:997-1002)
-            raise NotImplementedError("generate_x_only: the atom_types_and_coords dynamics network always denoises positions AND node features")
+            # position-only diffusion (:1292, 1325-1327, 1349, 1385, 1407-1408): z = z_x, every draw is the centred x-noise alone, the result is the
+            # [N, 3] positions.  It needs a dynamics network built WITHOUT node features (dataloader_cfg.num_atom_types = 0, include_charges = False:
+            # xh is [N, 3] then, as in the reference) -- the general loop on the module path.
+            if getattr(self.dynamics_network, "num_atom_types", 0) + int(getattr(self.dynamics_network, "include_charges", False)) > 0:
+                raise ValueError("generate_x_only needs a dynamics network built without node features (num_atom_types = 0, include_charges = False); "
+                                 "the reference fails on the feature width of this one too (gcpnet.py:1093-1110)")
+            return self._mol_gen_sample_modules(num_samples, num_nodes, device, return_frames, num_timesteps, node_mask, context, fix_noise,
+                                                fix_self_conditioning_noise, norm_with_original_timesteps, noise_fn, step_callback, generate_x_only=True)
         masked = node_mask is not None and not bool(node_mask.all())
         if masked or getattr(self.dynamics_network, "fused_unsupported", None) is not None or getattr(self.dynamics_network, "path", "auto") == "modules":
             # general loop: masked nodes inside the loop, or a configuration the fused sampling kernels are not built for

@@ -447,6 +447,26 @@ def test_variant_state_dict_layout_equals_the_reference(name, golden_dir):
     assert net.fused_unsupported is not None
 
 
+def test_position_only_network_has_the_reference_layout_and_feature_networks_refuse_x_only(golden_dir):
+    """A dynamics network built without node features (num_atom_types = 0, include_charges = False: what `generate_x_only` needs) registers the
+    reference's keys and shapes (fixture: sampler_xonly_qm9.npz) and runs on the module path; a network WITH features refuses the [N, 3] latent."""
+    g = np.load(os.path.join(golden_dir, "sampler_xonly_qm9.npz"))
+    cfgs = pkg.default_cfgs("qm9")
+    synth.apply_variant(cfgs, None)
+    cfgs["dataloader_cfg"]["num_atom_types"] = 0
+    cfgs["dataloader_cfg"]["include_charges"] = False
+    net = pkg.GCPNetDynamics(**cfgs)
+    want = {k: tuple(int(x) for x in sh.split(",")) if sh else () for k, sh in zip(g["keys"].tolist(), g["shapes"].tolist())}
+    got = {k: tuple(v.shape) for k, v in net.state_dict().items()}
+    assert got == want and list(got) == list(want)
+    full = pkg.default_cfgs("qm9")
+    net_full = pkg.GCPNetDynamics(**full)
+    assert "no node features" in pkg.GCPNetDynamics(**{**full, "dataloader_cfg": {**full["dataloader_cfg"], "num_atom_types": 0, "include_charges": False}}).fused_unsupported
+    ddpm = pkg.EquivariantVariationalDiffusion(net_full, full["diffusion_cfg"], full["dataloader_cfg"], pkg.dataset_info("qm9"))
+    with pytest.raises(ValueError, match="without node features"):
+        ddpm.mol_gen_sample(num_samples=2, num_nodes=torch.tensor([3, 4]), device="cpu", num_timesteps=2, generate_x_only=True)
+
+
 def test_embedding_with_an_atom_type_table_has_the_reference_layout(golden_dir):
     """`GCPEmbedding(num_atom_types > 0)` registers the reference's keys and shapes in its order (fixture: the reference's own state dict)."""
     g = np.load(os.path.join(golden_dir, "fn_atom_embedding.npz"))

@@ -323,6 +323,49 @@ def test_sampling_with_masked_nodes_matches_reference_golden(width, golden_dir):
     assert torch.equal(out[:, 3:].double()[agree], f32[:, 3:][agree]) and bool((out[~mask] == 0).all())
 
 
+def _xonly_cfgs():
+    cfgs = pkg.default_cfgs("qm9")
+    synth.apply_variant(cfgs, None)
+    cfgs["dataloader_cfg"]["num_atom_types"] = 0
+    cfgs["dataloader_cfg"]["include_charges"] = False
+    return cfgs
+
+
+def test_position_only_sampling_matches_reference_golden(golden_dir):
+    """`mol_gen_sample(..., generate_x_only=True)` -- z = z_x, centred x-noise only, [N, 3] positions out (variational_diffusion.py:795-836, 840-907,
+    1282-1412) -- around a dynamics network built without node features, against the reference's own 12-step run on the same noise tape
+    (make_xonly_golden.py): z after every step within 4 |ref32 - ref64| + 1e-4 max|z|, the final positions likewise."""
+    g = np.load(os.path.join(golden_dir, "sampler_xonly_qm9.npz"))
+    cfgs = _xonly_cfgs()
+    net = pkg.GCPNetDynamics(**cfgs)
+    assert net.fused_unsupported is not None
+    want = {k: tuple(int(x) for x in sh.split(",")) if sh else () for k, sh in zip(g["keys"].tolist(), g["shapes"].tolist())}
+    shapes = {k: tuple(v.shape) for k, v in net.state_dict().items()}
+    assert shapes == want and list(shapes) == list(want)
+    net.load_state_dict(synth.make_weights(shapes, seed=int(g["weight_seed"]), scale_2d=float(g["weight_scale"])))
+    net = net.to(DEV)
+    ddpm = pkg.EquivariantVariationalDiffusion(net, cfgs["diffusion_cfg"], cfgs["dataloader_cfg"], pkg.dataset_info("qm9")).to(DEV).eval()
+    nn_, steps = torch.tensor(g["num_nodes"]), int(g["steps"])
+    N = int(nn_.sum())
+    tape = O.TapeNoise(int(g["noise_seed"]))
+    draws = [tape(N, 3).to(DEV) for _ in range(steps + 2)]
+    zs = []
+    out, bi, _ = ddpm.mol_gen_sample(num_samples=len(nn_), num_nodes=nn_, device=DEV, num_timesteps=steps, generate_x_only=True,
+                                     noise_fn=lambda k: draws[k], step_callback=lambda s, z: zs.append(z.detach().cpu().clone()))
+    z32, z64 = torch.tensor(g["z32"]).double(), torch.tensor(g["z64"])
+    assert len(zs) == steps and tuple(out.shape) == (N, 3)
+    for i in range(steps):
+        bound = 4.0 * (z32[i] - z64[i]).abs().max().item() + 1e-4 * z64[i].abs().max().item()
+        assert (zs[i].double() - z32[i]).abs().max().item() <= bound, i
+    f32, f64 = torch.tensor(g["final32"]).double(), torch.tensor(g["final64"])
+    assert (out.cpu().double() - f32).abs().max().item() <= 4.0 * (f32 - f64).abs().max().item() + 1e-4 * f64.abs().max().item()
+    # a network WITH node features cannot take the [N, 3] latent (neither can the reference's)
+    full = pkg.default_cfgs("qm9")
+    ddpm_full = pkg.EquivariantVariationalDiffusion(pkg.GCPNetDynamics(**full).to(DEV), full["diffusion_cfg"], full["dataloader_cfg"], pkg.dataset_info("qm9")).to(DEV).eval()
+    with pytest.raises(ValueError, match="without node features"):
+        ddpm_full.mol_gen_sample(num_samples=2, num_nodes=torch.tensor([3, 4]), device=DEV, num_timesteps=2, generate_x_only=True)
+
+
 def test_module_path_sampling_loop_matches_oracle():
     """The general sampling loop (reference-signature sample_p_zs_given_zt / sample_p_xh_given_z0 of this package, network on the module
     path) against the oracle's mol_gen_sample on the same tape: production configuration forced onto the module path, 10 steps."""
