@@ -599,7 +599,8 @@ def main():
         res["modes"]["measured_on"] = "whole batch on one handle, 8 steps wall clock after 3 settling steps; the headline ms_per_step runs the default mode as config.slices_of_the_batch slices"
         res["plug_point_1"] = {"ms_per_step": plug1_ms, "value": None if plug1_ms is None else world * B / (plug1_ms * 1e-3 * NET_EVALS_PER_SAMPLE), "unit": "molecules/s",
                                "what": "reference-signature sample_p_zs_given_zt per step (torch algebra + GCPNetDynamics.forward on one handle, no per-call host sync): "
-                                       "the cost of the reference's unchanged sampling loop after the dynamics_networks registry swap"}
+                                       "the cost of the reference's sampling loop after the dynamics_networks registry swap, less the one host sync per step "
+                                       "its torch_scatter noise centring makes (batch_index.max(): ~0.6 ms of GPU idle per step at this size)"}
         res["nll_evaluation"] = {"ms_per_batch": nll_ms, "value": None if nll_ms is None else B / (nll_ms * 1e-3), "unit": "molecules/s",
                                  "what": "likelihood terms of one validation / test batch of the headline shape (EquivariantVariationalDiffusion.forward, evaluation mode: "
                                          "two network evaluations on one handle + the O(N) algebra of the terms in torch, incl. the host-side size-prior lookup)"}
