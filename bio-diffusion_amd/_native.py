@@ -97,6 +97,7 @@ OPS_SIGNATURES = {
     "gcdm_op_gemm": [P, I64, I64, P, I64, I64, P, P, I64, I32, I64, I32, P],
     "gcdm_op_reduce_slices": [P, P, I64, I32, P],
     "gcdm_op_colsum": [P, P, I64, I32, P],
+    "gcdm_op_colsum_slices": [P, P, I64, I32, I32, P],
     "gcdm_op_act": [I32, P, P, I64, P],
     "gcdm_op_act_bwd": [I32, P, P, P, I64, P],
     "gcdm_op_norm3": [P, P, I64, I32, I32, P],

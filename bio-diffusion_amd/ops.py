@@ -93,7 +93,13 @@ class _Linear(torch.autograd.Function):
             dw = _gemm(g, 1, N, xs, K, 1, N, K, M, split=True)                            # dW = dy^T x  (A(n, m) = dy[m][n])
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = torch.empty(N, dtype=torch.float32, device=g.device)
-            _chk(_lib().gcdm_op_colsum(_p(g), _p(db), M, N, _st(g)), "gcdm_op_colsum")
+            if M >= 4096:                # many rows: partial sums over row slices on the whole chip, then a fixed-order reduction
+                slices = int(min(256, (M + 511) // 512))
+                part = torch.empty((slices, N), dtype=torch.float32, device=g.device)
+                _chk(_lib().gcdm_op_colsum_slices(_p(g), _p(part), M, N, slices, _st(g)), "gcdm_op_colsum_slices")
+                _chk(_lib().gcdm_op_reduce_slices(_p(part), _p(db), N, slices, _st(g)), "gcdm_op_reduce_slices")
+            else:
+                _chk(_lib().gcdm_op_colsum(_p(g), _p(db), M, N, _st(g)), "gcdm_op_colsum")
         return dx, dw, db
 
 

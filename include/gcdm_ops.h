@@ -35,6 +35,8 @@ int gcdm_op_gemm(const float* A, int64_t sam, int64_t sak, const float* B, int64
                  int64_t K, int32_t slices, void* stream);
 int gcdm_op_reduce_slices(const float* part, float* out, int64_t n, int32_t slices, void* stream);
 int gcdm_op_colsum(const float* dy, float* db, int64_t M, int32_t N, void* stream);
+/* partial column sums over `slices` contiguous row ranges, part [slices][N] (then gcdm_op_reduce_slices(part, db, N, slices)): the bias gradient when M = #edges */
+int gcdm_op_colsum_slices(const float* dy, float* part, int64_t M, int32_t N, int32_t slices, void* stream);
 
 /* kind: 0 identity, 1 silu, 2 relu, 3 sigmoid, 4 leakyrelu(0.01), 5 selu */
 int gcdm_op_act(int32_t kind, const float* x, float* y, int64_t n, void* stream);
