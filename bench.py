@@ -137,12 +137,15 @@ def strip_cxx_comments(text):
 
 
 def csrc_sha16(directory=None):
-    """Fingerprint of the device/host sources the library is built from (comments and blank lines excluded: they do not change the
-    kernels): a PMC summary collected on other sources is stale."""
+    """Fingerprint of the device/host sources libgcdm_hip.so -- the library whose kernels the PMC passes count -- is built from (comments and
+    blank lines excluded: they do not change the kernels): a PMC summary collected on other sources is stale.  The module-path operator
+    library (gcdm_ops.hip / gcdm_ops.hip.h -> libgcdm_ops.so) is a separate build and not part of it."""
     import hashlib
     hsh = hashlib.sha256()
     d = directory or os.path.join(ROOT, "bio-diffusion_amd", "csrc")
     for f in sorted(os.listdir(d)):
+        if f.startswith("gcdm_ops."):
+            continue
         with open(os.path.join(d, f), "r", encoding="utf-8", errors="replace") as fh:
             hsh.update(f.encode() + b"\0" + strip_cxx_comments(fh.read()).encode())
     return hsh.hexdigest()[:16]

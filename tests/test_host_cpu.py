@@ -552,6 +552,29 @@ def test_source_fingerprint_ignores_comments_only():
     assert len(bench.csrc_sha16()) == 16
 
 
+def test_committed_pmc_summaries_belong_to_the_kernels_in_the_tree():
+    """The PMC summaries bench.py takes `roofline.traffic` / `mfma_busy_frac_pmc` from carry the fingerprint of the libgcdm_hip.so sources they
+    were collected on; a kernel change without a new measurement round would make the bench line report nulls (`pmc_stale`).  The operator
+    library (gcdm_ops.*) is a separate build and outside the fingerprint."""
+    import bench
+    for workload in ("qm9", "geom"):
+        pmc = bench.load_pmc_summary(workload, True)
+        assert pmc and pmc["stale"] is False and pmc["hbm_bytes_per_launch"] and pmc["mfma_busy_frac"], workload
+    import tempfile, shutil
+    src = os.path.join(ROOT, "bio-diffusion_amd", "csrc")
+    with tempfile.TemporaryDirectory() as tmp:
+        for f in os.listdir(src):
+            shutil.copy(os.path.join(src, f), tmp)
+        base = bench.csrc_sha16(tmp)
+        assert base == bench.csrc_sha16()
+        with open(os.path.join(tmp, "gcdm_ops.hip.h"), "a") as f:
+            f.write("\nint not_a_kernel_of_the_hip_library;\n")
+        assert bench.csrc_sha16(tmp) == base
+        with open(os.path.join(tmp, "gcdm_edge_x3.hip.h"), "a") as f:
+            f.write("\nint a_change;\n")
+        assert bench.csrc_sha16(tmp) != base
+
+
 def test_no_mfma_directly_behind_a_partial_write_of_its_source():
     """Static check of the compiled gfx950 kernels (no GPU): an MFMA issued with no wait state behind a v_fma_mix{lo,hi}_f16 write of one
     of its source registers reads the old register on gfx950 (tools/mfma_partial_write_hazard.hip); the compiler is expected to separate the
