@@ -26,11 +26,14 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 // C + z * M * N (reduced in fixed order by k_reduce_slices: deterministic).
 constexpr int GM = 64, GN = 64, GK = 16;
 
+// Round 3: the per-thread element addresses are set up once (pointer += stride per K step instead of two 64-bit multiplies per element and
+// step), the next K step's 8 elements are requested into registers before the current step's MFMAs and stored into the OTHER half of a
+// double-buffered LDS tile behind them -- one barrier per step, global latency under the MFMAs.
 __global__ __launch_bounds__(256) void k_gemm(const float* __restrict__ A, int64_t sam, int64_t sak, const float* __restrict__ B, int64_t sbk,
                                               int64_t sbn, float* __restrict__ C, const float* __restrict__ bias, int64_t M, int N, int64_t K,
                                               int64_t kslice) {
-    __shared__ float As[GK][GM + 1];
-    __shared__ float Bs[GK][GN + 1];
+    __shared__ float As[2][GK][GM + 1];
+    __shared__ float Bs[2][GK][GN + 1];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave & 1, wn = wave >> 1;
     const int64_t m0 = (int64_t)blockIdx.x * GM;
@@ -38,26 +41,50 @@ __global__ __launch_bounds__(256) void k_gemm(const float* __restrict__ A, int64
     const int64_t k_begin = (int64_t)blockIdx.z * kslice, k_end = k_begin + kslice < K ? k_begin + kslice : K;
     f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     const bool a_kfast = sak == 1, b_nfast = sbn == 1;
-    for (int64_t k0 = k_begin; k0 < k_end; k0 += GK) {
+    // this thread's 4 + 4 elements of a K step: tile coordinates, running global pointers, row / column validity
+    int am[4], ak[4], bn[4], bk[4];
+    const float* pa[4];
+    const float* pb[4];
+    bool va[4], vb[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int idx = tid + 256 * i;
+        am[i] = a_kfast ? idx / GK : idx % GM; ak[i] = a_kfast ? idx % GK : idx / GM;
+        bn[i] = b_nfast ? idx % GN : idx / GK; bk[i] = b_nfast ? idx / GN : idx % GK;
+        va[i] = m0 + am[i] < M; vb[i] = n0 + bn[i] < N;
+        pa[i] = A + (va[i] ? (m0 + am[i]) * sam : 0) + (k_begin + ak[i]) * sak;
+        pb[i] = B + (k_begin + bk[i]) * sbk + (vb[i] ? (int64_t)(n0 + bn[i]) * sbn : 0);
+    }
+    const int64_t da = GK * sak, db_ = GK * sbk;
+    float ra[4], rb[4];
+    auto fetch = [&](int64_t k0) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int idx = tid + 256 * i;
-            const int am = a_kfast ? idx / GK : idx % GM, ak = a_kfast ? idx % GK : idx / GM;
-            const int64_t gm = m0 + am, gk = k0 + ak;
-            As[ak][am] = (gm < M && gk < k_end) ? A[gm * sam + gk * sak] : 0.f;
-            const int bn = b_nfast ? idx % GN : idx / GK, bk = b_nfast ? idx / GN : idx % GK;
-            const int64_t gk2 = k0 + bk;
-            const int gn = n0 + bn;
-            Bs[bk][bn] = (gn < N && gk2 < k_end) ? B[gk2 * sbk + (int64_t)gn * sbn] : 0.f;
+            ra[i] = (va[i] && k0 + ak[i] < k_end) ? *pa[i] : 0.f;
+            rb[i] = (vb[i] && k0 + bk[i] < k_end) ? *pb[i] : 0.f;
+            pa[i] += da; pb[i] += db_;
         }
-        __syncthreads();
+    };
+    auto stash = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { As[buf][ak[i]][am[i]] = ra[i]; Bs[buf][bk[i]][bn[i]] = rb[i]; }
+    };
+    fetch(k_begin);
+    stash(0);
+    __syncthreads();
+    int buf = 0;
+    for (int64_t k0 = k_begin; k0 < k_end; k0 += GK) {
+        const bool more = k0 + GK < k_end;
+        if (more) fetch(k0 + GK);                     // in flight during the MFMAs below
 #pragma unroll
         for (int kk = 0; kk < GK; kk += 2) {
-            const float a = As[kk + (lane >> 5)][wm * 32 + (lane & 31)];
-            const float b = Bs[kk + (lane >> 5)][wn * 32 + (lane & 31)];
+            const float a = As[buf][kk + (lane >> 5)][wm * 32 + (lane & 31)];
+            const float b = Bs[buf][kk + (lane >> 5)][wn * 32 + (lane & 31)];
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
         }
+        if (more) stash(buf ^ 1);                     // the other half: nobody reads it before the barrier
         __syncthreads();
+        buf ^= 1;
     }
     float* Cz = C + (int64_t)blockIdx.z * M * N;
     const int col = n0 + wn * 32 + (lane & 31);
