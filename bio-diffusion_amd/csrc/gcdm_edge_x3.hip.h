@@ -899,9 +899,9 @@ __global__ __launch_bounds__(ET * 8) __attribute__((amdgpu_waves_per_eu(2, 2))) 
         w.e = (ET == 64) ? w.lane : (tid_ & (ET - 1));
         w.part = (ET == 64) ? w.wave : (tid_ / ET);
         w.mt0 = (8 / (ET / 8)) * w.wave;
-        // the frame rows of an edge are needed by the thread that stages them in LDS (part 0) and by the threads whose rows of the pre-phase are
+        // the frame rows of an edge are needed by the thread that stages them in LDS (the last part) and by the threads whose rows of the pre-phase are
         // the three frame vectors (H0 <= part + PARTS i < H0 + 3): 4 of the 8 threads per edge; the others skip the nine loads
-        w.need_fr = w.part == 0;
+        w.need_fr = w.part == PARTS - 1;
 #pragma unroll
         for (int i = 0; i < (H0 + 3 + PARTS - 1) / PARTS; ++i) w.need_fr |= (w.part + PARTS * i >= H0) && (w.part + PARTS * i < H0 + 3);
         return w;
@@ -982,9 +982,9 @@ __global__ __launch_bounds__(ET * 8) __attribute__((amdgpu_waves_per_eu(2, 2))) 
             for (int c = 0; c < VE; ++c) in.al[c] = ws.ld1(ve4, o + c * rowE);
         }
         if constexpr ((P < 0 || P == 1) && BETA_MFMA) {
-            if (w.wave < ET / 32) {
+            if (w.wave >= ET / 8 - ET / 32) {         // the LAST waves contract beta: they are the first to leave the previous tile's segment sums
                 // (the half of K this lane holds rides in the per-lane offset: a lane-dependent scalar offset would cost a waterfall loop per load)
-                const uint32_t eg4 = (uint32_t)min(e0 + 32 * w.wave + (w.lane & 31), E - 1) * 4u + (uint32_t)(8 * (w.lane >> 5)) * rowE, o = ws.off(a.AL);
+                const uint32_t eg4 = (uint32_t)min(e0 + 32 * (w.wave - (ET / 8 - ET / 32)) + (w.lane & 31), E - 1) * 4u + (uint32_t)(8 * (w.lane >> 5)) * rowE, o = ws.off(a.AL);
 #pragma unroll
                 for (int j = 0; j < 8; ++j) in.av[j] = ws.ld1(eg4, o + (uint32_t)j * rowE);
             }
@@ -1058,20 +1058,6 @@ __global__ __launch_bounds__(ET * 8) __attribute__((amdgpu_waves_per_eu(2, 2))) 
     x3_prefetch_b<MT, PD>(ring, wp, o0H, o0L, KB0C);   // flies during P1
     const float u0 = in.u0, u1 = in.u1, u2 = in.u2;
 
-    if (wave == 0) {
-        const bool own = lane < ET;
-        const int prev = __shfl_up(ni, 1);
-        const bool start = own && (e < nvalid) && (e == 0 || prev != ni);
-        const unsigned long long mask = __ballot(start);
-        const int sid = __popcll(mask & ((2ull << lane) - 1ull)) - 1;
-        if (start) {
-            const unsigned long long rest = lane < 63 ? mask >> (lane + 1) : 0ull;
-            const int next = rest ? lane + 1 + __builtin_ctzll(rest) : nvalid;
-            // (whole: the segment is the node's whole row; else a partial for the cut-row fix-up)
-            m_rec[sid] = make_int2(ni, e | (next << 8) | (((next - e) == in.ncnt ? 1 : 0) << 16));
-        }
-        if (lane == 0) m_misc[0] = __popcll(mask);
-    }
     // ---- P1: msg0 pre-phase ---------------------------------------------------------------------------------------------
 #ifndef GCDM_ABL_NOP1
     {
@@ -1083,9 +1069,9 @@ __global__ __launch_bounds__(ET * 8) __attribute__((amdgpu_waves_per_eu(2, 2))) 
         // vectors (gcpnet.py:442-459) -- is a [23 x 16] . [16 x ET] contraction: ONE wave per 32 edges evaluates it on the matrix pipe (3 MFMAs,
         // 8 alpha loads per lane) and hands it over in LDS, instead of 16 alpha loads + 48 weight loads + 48 FMAs in each of the 8 threads
         // of an edge.  BETA aliases the gate-partial buffer PG, which is first written after the msg0 GEMM.
-        if (wave < ET / 32) {
-            const int n_ = lane & 31, kh_ = lane >> 5;
-            const uint32_t eg4 = (uint32_t)min(e0 + 32 * wave + n_, E - 1) * 4u;
+        if (wave >= NW - ET / 32) {
+            const int n_ = lane & 31, kh_ = lane >> 5, wb_ = wave - (NW - ET / 32);
+            const uint32_t eg4 = (uint32_t)min(e0 + 32 * wb_ + n_, E - 1) * 4u;
             const h8 aH = wp.ld(wp.off(ax.wbeH)), aL = wp.ld(wp.off(ax.wbeL));
             const f32x16 zero_ = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
             auto contract = [&](const float (&av)[8], float* DST) {
@@ -1102,7 +1088,7 @@ __global__ __launch_bounds__(ET * 8) __attribute__((amdgpu_waves_per_eu(2, 2))) 
                 f32x16 al_ = MFMA16(aH, bl, zero_);
                 al_ = MFMA16(aL, bh, al_);
 #pragma unroll
-                for (int r = 0; r < 16; ++r) DST[(32 * wave + n_) * 33 + (r & 3) + 8 * (r >> 2) + 4 * kh_] = am_[r] + al_[r] * X3_INV_SCALE;
+                for (int r = 0; r < 16; ++r) DST[(32 * wb_ + n_) * 33 + (r & 3) + 8 * (r >> 2) + 4 * kh_] = am_[r] + al_[r] * X3_INV_SCALE;
             };
             contract(in.av, BETA);
             if (a.BL) {                  // self-conditioning: the second rank, loaded here (not on the production path)
@@ -1114,29 +1100,11 @@ __global__ __launch_bounds__(ET * 8) __attribute__((amdgpu_waves_per_eu(2, 2))) 
             }
         }
         }
-        if (part == 0) {
+        if (part == PARTS - 1) {
 #pragma unroll
             for (int r = 0; r < 9; ++r) FR[r * ETP + e] = in.fr[r];
         }
         load_pq_part(std::integral_constant<int, 1>{}, a, me, ix, in);
-#pragma unroll
-        for (int i = 0; i < EPN1; ++i) {       // e' (fp32 in HBM) -> hi / lo' halves of an 8-group
-            const int g = part + PARTS * i;
-            if (g >= SEG) break;
-            const v4f v = in.epv[i];
-            h4 vh, vl;
-#pragma unroll
-            for (int t = 0; t < 4; t += 2) {
-                h2 hi, lo;
-                split16x2(v[t], v[t + 1], hi, lo);
-                vh[t] = hi[0]; vh[t + 1] = hi[1];
-                vl[t] = lo[0]; vl[t + 1] = lo[1];
-                over |= X3_OVER(fmaxf(fabsf(v[t]), fabsf(v[t + 1])) > X3_RANGE);
-            }
-            const int off = ((g >> 1) * ETP + e) * 16 + 8 * (g & 1);
-            *(h4*)(XH + off) = vh;
-            *(h4*)(XL + off) = vl;
-        }
         load_pq_part(std::integral_constant<int, 2>{}, a, me, ix, in);
         load_pq_part(std::integral_constant<int, 3>{}, a, me, ix, in);
         float beta[NH0], beta2[NH0];
@@ -1175,14 +1143,51 @@ __global__ __launch_bounds__(ET * 8) __attribute__((amdgpu_waves_per_eu(2, 2))) 
                 beta2[i] = bsum;
             }
         }
+        __syncthreads();                 // the END-OF-TILE barrier of the persistent loop, behind the register-only beta sums (see the other branch)
         } else {
-        __syncthreads();                 // BETA complete (the gathers above are in flight across it)
+        // BETA complete (the gathers above are in flight across it).  It is also the END-OF-TILE barrier of the persistent loop: everything this
+        // tile has written so far (BETA in the gate-partial buffer, the frame rows) goes to LDS the previous tile's segment sums do not read, so the
+        // waves that finished those early start here instead of waiting; the images (which alias the fp32 image the sums read) and the segment
+        // table are written behind it
+        __syncthreads();
 #pragma unroll
         for (int i = 0; i < NH0; ++i) {
             const int hh = min(part + PARTS * i, ROWS0 - 1);
             beta[i] = BETA[e * 33 + hh];
             if (a.BL) beta2[i] = BETA2[e * 33 + hh];
         }
+        }
+        if (wave == 0) {
+            const bool own = lane < ET;
+            const int prev = __shfl_up(ni, 1);
+            const bool start = own && (e < nvalid) && (e == 0 || prev != ni);
+            const unsigned long long mask = __ballot(start);
+            const int sid = __popcll(mask & ((2ull << lane) - 1ull)) - 1;
+            if (start) {
+                const unsigned long long rest = lane < 63 ? mask >> (lane + 1) : 0ull;
+                const int next = rest ? lane + 1 + __builtin_ctzll(rest) : nvalid;
+                // (whole: the segment is the node's whole row; else a partial for the cut-row fix-up)
+                m_rec[sid] = make_int2(ni, e | (next << 8) | (((next - e) == in.ncnt ? 1 : 0) << 16));
+            }
+            if (lane == 0) m_misc[0] = __popcll(mask);
+        }
+#pragma unroll
+        for (int i = 0; i < EPN1; ++i) {       // e' (fp32 in HBM) -> hi / lo' halves of an 8-group
+            const int g = part + PARTS * i;
+            if (g >= SEG) break;
+            const v4f v = in.epv[i];
+            h4 vh, vl;
+#pragma unroll
+            for (int t = 0; t < 4; t += 2) {
+                h2 hi, lo;
+                split16x2(v[t], v[t + 1], hi, lo);
+                vh[t] = hi[0]; vh[t + 1] = hi[1];
+                vl[t] = lo[0]; vl[t + 1] = lo[1];
+                over |= X3_OVER(fmaxf(fabsf(v[t]), fabsf(v[t + 1])) > X3_RANGE);
+            }
+            const int off = ((g >> 1) * ETP + e) * 16 + 8 * (g & 1);
+            *(h4*)(XH + off) = vh;
+            *(h4*)(XL + off) = vl;
         }
 #pragma unroll
         for (int i = 0; i < NH0; ++i) {
@@ -1520,6 +1525,6 @@ __global__ __launch_bounds__(ET * 8) __attribute__((amdgpu_waves_per_eu(2, 2))) 
     STAMP(20);
     it_ += stride_;
     if (it_ >= cnt_) break;
-    __syncthreads();                 // every wave is done with this tile's LDS (XS4 / VV4 / segment table) before the next pre-phase rewrites it
+    // (no barrier here: the one inside the next tile's pre-phase says that every wave is done with this tile's LDS)
     }
 }
