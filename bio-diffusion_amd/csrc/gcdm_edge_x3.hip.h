@@ -12,6 +12,9 @@
 //     LDS holds only their hi / lo' images in 8-channel groups (XH8 / XL8: 16 B per group, same footprint as fp32);
 //   * f16 range: images hold x * 2^-11 (the packed weights carry the 2^11), so |x| up to 1.2e8 is representable; beyond that
 //     GCDM_FLAG_F16_RANGE is raised and the caller re-runs in fp32 mode.
+//   * round 3: the kernel is PERSISTENT -- one workgroup per CU walks its XCD's contiguous range of tiles, the next tile's index words,
+//     per-edge constants and gathered node rows are requested while the current tile still computes (k_edge_msg_x3 below); the attention
+//     logits are formed on the state registers and the segment sums read an image that is already attention-weighted.
 #pragma once
 #include "gcdm_kernels.hip.h"
 #include <type_traits>
@@ -871,13 +874,13 @@ __global__ __launch_bounds__(ET * 8) __attribute__((amdgpu_waves_per_eu(2, 2))) 
     char* XH = smem + Geo::OFF_XS;                      // [36][65] x 16 B : hi images
     char* XL = XH + X3_GROUPS8 * ETP * 16;              // [36][65] x 16 B : lo' images
     static_assert(2 * X3_GROUPS8 * ETP * 16 <= Geo::OFF_VV, "XH8/XL8 must fit the fp32 XS4 region");
-    v4f* XS4 = (v4f*)(smem + Geo::OFF_XS);              // fp32 alias, used after the last GEMM (attention + aggregation)
+    v4f* XS4 = (v4f*)(smem + Geo::OFF_XS);              // fp32 alias, written after the last GEMM: attention-weighted messages for the segment sums
     float* VH = (float*)(smem + Geo::OFF_VH);
     float* PG = (float*)(smem + Geo::OFF_PG);
     float* FR = (float*)(smem + Geo::OFF_FR);
     int2* m_rec = (int2*)(smem + Geo::OFF_META);        // [segment] {node, first edge | end << 8 | whole row << 16}: one LDS read per work item of the aggregation
-    int* m_seg = (int*)(m_rec + ET);                    // (the fp32 kernel's segment-start table; unused here)
-    float* m_att = (float*)(m_seg + ET + 2);
+    int* m_seg = (int*)(m_rec + ET);                    // (the fp32 kernel's segment-start table and attention table follow: unused here, they only
+    float* m_att = (float*)(m_seg + ET + 2);            //  place m_misc where the shared geometry has it)
     int* m_misc = (int*)(m_att + ET);
 
     constexpr int H0 = (2 * GCDM_V + VE) / 4;
