@@ -5,7 +5,7 @@
  *
  * What each entry replaces in the reference (BioinfoMachineLearning/bio-diffusion, src/models/components/):
  *   gcdm_op_gemm            every nn.Linear of GCP / GCP2 (gcpnet.py:85-118, 320-348) and its autograd: y = x W^T + b, dx = dy W, dW = dy^T x
- *   gcdm_op_colsum          the bias gradient of those Linears
+ *   gcdm_op_colsum[_slices] the bias gradient of those Linears (with many rows: partial sums over row slices on the whole chip + gcdm_op_reduce_slices)
  *   gcdm_op_act[_bwd]       get_nonlinearity(...) (components/__init__.py: relu / leakyrelu / selu / silu) and torch.sigmoid (gcpnet.py:135,404)
  *   gcdm_op_norm3[_bwd]     safe_norm over the spatial axis (components/__init__.py:275-286; gcpnet.py:231,402,406,448)
  *   gcdm_op_scalarize[_bwd] scalarize (components/__init__.py:174-224): frames x vectors -> 3 x CH scalars; node mode = the same kernel on the
