@@ -552,6 +552,30 @@ def test_source_fingerprint_ignores_comments_only():
     assert len(bench.csrc_sha16()) == 16
 
 
+def test_persistent_tile_schedule_visits_every_tile_once():
+    """The contract between gcdm_api.hip (grid size, `wg_stride`) and the persistent loop of k_edge_msg_x3 (gcdm_edge_x3.hip.h): workgroup b works on
+    XCD b % 8's contiguous range [start, start + cnt) and takes local tiles (b >> 3), (b >> 3) + stride, ...  Restated here and checked for every
+    tile count that can occur around the interesting boundaries: each tile exactly once, never a tile >= G, for both workgroup budgets."""
+    def schedule(G, budget):
+        wgs = budget // 8 * 8
+        if G <= wgs or wgs < 8:
+            nwg, stride = G, G                      # one tile per workgroup (the round-2 launch)
+        else:
+            nwg, stride = wgs, wgs // 8
+        seen = [0] * G
+        for b in range(nwg):
+            xcd, base, rem = b & 7, G >> 3, G & 7
+            cnt, start, it = base + (1 if xcd < rem else 0), xcd * base + min(xcd, rem), b >> 3
+            while it < cnt:
+                seen[start + it] += 1
+                it += stride
+        return seen
+    for budget in (256, 512, 304, 32):              # CUs x workgroups per CU (64- / 32-edge tiles), a non-multiple of 8, a partition of 32 CUs
+        for G in list(range(1, 40)) + list(range(250, 270)) + list(range(505, 530)) + [1023, 1024, 1025, 2888, 5776, 5777, 7744, 40001]:
+            seen = schedule(G, budget)
+            assert all(c == 1 for c in seen), (budget, G, [i for i, c in enumerate(seen) if c != 1][:5])
+
+
 def test_committed_pmc_summaries_belong_to_the_kernels_in_the_tree():
     """The PMC summaries bench.py takes `roofline.traffic` / `mfma_busy_frac_pmc` from carry the fingerprint of the libgcdm_hip.so sources they
     were collected on; a kernel change without a new measurement round would make the bench line report nulls (`pmc_stale`).  The operator
