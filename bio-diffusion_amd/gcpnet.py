@@ -148,6 +148,11 @@ class GCPNetDynamics(nn.Module):
         operators (ops.py), differentiable.  Any configuration; ~10^2 launches per layer, so sampling prefers the fused path."""
         from . import ops
         from .config import AttrDict
+        if torch.is_grad_enabled() and xh.requires_grad:
+            # frames, edge features, orientations and mean frames are functions of the input positions evaluated WITHOUT a backward twin
+            # (ops.localize / edge_features / orientations / mean_frames): d(out)/d(xh) would silently miss those terms
+            raise NotImplementedError("GCPNetDynamics (bio-diffusion_amd): gradients with respect to the input xh are not built (parameter gradients "
+                                      "only -- the geometry operators of the network input have no backward); detach xh")
         nx = self.num_x_dims
         bi = cfg_get(batch, "batch")
         mask = cfg_get(batch, "mask")
@@ -275,15 +280,22 @@ class GCPNetDynamics(nn.Module):
         _native.check(self._lib, self._handle, st, "gcdm_plan_batch")
         self._plan_key = key
         self._plan_src = None
+        self._plan_keep = None
 
     def _plan_from_batch_index(self, batch_index: torch.Tensor, mask: Optional[torch.Tensor]):
+        # Short cut for the reference-signature step loops, which pass the SAME tensors 1000 times: (address, length, version) of both tensors.
+        # The cache KEEPS the tensors alive (`_plan_keep`): while the key is held the caching allocator cannot hand their addresses to the
+        # tensors of a different batch (a loop under inference_mode builds batch_index / mask afresh per call and frees them on return).
+        # Inference tensors have no version counter (tensor_version == -1): for them the key is address + length only -- this package never
+        # edits them in place; a caller who does must call plan() explicitly.
         src = (batch_index.data_ptr(), batch_index.shape[0], _native.tensor_version(batch_index),
-               None if mask is None else (mask.data_ptr(), _native.tensor_version(mask)))
-        if getattr(self, "_plan_src", None) == src and self._plan_key is not None:
+               None if mask is None else (mask.data_ptr(), mask.shape[0], _native.tensor_version(mask)))
+        if getattr(self, "_plan_src", None) == src and self._plan_key is not None and getattr(self, "_plan_keep", None) is not None:
             return
         counts = torch.unique_consecutive(batch_index, return_counts=True)[1]
         self.plan(counts.cpu(), mask)              # masked nodes (batch.mask with False entries): gcdm_plan_batch_masked
         self._plan_src = src
+        self._plan_keep = (batch_index, mask)
 
     # ------------------------------------------------------------------------------------------
     def forward(self, batch: Any, xh: torch.Tensor, t: torch.Tensor, **kwargs: Any) -> Tuple[Any, torch.Tensor]:
@@ -331,8 +343,8 @@ class GCPNetDynamics(nn.Module):
             self._flags.zero_()
             self.set_mfma_mode(0)
             raise F16RangeError("an activation exceeded the range of the split-precision (f16x3) images in an earlier forward call; its output "
-                                "was invalid.  The handle now runs fp32 MFMA: re-run the computation (or set check_f16_range=True for a "
-                                "self-healing, host-synchronising call)")
+                                "was invalid.  The handle now runs fp32 MFMA: re-run the computation, then call set_mfma_mode(1) to return to the "
+                                "default mode (or set check_f16_range=True for a self-healing, host-synchronising call)")
         return v
 
     @property

@@ -197,7 +197,8 @@ class _RangeCheckpoints:
             self.pend = None
             if dirty:
                 return self._rewind()
-            self.good = (st, copies)
+            st["flags"] = [int(v) for v in host.tolist()]      # the flag word(s) AT the snapshot: what a rewind restores (bits raised during a
+            self.good = (st, copies)                           # discarded f16 interval -- NaN in vel, CoG drift -- must not survive it)
         if final_flags is not None and final_flags & _native.FLAG_F16_RANGE:
             return self._rewind()
         return None
@@ -205,6 +206,16 @@ class _RangeCheckpoints:
     def _rewind(self):
         self.rewinds += 1
         return self.good
+
+    @staticmethod
+    def restore_flags(flags: torch.Tensor, state: Dict[str, Any]) -> None:
+        """Device flag word(s) back to their value at the restart point.  The first restart point (start of the loop) has no copy: only the
+        bits a network evaluation / decode can raise are cleared there (a mean-not-zero flag of the encode step in front of it stays)."""
+        saved = state.get("flags")
+        if saved is not None:
+            flags.copy_(torch.tensor(saved, dtype=flags.dtype).to(flags.device, non_blocking=True))
+        else:
+            flags.bitwise_and_(~(_native.FLAG_F16_RANGE | _native.FLAG_NAN_VEL | _native.FLAG_COG_DRIFT))
 
 
 class _Batch(AttrDict):
@@ -266,10 +277,11 @@ class EquivariantVariationalDiffusion(nn.Module):
         return torch.cat([z_x, z_h], dim=-1)
 
     def sample_normal(self, mu, sigma, batch_index, node_mask, fix_noise: bool = False, generate_x_only: bool = False,
-                      eps: Optional[torch.Tensor] = None):
+                      eps: Optional[torch.Tensor] = None, generator: Optional[torch.Generator] = None):
         if eps is None:
             bi = torch.zeros_like(batch_index) if fix_noise else batch_index
-            eps = self.sample_combined_position_feature_noise(bi, node_mask, generate_x_only=generate_x_only, num_graphs=sigma.shape[0])
+            eps = self.sample_combined_position_feature_noise(bi, node_mask, generate_x_only=generate_x_only, generator=generator,
+                                                              num_graphs=1 if fix_noise else sigma.shape[0])
         return mu + sigma[batch_index] * eps
 
     def compute_x_pred(self, zt, net_out, gamma_t, batch_index):
@@ -439,7 +451,10 @@ class EquivariantVariationalDiffusion(nn.Module):
             try:
                 net_out, net_out_0 = two_evaluations()
             except F16RangeError:           # an activation left the f16 images: the handle now runs fp32 MFMA, same inputs again
-                net_out, net_out_0 = two_evaluations()
+                try:
+                    net_out, net_out_0 = two_evaluations()
+                finally:                    # ... and returns to its default mode: one overflowing batch must not slow every later call
+                    self.dynamics_network.set_mfma_mode(1)
             error_t = self.sum_node_features_except_batch((eps_t - net_out) ** 2, bi, B)
             SNR_weight = (self.SNR(gamma_s - gamma_t) - 1).squeeze(-1)
             log_px, log_ph = self.log_pxh_given_z0_without_constants(h=h, z_0=z_0, eps=eps_0, net_out=net_out_0, gamma_0=gamma_0, batch_index=bi,
@@ -458,7 +473,7 @@ class EquivariantVariationalDiffusion(nn.Module):
     @torch.inference_mode()
     def sample_p_zs_given_zt(self, s, t, z, batch_index, node_mask, batch=None, context=None, fix_noise: bool = False,
                              generate_x_only: bool = False, self_condition: bool = False, xh_self_cond=None,
-                             noise: Optional[torch.Tensor] = None):
+                             noise: Optional[torch.Tensor] = None, generator: Optional[torch.Generator] = None):
         gamma_s, gamma_t = self.gamma(s), self.gamma(t)
         sigma2_t_given_s, sigma_t_given_s, alpha_t_given_s = self.sigma_and_alpha_t_given_s(gamma_t, gamma_s, z)
         sigma_s = self.sigma(gamma_s, target_tensor=z)
@@ -474,7 +489,7 @@ class EquivariantVariationalDiffusion(nn.Module):
             B = int(s.shape[0])
             nx = _segment_mean_sub(noise[:, : self.num_x_dims] * node_mask.float().unsqueeze(-1), batch_index, B, node_mask)
             noise = torch.cat([nx, noise[:, self.num_x_dims:] * node_mask.float().unsqueeze(-1)], dim=-1)
-        zs = self.sample_normal(mu, sigma, batch_index, node_mask, fix_noise=fix_noise, generate_x_only=generate_x_only, eps=noise)
+        zs = self.sample_normal(mu, sigma, batch_index, node_mask, fix_noise=fix_noise, generate_x_only=generate_x_only, eps=noise, generator=generator)
         zs_x = _segment_mean_sub(zs[:, : self.num_x_dims], batch_index, int(s.shape[0]), node_mask)
         return zs_x if generate_x_only else torch.cat([zs_x, zs[:, self.num_x_dims:]], dim=-1)
 
@@ -493,7 +508,8 @@ class EquivariantVariationalDiffusion(nn.Module):
 
     @torch.inference_mode()
     def sample_p_xh_given_z0(self, z_0, batch_index, node_mask, batch_size: int, batch=None, context=None, fix_noise: bool = False,
-                             generate_x_only: bool = False, xh_self_cond=None, noise: Optional[torch.Tensor] = None):
+                             generate_x_only: bool = False, xh_self_cond=None, noise: Optional[torch.Tensor] = None,
+                             generator: Optional[torch.Generator] = None):
         """x, h ~ p(x, h | z0) with the reference's signature (:839-907): the call that ends each of the reference's sampling loops.  One
         network evaluation at t = 0 plus O(N) torch algebra; extension: ``noise`` = the raw standard-normal draw [N, 3 + F].  Before the
         samples are returned the deferred range guard of this evaluation AND of the sample_p_zs_given_zt calls in front of it is checked
@@ -508,7 +524,8 @@ class EquivariantVariationalDiffusion(nn.Module):
         if noise is not None:
             m = node_mask.float().unsqueeze(-1)
             noise = torch.cat([_segment_mean_sub(noise[:, : self.num_x_dims] * m, batch_index, batch_size, node_mask), noise[:, self.num_x_dims:] * m], dim=-1)
-        xh = self.sample_normal(mu=mu_x, sigma=sigma_x, batch_index=batch_index, node_mask=node_mask, fix_noise=fix_noise, generate_x_only=generate_x_only, eps=noise)
+        xh = self.sample_normal(mu=mu_x, sigma=sigma_x, batch_index=batch_index, node_mask=node_mask, fix_noise=fix_noise, generate_x_only=generate_x_only, eps=noise,
+                                generator=generator)
         x = xh[:, : self.num_x_dims]
         if generate_x_only:              # positions only (:894-897): no node features to decode
             x, _, _ = self.unnormalize(x, node_mask, generate_x_only=True)
@@ -549,10 +566,31 @@ class EquivariantVariationalDiffusion(nn.Module):
         return dyn, lib, h
 
     def _mol_gen_sample_modules(self, num_samples, num_nodes, device, return_frames, num_timesteps, node_mask, context, fix_noise,
-                                fix_self_conditioning_noise, norm_with_original_timesteps, noise_fn, step_callback, generate_x_only: bool = False):
+                                fix_self_conditioning_noise, norm_with_original_timesteps, noise_fn, step_callback, generate_x_only: bool = False,
+                                seed: int = 1234):
         """mol_gen_sample (:1282-1412) step by step through the reference-signature methods of this class -- torch algebra on the device around
         one network evaluation per step on whichever HIP path the configuration / mask selects.  Serves masked nodes inside the loop and the
-        configurations the fused sampling kernels are not built for; ~10x slower per step than the fused loop.  ``noise_fn(k)``: raw draw k."""
+        configurations the fused sampling kernels are not built for; ~10x slower per step than the fused loop.  ``noise_fn(k)``: raw draw k;
+        without it the draws come from a device torch.Generator seeded with ``seed`` (reproducible per seed, in the reference's randn order).
+        An activation beyond the f16 range of the split-precision kernels (F16RangeError of the deferred guard; the handle is then in fp32
+        MFMA) re-runs the loop from z_T on the same noise, and the handle returns to its default mode afterwards."""
+        dyn = self.dynamics_network
+        try:
+            return self._mol_gen_sample_modules_once(num_samples, num_nodes, device, return_frames, num_timesteps, node_mask, context, fix_noise,
+                                                     fix_self_conditioning_noise, norm_with_original_timesteps, noise_fn, step_callback, generate_x_only, seed)
+        except F16RangeError:
+            log.warning("An activation left the f16 range of the split-precision kernels; re-running the sampling loop with fp32 MFMA.")
+            try:
+                out = self._mol_gen_sample_modules_once(num_samples, num_nodes, device, return_frames, num_timesteps, node_mask, context, fix_noise,
+                                                        fix_self_conditioning_noise, norm_with_original_timesteps, noise_fn, step_callback, generate_x_only, seed)
+            finally:
+                if getattr(dyn, "_handle", None) is not None:
+                    dyn.set_mfma_mode(1)
+            self.last_flags = _native.FLAG_F16_RANGE          # reported: this sample was computed with fp32 MFMA
+            return out
+
+    def _mol_gen_sample_modules_once(self, num_samples, num_nodes, device, return_frames, num_timesteps, node_mask, context, fix_noise,
+                                     fix_self_conditioning_noise, norm_with_original_timesteps, noise_fn, step_callback, generate_x_only, seed):
         num_timesteps = self.T if num_timesteps is None else num_timesteps
         assert 0 < return_frames <= num_timesteps, "Number of frames cannot be greater than number of timesteps."
         assert num_timesteps % return_frames == 0, "Number of frames must be evenly divisible by number of timesteps."
@@ -563,6 +601,10 @@ class EquivariantVariationalDiffusion(nn.Module):
             context = context.to(device)[bi] * node_mask.float().unsqueeze(-1)
         t_norm = self.T if norm_with_original_timesteps else num_timesteps
         k = [0]
+        gen = None
+        if noise_fn is None:
+            gen = torch.Generator(device=device)
+            gen.manual_seed(int(seed))
 
         def draw():
             if noise_fn is None:
@@ -573,7 +615,8 @@ class EquivariantVariationalDiffusion(nn.Module):
         m = node_mask.float().unsqueeze(-1)
         raw = draw()
         if raw is None:
-            z = self.sample_combined_position_feature_noise(torch.zeros_like(bi) if fix_noise else bi, node_mask, generate_x_only=generate_x_only, num_graphs=num_samples)
+            z = self.sample_combined_position_feature_noise(torch.zeros_like(bi) if fix_noise else bi, node_mask, generate_x_only=generate_x_only,
+                                                            generator=gen, num_graphs=1 if fix_noise else num_samples)
         else:
             z = torch.cat((_segment_mean_sub(raw[:, : self.num_x_dims] * m, bi, num_samples, node_mask), raw[:, self.num_x_dims:] * m), dim=-1)
         self_cond_on = bool(cfg_get(self.diffusion_cfg, "self_condition", False))
@@ -583,17 +626,17 @@ class EquivariantVariationalDiffusion(nn.Module):
             s_arr = torch.full((num_samples, 1), s / t_norm, device=device)
             t_arr = torch.full((num_samples, 1), (s + 1) / t_norm, device=device)
             z = self.sample_p_zs_given_zt(s=s_arr, t=t_arr, z=z, batch_index=bi, node_mask=node_mask, context=context, fix_noise=fix_noise,
-                                          generate_x_only=generate_x_only, xh_self_cond=self_cond, noise=draw())
+                                          generate_x_only=generate_x_only, xh_self_cond=self_cond, noise=draw(), generator=gen)
             if step_callback is not None:
                 step_callback(s, z)
             if (s * return_frames) % num_timesteps == 0:
                 out[(s * return_frames) // num_timesteps] = self.unnormalize_z(z, node_mask, generate_x_only=generate_x_only)
             if self_cond_on:
                 self_cond = self.sample_p_zs_given_zt(s=torch.zeros_like(s_arr), t=s_arr, z=z, batch_index=bi, node_mask=node_mask, context=context,
-                                                      fix_noise=fix_self_conditioning_noise, self_condition=True, noise=draw())
+                                                      fix_noise=fix_self_conditioning_noise, self_condition=True, noise=draw(), generator=gen)
         x, h = self.sample_p_xh_given_z0(z_0=z, batch_index=bi, node_mask=node_mask, batch_size=num_samples, context=context,
                                          fix_noise=fix_self_conditioning_noise if self_cond_on else fix_noise, generate_x_only=generate_x_only,
-                                         xh_self_cond=self_cond, noise=draw())
+                                         xh_self_cond=self_cond, noise=draw(), generator=gen)
         if return_frames == 1:
             cog = torch.zeros(num_samples, self.num_x_dims, device=device).index_add_(0, bi, x).abs().max().item()
             if cog > 5e-2:
@@ -630,14 +673,14 @@ class EquivariantVariationalDiffusion(nn.Module):
                 raise ValueError("generate_x_only needs a dynamics network built without node features (num_atom_types = 0, include_charges = False); "
                                  "the reference fails on the feature width of this one too (gcpnet.py:1093-1110)")
             return self._mol_gen_sample_modules(num_samples, num_nodes, device, return_frames, num_timesteps, node_mask, context, fix_noise,
-                                                fix_self_conditioning_noise, norm_with_original_timesteps, noise_fn, step_callback, generate_x_only=True)
+                                                fix_self_conditioning_noise, norm_with_original_timesteps, noise_fn, step_callback, generate_x_only=True, seed=seed)
         masked = node_mask is not None and not bool(node_mask.all())
         if masked or getattr(self.dynamics_network, "fused_unsupported", None) is not None or getattr(self.dynamics_network, "path", "auto") == "modules":
             # general loop: masked nodes inside the loop, or a configuration the fused sampling kernels are not built for
             if _init_xh is not None or _t_norm is not None:
                 raise NotImplementedError("property-guided optimisation runs on the fused path only")
             return self._mol_gen_sample_modules(num_samples, num_nodes, torch.device(device), return_frames, num_timesteps, node_mask, context,
-                                                fix_noise, fix_self_conditioning_noise, norm_with_original_timesteps, noise_fn, step_callback)
+                                                fix_noise, fix_self_conditioning_noise, norm_with_original_timesteps, noise_fn, step_callback, seed=seed)
         self_cond_on = bool(getattr(self.dynamics_network, "self_condition", False))
         if fix_noise or self_cond_on:
             lanes = 1                  # fix_noise: the noise is centred over the whole flat batch; self-conditioning: not sliced (yet)
@@ -707,7 +750,7 @@ class EquivariantVariationalDiffusion(nn.Module):
             if self_cond_on:
                 self_cond.copy_(rest[0])
             k = st0["k"]
-            flags.bitwise_and_(~_native.FLAG_F16_RANGE)
+            _RangeCheckpoints.restore_flags(flags, st0)
             if not fell_back:
                 log.warning("An activation left the f16 range of the split-precision kernels; resuming from step %d with fp32 MFMA.", st0["s"])
                 dyn.set_mfma_mode(0)
@@ -1121,7 +1164,7 @@ class EquivariantVariationalDiffusion(nn.Module):
             st0, (z0,) = point
             sb.wait()
             sb.bufs[sb.cur].copy_(z0)
-            sb.flags.bitwise_and_(~_native.FLAG_F16_RANGE)
+            _RangeCheckpoints.restore_flags(sb.flags, st0)
             if not fell_back:
                 log.warning("An activation left the f16 range of the split-precision kernels; resuming from step %d with fp32 MFMA.", st0["s"])
                 for w in sb.sl:

@@ -5,6 +5,8 @@ after selected early steps, and the final decode.  -> tests/golden/long_full_qm9
 
     python tests/golden/make_long_golden.py              (build container only; ~10 min of CPU)
     python tests/golden/make_long_golden.py ragged16     -> tests/golden/long_ragged16_qm9.npz: 16 molecules of 5 ... 27 atoms (~40 min of CPU)
+    python tests/golden/make_long_golden.py config0      -> tests/golden/long_config0_qm9.npz: BASELINE.json configs[0], 64 molecules x 19 atoms (hours of CPU)
+    python tests/golden/make_long_golden.py geom8        -> tests/golden/long_geom8.npz: 8 GEOM-Drugs-sized molecules of 18 ... 72 atoms, GEOM architecture
 
 Only data is stored (inputs = num_nodes + seeds, outputs); the weights are re-created from `synth.make_weights(..., seed=LONG_WEIGHT_SEED,
 scale_2d=0.25)` and the noise from `TapeNoise(LONG_NOISE_SEED)` wherever the fixture is used.
@@ -33,19 +35,31 @@ if len(sys.argv) > 1 and sys.argv[1] == "ragged16":             # second fixture
     SIZES = [18, 19, 17, 23, 9, 16, 21, 12, 19, 14, 27, 5, 20, 18, 15, 22]
     CHECKPOINTS = [999, 900, 500, 100, 0]
     OUT_NAME = "long_ragged16_qm9.npz"
+DATASET = "qm9"
+if len(sys.argv) > 1 and sys.argv[1] == "config0":              # BASELINE.json configs[0]: 64 QM9 molecules x 19 atoms (1 216 atoms, 23 104 edges)
+    LONG_WEIGHT_SEED, LONG_NOISE_SEED = 47, 77
+    SIZES = [19] * 64
+    CHECKPOINTS = [999] + list(range(900, -1, -100))
+    OUT_NAME = "long_config0_qm9.npz"
+if len(sys.argv) > 1 and sys.argv[1] == "geom8":                # 8 GEOM-Drugs-sized molecules (342 atoms, 17 034 edges, rows of up to 72 edges), GEOM architecture
+    DATASET = "geom"
+    LONG_WEIGHT_SEED, LONG_NOISE_SEED = 71, 2468
+    SIZES = [44, 31, 58, 18, 72, 40, 27, 52]
+    CHECKPOINTS = [999, 900, 700, 500, 300, 100, 0]
+    OUT_NAME = "long_geom8.npz"
 
 
 def run(dtype):
     prev = torch.get_default_dtype()
     torch.set_default_dtype(dtype)          # the reference hard-wires the default dtype in localize / scalarize
     try:
-        cfgs = rh.load_reference_cfgs("qm9", ())
-        d = synth.DATASET_DIMS["qm9"]
+        cfgs = rh.load_reference_cfgs(DATASET, ())
+        d = synth.DATASET_DIMS[DATASET]
         net = rh.build_reference_dynamics(cfgs, seed=0)
         shapes = synth.dynamics_shapes(d["S"], d["V"], d["Se"], d["Ve"], d["L"], synth.dims_h_in(d))
         net.load_state_dict(synth.make_weights(shapes, seed=LONG_WEIGHT_SEED, scale_2d=0.25))
         net = net.to(dtype)
-        ddpm = rh.build_reference_ddpm(cfgs, net, "qm9").to(dtype)
+        ddpm = rh.build_reference_ddpm(cfgs, net, DATASET).to(dtype)
         nn_ = torch.tensor(SIZES)
         zs = {}
         orig = ddpm.sample_p_zs_given_zt
@@ -71,7 +85,7 @@ def main():
     assert rh.reference_available(), "reference checkout not found"
     x32, z32 = run(torch.float32)
     x64, z64 = run(torch.float64)
-    out = dict(num_nodes=np.array(SIZES), weight_seed=LONG_WEIGHT_SEED, weight_scale=0.25, noise_seed=LONG_NOISE_SEED, T=1000,
+    out = dict(dataset=DATASET, num_nodes=np.array(SIZES), weight_seed=LONG_WEIGHT_SEED, weight_scale=0.25, noise_seed=LONG_NOISE_SEED, T=1000,
                checkpoints=np.array(CHECKPOINTS), final32=x32.float().numpy(), final64=x64.double().numpy())
     for s in CHECKPOINTS:
         out[f"z32_{s}"] = z32[s].float().numpy()
