@@ -76,6 +76,19 @@ def algorithmic_flops(N, E, dims):
     return total, edge_layer
 
 
+WINDOWS = 3          # every ms/step of this file other than the driver-contract headline: WINDOWS timed windows, the MEDIAN counts
+
+
+def median_of_windows(run_steps, steps, windows=WINDOWS):
+    """run_steps(k) runs k steps and returns when the GPU is done with them; -> (median ms/step, all windows)."""
+    ms = []
+    for _ in range(windows):
+        t0 = time.perf_counter()
+        run_steps(steps)
+        ms.append((time.perf_counter() - t0) / steps * 1e3)
+    return sorted(ms)[len(ms) // 2], ms
+
+
 def cpu_baseline(dataset, cond, dims, seconds_budget=25.0):
     """Oracle (CPU restatement pinned to the reference) on a bounded sample of BASELINE.json configs[0]'s shape: 64 QM9 molecules x 19 atoms
     (GEOM: 16 x 44), >= 10 denoise steps, extrapolated to the 1001 network evaluations of a sample."""
@@ -85,8 +98,11 @@ def cpu_baseline(dataset, cond, dims, seconds_budget=25.0):
     d = synth.DATASET_DIMS[case]
     n = 44 if dataset == "geom" else 19       # ragged workloads: the CPU sample uses the fixed README sizes (same per-edge cost)
     Bc = 16 if dataset == "geom" else 64
-    threads = min(os.cpu_count() or 1, int(os.environ.get("GCDM_CPU_THREADS", "32")))
-    torch.set_num_threads(threads)     # very wide hosts: torch CPU ops on these sizes stop scaling (and thrash) past ~32 threads
+    # thread count: torch CPU ops on these sizes stop scaling (and thrash) on very wide hosts, so the count is SWEPT once (16 / 32 / 64 / 128,
+    # two steps each after one warm-up step) and the fastest is used for the timed sample; GCDM_CPU_THREADS pins it instead
+    ncpu = os.cpu_count() or 1
+    pinned = os.environ.get("GCDM_CPU_THREADS")
+    candidates = [min(ncpu, int(pinned))] if pinned else sorted({min(ncpu, t) for t in (16, 32, 64, 128)})
     W = synth.make_weights(synth.dynamics_shapes(d["S"], d["V"], d["Se"], d["Ve"], d["L"], synth.dims_h_in(d)), seed=0, scale_2d=0.25)
     ocfg = O.OracleConfig(num_atom_types=d["num_atom_types"], include_charges=d["include_charges"], num_context=d["n_ctx"],
                           num_layers=d["L"], norm_values=d["norm_values"])
@@ -97,8 +113,18 @@ def cpu_baseline(dataset, cond, dims, seconds_budget=25.0):
     noise = O.TapeNoise(1)
     ctx = torch.randn(Bc, 1)[bi] if d["n_ctx"] else None
     z = O.sample_combined_noise(noise, bi, Bc, mask, ocfg.num_node_scalar_features, torch.float32)
+    sweep = {}
     with torch.no_grad():
-        z, _ = O.sample_p_zs_given_zt(W, ocfg, gam, 0.999, 1.0, z, bi, Bc, mask, ctx, noise)   # warm-up
+        for th in candidates:
+            torch.set_num_threads(th)
+            z, _ = O.sample_p_zs_given_zt(W, ocfg, gam, 0.999, 1.0, z, bi, Bc, mask, ctx, noise)   # warm-up
+            if len(candidates) > 1:
+                ts = time.time()
+                for k in range(2):
+                    z, _ = O.sample_p_zs_given_zt(W, ocfg, gam, 0.998, 0.999, z, bi, Bc, mask, ctx, noise)
+                sweep[th] = (time.time() - ts) / 2 * 1e3
+        threads = min(sweep, key=sweep.get) if sweep else candidates[0]
+        torch.set_num_threads(threads)
         t0 = time.time()
         steps = 0
         while steps < 10 or (time.time() - t0 < seconds_budget and steps < 50):
@@ -108,7 +134,7 @@ def cpu_baseline(dataset, cond, dims, seconds_budget=25.0):
         dt = (time.time() - t0) / steps
     return {"value": Bc / (dt * NET_EVALS_PER_SAMPLE), "unit": "molecules/s", "cores": torch.get_num_threads(), "kind": "port",
             "ms_per_step": dt * 1e3,
-            "host_cpu_count": os.cpu_count(),
+            "host_cpu_count": os.cpu_count(), "thread_sweep_ms_per_step": {str(k): round(v, 1) for k, v in sweep.items()} or None,
             "sample": f"CPU oracle (torch fp32, {torch.get_num_threads()} threads), {Bc} molecules x {n} atoms (BASELINE.json configs[0] shape), "
                       f"{steps} denoise steps timed, extrapolated x{NET_EVALS_PER_SAMPLE}"}
 
@@ -151,9 +177,10 @@ def csrc_sha16(directory=None):
     return hsh.hexdigest()[:16]
 
 
-def load_pmc_summary(workload, x3):
-    """HBM traffic / MFMA-busy of the dominant kernel from the committed rocprofv3 --pmc passes (profiles/*_pmc_summary_*.json;
+def load_pmc_summary(workload, x3, prefix=None):
+    """HBM traffic / MFMA-busy of a kernel (default: the dominant one) from the committed rocprofv3 --pmc passes (profiles/*_pmc_summary_*.json;
     collected separately as MI355X_MICROARCH.md prescribes -- not live)."""
+    prefix = prefix or ("k_edge_msg_x3" if x3 else "k_edge_msg<")
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_pmc_summary_{workload}_{'x3' if x3 else 'f32'}.json")))
     if not files:
@@ -162,7 +189,7 @@ def load_pmc_summary(workload, x3):
         d = json.load(f)
     meta = d.get("_meta", {})
     for k, v in d.items():
-        if k.startswith("k_edge_msg_x3" if x3 else "k_edge_msg<"):
+        if k.startswith(prefix):
             out = dict(v)
             out["source"] = os.path.relpath(files[-1], ROOT)
             out["collected_at_commit"] = meta.get("git_head")
@@ -172,6 +199,21 @@ def load_pmc_summary(workload, x3):
                 out["mfma_busy_frac"] = None
             return out
     return {}
+
+
+def load_kernel_stats(workload, x3, prefix):
+    """Average launch duration of a kernel in the committed rocprofv3 --kernel-trace --stats summary of `bench.py --lanes 1` (profiles/): what the
+    judge recomputes the roofline fraction from.  -> (ms, relative path) or (None, None)."""
+    import csv
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_bench_{workload}_{'x3' if x3 else 'f32'}_kernel_stats.csv")))
+    if not files:
+        return None, None
+    with open(files[-1], newline="") as f:
+        for row in csv.DictReader(f):
+            if row["Name"].replace("void ", "").startswith(prefix):
+                return float(row["AverageNs"]) * 1e-6, os.path.relpath(files[-1], ROOT)
+    return None, None
 
 
 def quick_config(pkg, name, dev, rank, lanes=2, steps=40, warmup=25):
@@ -208,19 +250,19 @@ def quick_config(pkg, name, dev, rank, lanes=2, steps=40, warmup=25):
         if (999 - s_idx) % 16 == 0:
             sl.wait(); torch.cuda.synchronize(dev)
     sl.wait(); torch.cuda.synchronize(dev)
-    ms = float("inf")
-    for _ in range(2):          # two timed windows, the faster one counts: the first window of a freshly created model runs 5-10 % slow
-        t0 = time.perf_counter()
-        for _ in range(steps):
+    def run_steps(k):
+        nonlocal s_idx
+        for _ in range(k):
             sl.step(max(s_idx, 0), 1000); s_idx -= 1
         sl.wait(); torch.cuda.synchronize(dev)
-        ms = min(ms, (time.perf_counter() - t0) / steps * 1e3)
+
+    ms, wins = median_of_windows(run_steps, steps)
     flags = int(sl.flags.max().item())
     sl.close()
     ddpm.release_lanes()
     net.release()
     return {"workload": wl["name"], "ms_per_step": ms, "value": B / (ms * 1e-3 * NET_EVALS_PER_SAMPLE), "unit": "molecules/s", "steps": steps,
-            "slices_of_the_batch": lanes, "flags": flags, "atoms": int(num_nodes.sum()), "edges": int((num_nodes.long() ** 2).sum())}
+            "windows_ms_per_step": [round(w, 4) for w in wins], "slices_of_the_batch": lanes, "flags": flags, "atoms": int(num_nodes.sum()), "edges": int((num_nodes.long() ** 2).sum())}
 
 
 def eval_driver_config(pkg, dev, rank, in_flight, steps=100):
@@ -247,15 +289,16 @@ def eval_driver_config(pkg, dev, rank, in_flight, steps=100):
         torch.cuda.synchronize(dev)
 
     run(10)
-    ms = float("inf")
-    for _ in range(2):
+    wins = []
+    for _ in range(WINDOWS):
         t0 = time.perf_counter()
         run(steps)
-        ms = min(ms, (time.perf_counter() - t0) / (steps + 1) * 1e3)
+        wins.append((time.perf_counter() - t0) / (steps + 1) * 1e3)
+    ms = sorted(wins)[len(wins) // 2]
     ddpm.release_lanes()
     net.release()
     return {"workload": wl["name"], "batches_in_flight": in_flight, "ms_per_step": ms, "value": in_flight * wl["B"] / (ms * 1e-3 * NET_EVALS_PER_SAMPLE),
-            "unit": "molecules/s", "steps": steps}
+            "unit": "molecules/s", "steps": steps, "windows_ms_per_step": [round(w, 4) for w in wins]}
 
 
 def log(msg):
@@ -276,6 +319,7 @@ def main():
     ap.add_argument("--lanes", type=int, default=2, help="sample the ONE flat batch as this many slices of molecules on separate handles / HIP "
                                                          "streams (same semantics, same noise; fills the round-quantisation tails)")
     ap.add_argument("--no-extras", action="store_true", help="skip plug_point_1 / nll_evaluation / training_step (profile runs: only the sampling kernels)")
+    ap.add_argument("--no-full-sample", action="store_true", help="skip the one complete 1000-step mol_gen_sample call after the timed loop (full_sample)")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the short runs of BASELINE.json configs[2] / configs[3] (extra fields of the JSON line)")
     ap.add_argument("--streams", type=int, default=1, help="independent batches in flight per GPU, each on its own handle and HIP stream "
                                                            "(the evaluation driver's concurrent_batches; for small batches)")
@@ -394,13 +438,56 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if dist.get_backend() == "gloo" else dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     ms_per_step = elapsed / args.steps * 1e3
     log(f"timed region: {ms_per_step:.3f} ms/step")
 
-    if sliced is not None:      # finish the sliced sample (decode), then measure the dominant kernel on the whole batch with the primary handle
+    # ---- one measurement method for everything but the driver-contract window above: the SAME stepper (the batch as config.slices_of_the_batch
+    # slices), WINDOWS windows of `mode_steps` steps, the median counts.  First the default mode again (ms_per_step_median), then -- same
+    # stepper, every slice's handle switched -- exact fp32 MFMA; other_configs below use the same rule on their own workloads.
+    def set_mode(mode):
+        lib.gcdm_set_option(h, b"mfma_mode", mode)
+        if sliced is not None:
+            for w in sliced.sl:
+                w["lane"].lib.gcdm_set_option(w["lane"].h, b"mfma_mode", mode)
+
+    def run_steps(k):
+        nonlocal s_idx
+        for _ in range(k):
+            step(max(s_idx, 0)); s_idx -= 1
+        if sliced is not None:
+            sliced.wait()
+        torch.cuda.synchronize(dev)
+
+    x3_mode = int(lib.gcdm_get_option(h, b"mfma_mode"))
+    mode_steps = 20
+    mode_wall = {}
+    run_steps(3)
+    mode_wall[x3_mode] = median_of_windows(run_steps, mode_steps)
+    if x3_mode == 1 and not args.no_fp32_timing:
+        set_mode(0)
+        run_steps(3)                # settle clocks / caches
+        mode_wall[0] = median_of_windows(run_steps, 8)
+        set_mode(1)
+        run_steps(3)
+
+    # a complete sample through the public entry point (1000 steps + decode, same slices, Philox): the wall time `value` extrapolates to
+    full_sample = None
+    if world == 1 and args.streams == 1 and not args.no_full_sample:
+        log("full 1000-step sample ...")
+        torch.cuda.synchronize(dev)
+        tfs = time.perf_counter()
+        xs, _, _ = ddpm.mol_gen_sample(num_samples=B, num_nodes=num_nodes, device=dev, lanes=max(1, args.lanes), seed=4321 + rank,
+                                       context=None if ctx is None else ctx[torch.cumsum(num_nodes.long(), 0).to(dev) - 1])
+        torch.cuda.synchronize(dev)
+        fs = time.perf_counter() - tfs
+        full_sample = {"seconds": fs, "value": B / fs, "unit": "molecules/s", "flags": int(ddpm.last_flags), "finite": bool(torch.isfinite(xs).all().item()),
+                       "vs_extrapolated": (B / fs) / (B / (ms_per_step * 1e-3 * NET_EVALS_PER_SAMPLE)),
+                       "what": "one complete mol_gen_sample call (1000 denoise steps + decode, host clock, same slices and matrix mode as the timed loop)"}
+
+    if sliced is not None:      # finish the sliced sample (decode)
         sliced.final()
         torch.cuda.synchronize(dev)
         sliced_flags = int(sliced.flags.max().item())
@@ -409,8 +496,8 @@ def main():
         sliced = None
     else:
         sliced_flags, sliced_finite = 0, True
-    # BASELINE.json configs[2] / configs[3] as extra fields of the one JSON line: short runs right after the timed region (before the
-    # fp32-mode steps, whose power draw leaves the chip at a lower clock for a while)
+    # BASELINE.json configs[2] / configs[3] as extra fields of the one JSON line: short runs (same window rule), before the per-kernel event
+    # timing below
     other_configs = None
     if args.workload == "qm9" and world == 1 and not args.no_other_configs and args.streams == 1:
         log("other configs ...")
@@ -424,38 +511,33 @@ def main():
         other_configs["qm9_eval"] = eval_driver_config(pkg, dev, rank, 1)
         other_configs["qm9_eval_4_in_flight"] = eval_driver_config(pkg, dev, rank, 4)
 
-    # Both matrix modes on the same footing: whole batch on ONE handle, wall clock over 8 steps + the dominant kernel's launch time from
-    # HIP events recorded by the library on the launch stream (separate un-timed steps).  f16x3 = the default (split-precision MFMA
-    # operands, fp32-equivalent accuracy), f32 = exact fp32 MFMA (also what the automatic re-run costs if an activation leaves the f16 range).
-    def single_handle_mode(mode):
+    # Launch durations of the two kernel families of a layer -- the fused edge-message kernel (dominant) and the node kernel -- from HIP events the
+    # library records on the launch stream.  These need WHOLE-BATCH launches on one handle (the slices' kernels of the timed loop overlap each
+    # other on the chip, so their individual durations say nothing): 5 un-timed steps per mode on the primary handle = the command profiled
+    # under profiles/ (bench.py --lanes 1).
+    def kernel_launch_ms(mode):
         nonlocal s_idx
         lib.gcdm_set_option(h, b"mfma_mode", mode)
-        for _ in range(3):          # settle clocks / caches
-            step(max(s_idx, 0)); s_idx -= 1
-        torch.cuda.synchronize(dev)
-        tf = time.perf_counter()
-        for _ in range(8):
-            step(max(s_idx, 0)); s_idx -= 1
-        torch.cuda.synchronize(dev)
-        wall_ms = (time.perf_counter() - tf) / 8 * 1e3
+        for _ in range(3):
+            st_ = lib.gcdm_sample_step(h, zp, cptr, max(s_idx, 0), T, None, seed, fp, stream); s_idx -= 1
         lib.gcdm_profile_enable(h, 1)
-        tot, cnt = 0.0, 0
+        tot, totn, cnt = 0.0, 0.0, 0
         for _ in range(5):
-            step(max(s_idx, 0)); s_idx -= 1
+            st_ = lib.gcdm_sample_step(h, zp, cptr, max(s_idx, 0), T, None, seed, fp, stream); s_idx -= 1
+            if st_ < 0:
+                native.check(lib, h, st_, "gcdm_sample_step")
             ms, nl = C.c_double(), C.c_int32()
             native.check(lib, h, lib.gcdm_profile_edge_kernel_ms(h, C.byref(ms), C.byref(nl)), "gcdm_profile_edge_kernel_ms")
             tot += ms.value
             cnt += nl.value
+            native.check(lib, h, lib.gcdm_profile_node_kernel_ms(h, C.byref(ms), C.byref(nl)), "gcdm_profile_node_kernel_ms")
+            totn += ms.value
         lib.gcdm_profile_enable(h, 0)
-        return wall_ms, tot / max(cnt, 1)
+        return tot / max(cnt, 1), totn / max(cnt, 1)
 
-    x3_mode = int(lib.gcdm_get_option(h, b"mfma_mode"))
-    mode_ms = {}
-    mode_ms[x3_mode] = single_handle_mode(x3_mode)
-    if x3_mode == 1 and not args.no_fp32_timing:
-        mode_ms[0] = single_handle_mode(0)
-        lib.gcdm_set_option(h, b"mfma_mode", 1)
-    edge_ms = mode_ms[x3_mode][1]
+    mode_ms = {m: (mode_wall[m][0], *kernel_launch_ms(m)) for m in sorted(mode_wall, reverse=True)}
+    lib.gcdm_set_option(h, b"mfma_mode", x3_mode)
+    edge_ms, node_ms = mode_ms[x3_mode][1], mode_ms[x3_mode][2]
     fallback_ms = mode_ms[0][0] if 0 in mode_ms and x3_mode == 1 else None
 
     # plug point 1: what the reference's UNCHANGED mol_gen_sample loop costs after the one-line registry swap -- per step one
@@ -535,8 +617,13 @@ def main():
     gather_ms = 0.0
     if dist is not None:
         tg = time.perf_counter()
-        bufs = [torch.empty_like(out) for _ in range(world)]
-        dist.all_gather(bufs, out)
+        if dist.get_backend() == "gloo":           # (test hook only: gloo gathers host tensors)
+            src = out.cpu()
+            bufs = [torch.empty_like(src) for _ in range(world)]
+            dist.all_gather(bufs, src)
+        else:
+            bufs = [torch.empty_like(out) for _ in range(world)]
+            dist.all_gather(bufs, out)
         torch.cuda.synchronize(dev)
         gather_ms = (time.perf_counter() - tg) * 1e3
     finite = bool(torch.isfinite(out).all().item())
@@ -554,16 +641,22 @@ def main():
 
     if rank == 0:
         dims = (d["S"], d["V"], d["Se"], d["Ve"], d["L"], synth.dims_h_in(d))
-        alg_total, alg_edge_layer = algorithmic_flops(N, E, dims)
+        alg_total, alg_edge_layer, alg_node_layer = algorithmic_flops(N, E, dims)
         exe_total = float(lib.gcdm_forward_flops_executed(h))
         achieved = alg_edge_layer / (edge_ms * 1e-3) / 1e12
         x3 = int(lib.gcdm_get_option(h, b"mfma_mode")) == 1
         # split-precision mode issues three f16 MFMAs per fp32 multiply-add block: the fp32-equivalent roof is the f16 peak / 3
         peak = PEAK_F16_MFMA_TFLOPS / 3.0 if x3 else PEAK_FP32_MFMA_TFLOPS
         pmc = load_pmc_summary(args.workload, x3)
+        node_name = "k_node_x3<false" if x3 else "k_node<false"
+        pmc_node = load_pmc_summary(args.workload, x3, node_name)
+        prof_edge_ms, prof_src = load_kernel_stats(args.workload, x3, "k_edge_msg_x3" if x3 else "k_edge_msg<")
+        prof_node_ms, _ = load_kernel_stats(args.workload, x3, node_name)
+        node_achieved = alg_node_layer / (node_ms * 1e-3) / 1e12 if node_ms else None
         res = {
             "metric": "molecules/sec (1000-step DDPM sample)", "value": world * B * max(1, args.streams) / (ms_per_step * 1e-3 * NET_EVALS_PER_SAMPLE),
             "unit": "molecules/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+            "ms_per_step_median": mode_wall[x3_mode][0], "full_sample": full_sample,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32 (f16x3 split MFMA operands: x = hi + 2^-11 lo', 22 significant bits, fp32 accumulate)" if x3_mode else "f32", "data": "synthetic",
             "config": {"workload": wl["name"], "molecules_per_gpu": B * max(1, args.streams), "batches_in_flight": max(1, args.streams), "slices_of_the_batch": max(1, args.lanes), "atoms_per_molecule": wl["n"] if wl["n"] is not None else round(N / B, 2), "nodes_per_gpu": N,
@@ -587,19 +680,35 @@ def main():
                          # no stand-alone scatter kernel whose HBM rate could be quoted)
                          "hbm_gbps": (pmc["hbm_bytes_per_launch"] / (edge_ms * 1e-3) / 1e9) if pmc.get("hbm_bytes_per_launch") else None,
                          "hbm_frac_of_8TBps": (pmc["hbm_bytes_per_launch"] / (edge_ms * 1e-3) / 8e12) if pmc.get("hbm_bytes_per_launch") else None,
-                         "measured_on": "whole-batch launches on one handle, HIP events, un-timed steps after the timed loop (= bench.py --lanes 1, the command "
-                                        "profiled under profiles/); the timed loop runs the batch as config.slices_of_the_batch slices"},
+                         "measured_on": "launch durations need whole-batch launches: 5 un-timed steps on the primary handle after the timed loop, HIP events "
+                                        "recorded by the library on the launch stream (= bench.py --lanes 1, the command profiled under profiles/); the slices of the "
+                                        "timed loop overlap on the chip, so their launches cannot be timed one by one",
+                         # the same fraction from the committed rocprofv3 kernel statistics (what a reader recomputes): algorithmic FLOP / average launch / peak
+                         "frac_recomputed_from_profiles": (alg_edge_layer / (prof_edge_ms * 1e-3) / 1e12 / peak) if prof_edge_ms else None,
+                         "profiles_avg_launch_ms": prof_edge_ms, "profiles_source": prof_src,
+                         # whole-step view with the headline's own clock (same slices, driver-contract window): every algorithmic FLOP of a step / ms_per_step / peak
+                         "step_frac": alg_total / (ms_per_step * 1e-3) / 1e12 / peak,
+                         "node_kernel": {"kernel": node_name.replace("<false", "<false, 2>") if x3 else "k_node<false>", "avg_launch_ms": node_ms, "launches_per_step": d["L"],
+                                         "algorithmic_flop_per_launch": alg_node_layer, "achieved": node_achieved, "peak": peak, "unit": "TFLOP/s",
+                                         "frac": (node_achieved / peak) if node_achieved else None, "traffic": pmc_node.get("hbm_bytes_per_launch"),
+                                         "mfma_busy_frac_pmc": pmc_node.get("mfma_busy_frac"),
+                                         "frac_recomputed_from_profiles": (alg_node_layer / (prof_node_ms * 1e-3) / 1e12 / peak) if prof_node_ms else None,
+                                         "what": "feed-forward + position-update GCP2s of a layer and the node-level halves of the next layer's msg0 "
+                                                 "(gcpnet.py:834-930); algorithmic FLOPs as the reference evaluates the two node GCP2s (the msg0 halves are not credited)"}},
         }
         def mode_entry(mode):
-            wall, ems = mode_ms[mode]
+            wall, ems, _nms = mode_ms[mode]
             pk = PEAK_F16_MFMA_TFLOPS / 3.0 if mode else PEAK_FP32_MFMA_TFLOPS
             ach = alg_edge_layer / (ems * 1e-3) / 1e12
-            return {"ms_per_step": wall, "value": world * B / (wall * 1e-3 * NET_EVALS_PER_SAMPLE), "unit": "molecules/s",
+            return {"ms_per_step": wall, "windows_ms_per_step": [round(w, 4) for w in mode_wall[mode][1]],
+                    "value": world * B * max(1, args.streams) / (wall * 1e-3 * NET_EVALS_PER_SAMPLE), "unit": "molecules/s",
                     "roofline": {"bound": "mfma", "kernel": "k_edge_msg_x3" if mode else "k_edge_msg", "avg_launch_ms": ems, "achieved": ach, "peak": pk,
                                  "unit": "TFLOP/s", "frac": ach / pk}}
         # both matrix modes, measured the same way (whole batch, one handle); quote them together
         res["modes"] = {("f16x3" if m else "f32"): mode_entry(m) for m in sorted(mode_ms, reverse=True)}
-        res["modes"]["measured_on"] = "whole batch on one handle, 8 steps wall clock after 3 settling steps; the headline ms_per_step runs the default mode as config.slices_of_the_batch slices"
+        res["modes"]["measured_on"] = (f"ms_per_step: the timed loop's own stepper (the batch as config.slices_of_the_batch slices, every slice's handle in the mode), "
+                                       f"median of {WINDOWS} windows of {mode_steps} (f32: 8) steps after 3 settling steps -- the rule of other_configs too; "
+                                       "roofline.avg_launch_ms: whole-batch launches on the primary handle (see roofline.measured_on)")
         res["plug_point_1"] = {"ms_per_step": plug1_ms, "value": None if plug1_ms is None else world * B / (plug1_ms * 1e-3 * NET_EVALS_PER_SAMPLE), "unit": "molecules/s",
                                "what": "reference-signature sample_p_zs_given_zt per step (torch algebra + GCPNetDynamics.forward on one handle, no per-call host sync): "
                                        "the cost of the reference's sampling loop after the dynamics_networks registry swap, less the one host sync per step "

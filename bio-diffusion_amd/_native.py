@@ -49,7 +49,7 @@ EXPORTS = [
     "gcdm_create", "gcdm_destroy", "gcdm_last_error", "gcdm_set_weight", "gcdm_finalize_weights", "gcdm_set_gamma",
     "gcdm_plan_batch", "gcdm_forward", "gcdm_sample_step", "gcdm_sample_final", "gcdm_sample_init", "gcdm_debug_read",
     "gcdm_debug_set_layer_limit", "gcdm_num_nodes", "gcdm_num_edges", "gcdm_forward_flops_executed",
-    "gcdm_profile_enable", "gcdm_profile_edge_kernel_ms", "gcdm_set_option", "gcdm_get_option", "gcdm_check_stability", "gcdm_encode_samples", "gcdm_unnormalize_z", "gcdm_sample_step_to", "gcdm_forward_sc", "gcdm_sample_step_sc", "gcdm_sample_final_sc",
+    "gcdm_profile_enable", "gcdm_profile_edge_kernel_ms", "gcdm_profile_node_kernel_ms", "gcdm_set_option", "gcdm_get_option", "gcdm_check_stability", "gcdm_encode_samples", "gcdm_unnormalize_z", "gcdm_sample_step_to", "gcdm_forward_sc", "gcdm_sample_step_sc", "gcdm_sample_final_sc",
     "gcdm_inpaint_center", "gcdm_inpaint_step", "gcdm_inpaint_jump", "gcdm_timestep_index", "gcdm_bond_orders", "gcdm_plan_batch_masked",
 ]
 
@@ -186,6 +186,7 @@ def load() -> C.CDLL:
     lib.gcdm_get_option.argtypes = [H, C.c_char_p]
     lib.gcdm_profile_enable.argtypes = [H, C.c_int32]
     lib.gcdm_profile_edge_kernel_ms.argtypes = [H, C.POINTER(C.c_double), C.POINTER(C.c_int32)]
+    lib.gcdm_profile_node_kernel_ms.argtypes = [H, C.POINTER(C.c_double), C.POINTER(C.c_int32)]
     lib.gcdm_forward_flops_executed.argtypes = [H]
     lib.gcdm_forward_flops_executed.restype = C.c_double
     lib.gcdm_check_stability.argtypes = [C.POINTER(GcdmBondTables), C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p,

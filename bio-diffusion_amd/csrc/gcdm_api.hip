@@ -1044,6 +1044,7 @@ int gcdm_forward_sc(gcdm_handle* h, const float* xh, const float* xh_sc, const f
         na.ff = d.ff; na.pos = d.pos;
         set_next(l + 1);   // next layer's msg0 halves, or the output projection after the last layer
         launch_node(false, l + 1, &d);
+        if (h->profile) HIP_OK(h, hipEventRecord(h->ev[2 * (size_t)h->L + l], st));      // end of the layer's node kernel (gcdm_profile_node_kernel_ms)
     }
     if (!truncated) {
         FinishArgs fa{h->VEL, h->d_noff, N, h->D, out, h->d_flags, flags, h->d_mask};
@@ -1289,7 +1290,7 @@ int gcdm_profile_enable(gcdm_handle* h, int32_t enable) {
     if (!h) return -1;
     DeviceGuard guard(h->cfg.device);
     if (enable && h->ev.empty()) {
-        h->ev.resize(2 * (size_t)h->L);
+        h->ev.resize(3 * (size_t)h->L);
         for (auto& e : h->ev) HIP_OK(h, hipEventCreate(&e));
     }
     if (enable >= 2 && !GCDM_HAVE_STAMPS)
@@ -1308,6 +1309,20 @@ int gcdm_profile_edge_kernel_ms(gcdm_handle* h, double* total_ms, int32_t* launc
         HIP_OK(h, hipEventSynchronize(h->ev[2 * l + 1]));
         float ms = 0.f;
         HIP_OK(h, hipEventElapsedTime(&ms, h->ev[2 * l], h->ev[2 * l + 1]));
+        tot += ms;
+    }
+    *total_ms = tot;
+    *launches = h->ev_used;
+    return 0;
+}
+
+int gcdm_profile_node_kernel_ms(gcdm_handle* h, double* total_ms, int32_t* launches) {
+    if (!h || !total_ms || !launches) return fail(h, "gcdm_profile_node_kernel_ms: bad argument");
+    double tot = 0.0;
+    for (int l = 0; l < h->ev_used; ++l) {
+        HIP_OK(h, hipEventSynchronize(h->ev[2 * (size_t)h->L + l]));
+        float ms = 0.f;
+        HIP_OK(h, hipEventElapsedTime(&ms, h->ev[2 * l + 1], h->ev[2 * (size_t)h->L + l]));
         tot += ms;
     }
     *total_ms = tot;

@@ -210,6 +210,9 @@ int gcdm_get_option(const gcdm_handle* h, const char* name);
  * -DGCDM_STAMPS (the stamps cost issue slots even when switched off): enable >= 2 fails on the default build. */
 int gcdm_profile_enable(gcdm_handle* h, int32_t enable);
 int gcdm_profile_edge_kernel_ms(gcdm_handle* h, double* total_ms, int32_t* launches);
+/* The same for the per-layer node kernel (feed-forward + position update + the next layer's node-level halves; launched right behind
+ * the edge-message kernel of its layer): summed duration and launch count of the LAST forward with profiling enabled. */
+int gcdm_profile_node_kernel_ms(gcdm_handle* h, double* total_ms, int32_t* launches);
 
 /* Sizes of the current plan. */
 int64_t gcdm_num_nodes(const gcdm_handle* h);

@@ -1,0 +1,64 @@
+"""bench.py's own control flow on the GPU box: the multi-rank branch (process group, barrier + MAX-over-ranks timing, the final all_gather) is
+executed here before the driver's 8-GPU node does it -- two ranks that share GPU 0 over gloo (GCDM_BENCH_SINGLE_GPU_TEST=1: a test hook, never
+used for reported numbers) -- and the N = 1 line under torchrun equals what a plain `python bench.py` prints (reference analogue:
+src/mol_gen_sample.py:108-112 picks one device)."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+QUICK = ["--steps", "10", "--warmup", "2", "--batch", "128", "--no-cpu-baseline", "--no-other-configs", "--no-extras", "--no-full-sample", "--no-fp32-timing"]
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _run(cmd, env_extra=None, timeout=280):
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1")
+    env.update(env_extra or {})
+    p = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=timeout)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, f"bench.py must print ONE JSON line, got {len(lines)}:\n{p.stdout[-2000:]}"
+    return json.loads(lines[0])
+
+
+def _check_line(r, n_gpus, B):
+    assert r["n_gpus"] == n_gpus and r["config"]["parallelism"] == f"shard{n_gpus}" and r["scaling"] == "weak"
+    assert r["steps"] == 10 and r["warmup"] == 2 and r["higher_is_better"] is True and r["vs_baseline"] is None
+    assert r["config"]["outputs_finite"] is True and r["config"]["flags"] == 0
+    assert r["config"]["molecules_per_gpu"] == B
+    # value = the units ALL ranks processed / the slowest rank's time: n_gpus x B molecules per 1001 network evaluations of ms_per_step each
+    want = n_gpus * B / (1001 * r["ms_per_step"] * 1e-3)
+    assert abs(r["value"] / want - 1) < 1e-9
+    assert 0.0 < r["roofline"]["frac"] < 1.0 and r["roofline"]["avg_launch_ms"] > 0 and r["roofline"]["node_kernel"]["avg_launch_ms"] > 0
+
+
+def test_two_ranks_run_the_multi_rank_branch():
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+           "bench.py", "--gpus", "2"] + QUICK
+    r = _run(cmd, {"GCDM_BENCH_SINGLE_GPU_TEST": "1"})
+    _check_line(r, 2, 128)
+    assert r["config"]["final_gather_ms"] > 0.0           # the one collective of the path: all_gather of the final samples, outside the timed region
+    assert "cpu_baseline" not in r                         # rank 0 at N = 1 only
+
+
+def test_one_rank_under_torchrun_prints_the_n1_line():
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+           "bench.py", "--gpus", "1"] + QUICK
+    a = _run(cmd)
+    b = _run([sys.executable, "bench.py"] + QUICK)
+    for r in (a, b):
+        _check_line(r, 1, 128)
+        assert r["config"]["final_gather_ms"] == 0.0 or r["n_gpus"] == 1
+    assert set(a) == set(b) and set(a["config"]) == set(b["config"]) and set(a["roofline"]) == set(b["roofline"])
+    assert a["metric"] == b["metric"] and a["unit"] == b["unit"] and a["config"]["workload"] == b["config"]["workload"]
+    assert abs(a["ms_per_step"] / b["ms_per_step"] - 1) < 0.25                 # same work, same box (clock noise only)

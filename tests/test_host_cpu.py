@@ -196,7 +196,7 @@ def test_bench_flop_count_matches_oracle_closed_form():
     import bench
     from oracle import gcdm_oracle as O
     for N, E, dims in ((19456, 369664, (256, 32, 64, 16, 9, 7)), (11264, 495616, (256, 32, 16, 8, 4, 17)), (1216, 23104, (256, 32, 64, 16, 9, 7))):
-        total, edge = bench.algorithmic_flops(N, E, dims)
+        total, edge, _node = bench.algorithmic_flops(N, E, dims)
         S, V, Se, Ve, L, h_in = dims
         assert total == O.forward_flops(N, E, S, V, Se, Ve, L, h_in)
         assert edge == O._gcp2_flops(E, 2 * S + Se, 2 * V + Ve, S, V, 4) + 3 * O._gcp2_flops(E, S, V, S, V, 4) + 2 * E * S

@@ -8,7 +8,9 @@
 //      barrier, all 8 waves run the finish, barrier.
 //   D  de-phased halves: waves 0-3 (one per SIMD) own edges 0-31, waves 4-7 edges 32-63, each wave two M-tiles x one N-tile (4 KB of
 //      weights per k-block and wave).  Slot 1: waves 0-3 GEMM, waves 4-7 finish; barrier; slot 2: roles swapped; barrier.
-// Same MFMAs and the same finish work per GCP2 in both; D streams every weight byte twice per 64 edges.  Prints shader cycles per GCP2.
+//   S  same-wave skew: every wave keeps its M-tile; slot 1: GEMM of edges 0-31 with the finish work of edges 32-63 (of the previous GCP2) cut into
+//      18 stages issued between the MFMAs of its k-blocks; barrier; slot 2: GEMM of edges 32-63 with the finish work of edges 0-31; barrier.
+// Same MFMAs and the same finish work per GCP2 in all three; D and S stream every weight byte twice per 64 edges.  Prints shader cycles per GCP2.
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <vector>
@@ -47,8 +49,9 @@ struct WPool {                         // weight stream through buffer loads, sc
 };
 
 // tile GEMM: MT M-tiles x NT N-tiles, weights streamed with a ring of PD + 1 register sets, B operands one block ahead (the kernel's tile_gemm_x3s)
-template <int MT, int NT>
-__device__ __forceinline__ void gemm(f32x16 (&am)[MT][NT], f32x16 (&al)[MT][NT], const WPool& wp, uint32_t wH, uint32_t wL, const h8* xh, const h8* xl, int lane) {
+template <int MT, int NT, int PER = 0, class Hook = void (*)(int)>
+__device__ __forceinline__ void gemm(f32x16 (&am)[MT][NT], f32x16 (&al)[MT][NT], const WPool& wp, uint32_t wH, uint32_t wL, const h8* xh, const h8* xl, int lane,
+                                     Hook hook = [](int) {}) {
     constexpr int R = PD + 1;
     h8 ah[R][MT], alo[R][MT], bh[2][NT], bl[2][NT];
     const int boff = (lane >> 5) * TP + (lane & 31);
@@ -81,6 +84,14 @@ __device__ __forceinline__ void gemm(f32x16 (&am)[MT][NT], f32x16 (&al)[MT][NT],
         for (int m = 0; m < MT; ++m)
 #pragma unroll
             for (int n = 0; n < NT; ++n) al[m][n] = MFMA16(alo[k % R][m], bh[k & 1][n], al[m][n]);
+        if constexpr (PER > 0) {                     // S: a stage of the OTHER half's finish work between this block's MFMAs
+            hook(k);
+#pragma unroll
+            for (int i = 0; i < 3 * MT * NT; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002 | 0x400 | 0x200 | 0x100 | 0x020, PER, 0);
+            }
+        }
         __builtin_amdgcn_sched_barrier(0);           // (as in the kernel: the scheduler works on one k-block at a time)
     }
 }
@@ -125,7 +136,7 @@ __device__ __forceinline__ void finish(const f32x16 (&p)[NB], f32x16 (&st)[NB], 
         v4f v;
 #pragma unroll
         for (int i = 0; i < 4; ++i) v[i] = gm[4 * t + i] + gl[4 * t + i] * inv;
-        *(v4f*)(PG + ((slot * 64 + l31) * 32 + 4 * ((2 * t + half) ^ (l31 & 7)))) = v;
+        *(v4f*)(PG + (((slot & 3) * 64 + l31) * 32 + 4 * ((2 * t + half) ^ (l31 & 7)))) = v;
     }
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
@@ -140,12 +151,78 @@ __device__ __forceinline__ void finish(const f32x16 (&p)[NB], f32x16 (&st)[NB], 
                 split16x2(st[b][4 * q + t], st[b][4 * q + t + 1], hi, lo, pre, neg);
                 vh[t] = hi[0]; vh[t + 1] = hi[1]; vl[t] = lo[0]; vl[t + 1] = lo[1];
             }
-            const int off = ((4 * (slot & 7) + q) * TP + 32 * b + l31) * 16 + 8 * half;
+            const int off = ((4 * (slot & 3) + q) * TP + 32 * b + l31) * 16 + 8 * half;
             *(h4*)(XH + off) = vh;
             *(h4*)(XL + off) = vl;
         }
     }
 }
+
+// The finish work of ONE block of 16 values cut into 18 stages (one per k-block of the hosting GEMM)
+struct FinStage {
+    f32x16 p, act, gm, gl;
+    h8 gwh[2], gwl[2], bh, bl;
+    f32x16* st;
+    char *XH, *XL; float* PG;
+    int slot, lane, b;
+    float pre, neg, inv;
+    __device__ __forceinline__ void silu4(int i) {
+#pragma unroll
+        for (int r = 4 * i; r < 4 * i + 4; ++r) { const float x = p[r]; act[r] = x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x)); }
+    }
+    __device__ __forceinline__ void gsplit(int j, int s0) {
+#pragma unroll
+        for (int s = s0; s < s0 + 4; s += 2) {
+            h2 hi, lo;
+            split16x2(act[8 * j + s], act[8 * j + s + 1], hi, lo, pre, neg);
+            bh[s] = hi[0]; bh[s + 1] = hi[1]; bl[s] = lo[0]; bl[s + 1] = lo[1];
+        }
+    }
+    __device__ __forceinline__ void gmfma(int j) {
+        const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        asm("s_nop 1" : "+v"(bh), "+v"(bl));
+        gm = MFMA16(gwh[j], bh, j == 0 ? zero : gm);
+        gl = MFMA16(gwh[j], bl, j == 0 ? zero : gl);
+        gl = MFMA16(gwl[j], bh, gl);
+    }
+    __device__ __forceinline__ void gout(int t0) {
+        const int half = lane >> 5, l31 = lane & 31;
+#pragma unroll
+        for (int t = t0; t < t0 + 2; ++t) {
+            v4f v;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[i] = gm[4 * t + i] + gl[4 * t + i] * inv;
+            *(v4f*)(PG + (((slot & 3) * 64 + 32 * b + l31) * 32 + 4 * ((2 * t + half) ^ (l31 & 7)))) = v;
+        }
+    }
+    __device__ __forceinline__ void image(int q) {
+        const int half = lane >> 5, l31 = lane & 31;
+        h4 vh, vl;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) (*st)[4 * q + t] += act[4 * q + t];
+#pragma unroll
+        for (int t = 0; t < 4; t += 2) {
+            h2 hi, lo;
+            split16x2((*st)[4 * q + t], (*st)[4 * q + t + 1], hi, lo, pre, neg);
+            vh[t] = hi[0]; vh[t + 1] = hi[1]; vl[t] = lo[0]; vl[t + 1] = lo[1];
+        }
+        const int off = ((4 * (slot & 3) + q) * TP + 32 * b + l31) * 16 + 8 * half;
+        *(h4*)(XH + off) = vh;
+        *(h4*)(XL + off) = vl;
+    }
+    __device__ __forceinline__ void run(int k) {
+        if (k < 4) silu4(k);
+        else if (k == 4) gsplit(0, 0);
+        else if (k == 5) gsplit(0, 4);
+        else if (k == 6) gmfma(0);
+        else if (k == 7) gsplit(1, 0);
+        else if (k == 8) gsplit(1, 4);
+        else if (k == 9) gmfma(1);
+        else if (k == 10) gout(0);
+        else if (k == 11) gout(2);
+        else if (k < 16) image(k - 12);
+    }
+};
 
 template <int VAR>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void kb(int n, float pre, float neg, float inv, const h8* __restrict__ W, float* out,
@@ -154,8 +231,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     char* XH = smem;                                   // GEMM operand images [36][65] x 16 B (hi), then lo'
     char* XL = XH + 36 * TP * 16;
     char* YH = XL + 36 * TP * 16;                      // images written by the finish work (a second buffer: no write / read ordering to model)
-    char* YL = YH + 32 * TP * 16;
-    float* PG = (float*)(YL + 32 * TP * 16);           // gate partials [8][64][32]
+    char* YL = YH + 16 * TP * 16;
+    float* PG = (float*)(YL + 16 * TP * 16);           // gate partials [4][64][32]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     for (int i = tid; i < 2 * 36 * TP; i += 512) {
@@ -186,6 +263,21 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             __syncthreads();
             finish<2>(p, st, wp, GW, YH, YL, PG, wave, lane, pre, neg, inv);
             __syncthreads();
+        } else if (VAR >= 2) {                          // S: same-wave skew -- GEMM of one half with the finish work of the other half between its MFMAs
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf) {
+                f32x16 am[1][1], al[1][1];
+                FinStage fs;
+                fs.p = p[hf ^ 1]; fs.st = &st[hf ^ 1]; fs.XH = YH; fs.XL = YL; fs.PG = PG; fs.slot = wave; fs.lane = lane; fs.b = hf ^ 1;
+                fs.pre = pre; fs.neg = neg; fs.inv = inv;
+#pragma unroll
+                for (int j = 0; j < 2; ++j) { fs.gwh[j] = wp.ld(GW + ((wave * 2 + (hf ^ 1)) * 2 + j) * 1024); fs.gwl[j] = wp.ld(GW + (32 + (wave * 2 + (hf ^ 1)) * 2 + j) * 1024); }
+                constexpr int PER = VAR == 2 ? 4 : (VAR == 3 ? 6 : 8);
+                gemm<1, 1, PER>(am, al, wp, wH + (uint32_t)wave * KB * 1024, wL + (uint32_t)wave * KB * 1024, xh + 32 * hf, xl + 32 * hf, lane, [&](int k) { fs.run(k); });
+#pragma unroll
+                for (int r = 0; r < 16; ++r) p[hf][r] = am[0][0][r] + al[0][0][r] * inv;
+                __syncthreads();
+            }
         } else {                                        // D: de-phased halves
 #pragma unroll
             for (int slot = 0; slot < 2; ++slot) {
@@ -219,10 +311,10 @@ void run(const char* name, int blocks) {
     (void)hipMalloc(&out, 4 * 512 * blocks); (void)hipMalloc(&ticks, 8 * 8 * blocks);
     const size_t wbytes = (size_t)(2 * 8 * (KB + 4) + 64) * 64 * 16;
     (void)hipMalloc(&W, wbytes); (void)hipMemset(W, 0x11, wbytes);       // every f16 = 0x1111 = 1.3e-4: finite data, the state stays bounded
-    const size_t lds = (2 * 36 + 2 * 32) * TP * 16 + 8 * 64 * 32 * 4;
+    const size_t lds = (2 * 36 + 2 * 16) * TP * 16 + 4 * 64 * 32 * 4;
     (void)hipFuncSetAttribute((const void*)kb<VAR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL((kb<VAR>), dim3(blocks), dim3(512), lds, 0, 5, 4.8828125e-4f, -2048.f, 4.8828125e-4f, W, out, ticks);
-    (void)hipDeviceSynchronize();
+    if (hipDeviceSynchronize() != hipSuccess || hipGetLastError() != hipSuccess) { printf("%s: launch failed (LDS %zu B)\n", name, lds); return; }
     hipLaunchKernelGGL((kb<VAR>), dim3(blocks), dim3(512), lds, 0, n, 4.8828125e-4f, -2048.f, 4.8828125e-4f, W, out, ticks);
     if (hipDeviceSynchronize() != hipSuccess) { printf("%s: launch failed\n", name); return; }
     std::vector<unsigned long long> h(8 * blocks);
@@ -239,6 +331,9 @@ int main() {
         run<0>("L lockstep (8 waves GEMM, then finish)", 256);
         run<1>("D de-phased halves (4 GEMM | 4 finish)", 256);
     }
+    run<2>("S same-wave skew, 1 MFMA : 4", 256);
+    run<3>("S same-wave skew, 1 MFMA : 6", 256);
+    run<4>("S same-wave skew, 1 MFMA : 8", 256);
     run<0>("L lockstep, one workgroup", 1);
     run<1>("D de-phased, one workgroup", 1);
     return 0;
