@@ -73,7 +73,7 @@ def algorithmic_flops(N, E, dims):
     node_layer = _gcp2_flops(N, 2 * S, 2 * V, S, V, 4, ff=True) + _gcp2_flops(N, S, V, S, 1, 4)
     total = (_gcp2_flops(E, 1, 1, Se, Ve, 1) + _gcp2_flops(N, h_in, 2, S, V, 1) + L * (edge_layer + node_layer)
              + _gcp2_flops(N, S, V, h_in, 0, 1))
-    return total, edge_layer
+    return total, edge_layer, node_layer
 
 
 WINDOWS = 3          # every ms/step of this file other than the driver-contract headline: WINDOWS timed windows, the MEDIAN counts
@@ -650,8 +650,10 @@ def main():
         pmc = load_pmc_summary(args.workload, x3)
         node_name = "k_node_x3<false" if x3 else "k_node<false"
         pmc_node = load_pmc_summary(args.workload, x3, node_name)
-        prof_edge_ms, prof_src = load_kernel_stats(args.workload, x3, "k_edge_msg_x3" if x3 else "k_edge_msg<")
-        prof_node_ms, _ = load_kernel_stats(args.workload, x3, node_name)
+        prof_edge_ms = prof_node_ms = prof_src = None
+        if B == wl["B"] and args.streams == 1:          # the committed profiles are of the workload's own batch
+            prof_edge_ms, prof_src = load_kernel_stats(args.workload, x3, "k_edge_msg_x3" if x3 else "k_edge_msg<")
+            prof_node_ms, _ = load_kernel_stats(args.workload, x3, node_name)
         node_achieved = alg_node_layer / (node_ms * 1e-3) / 1e12 if node_ms else None
         res = {
             "metric": "molecules/sec (1000-step DDPM sample)", "value": world * B * max(1, args.streams) / (ms_per_step * 1e-3 * NET_EVALS_PER_SAMPLE),
