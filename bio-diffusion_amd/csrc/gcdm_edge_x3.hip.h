@@ -22,7 +22,24 @@
 // SiLU in the scaled units of this kernel: the message scalars are kept as c * m.s with c = -log2(e) (the host folds c into the weights, gcdm_api.hip
 // X3_C), so for x' = c * x:  c * SiLU(x) = x' / (1 + exp2(x'))  -- exp2, add, rcp, mul: one multiply less than x * sigmoid(x)
 #define X3_C (-1.4426950408889634f)
-#ifdef GCDM_ABL_NOSILU          // (GCDM_ABL_*: timing ablations, wrong results by construction -- tools/ab_run.sh)
+// Timing ablations (-DGCDM_ABL_<piece> removes one piece of the kernel: wrong results by construction; tools/ab_run.sh reads the in-kernel end-of-tile
+// stamp of such builds, profiles/r03_ablation_edge_kernel.md is the record).  They exist only in a build that ALSO says -DGCDM_ABLATIONS.
+#ifndef GCDM_ABLATIONS
+#undef GCDM_ABL_NOSILU
+#undef GCDM_ABL_NOWLOAD
+#undef GCDM_ABL_NOB
+#undef GCDM_ABL_MFMA1
+#undef GCDM_ABL_NOGATHER
+#undef GCDM_ABL_NOP1
+#undef GCDM_ABL_NOBETA
+#undef GCDM_ABL_NOP1W
+#undef GCDM_ABL_NOPQ
+#undef GCDM_ABL_NOGATE
+#undef GCDM_ABL_GATE_NOPG
+#undef GCDM_ABL_NOSTORE
+#undef GCDM_ABL_NOAGG
+#endif
+#ifdef GCDM_ABL_NOSILU
 __device__ __forceinline__ float silu_scaled(float xs) { return xs; }
 #else
 __device__ __forceinline__ float silu_scaled(float xs) { return xs * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(xs)); }
@@ -71,7 +88,7 @@ __device__ __forceinline__ void split16(float x, _Float16& hi, _Float16& lo) {
 
 // Two values at once.  tools/valu_ubench8.hip (MI355X, two waves per SIMD): a v_fma_mix{lo,hi}_f16 -- the 16-bit-destination form --
 // occupies the SIMD for 6.9 clk, v_fma_mix_f32 / v_cvt_pk_f16_f32 / v_mul_f32 for 3.0-3.8.  So instead of four f16-destination FMAs per
-// pair (round 2) the split is: scale (v_mul x2, or one v_pk_mul_f32 with -DGCDM_X3_PK), v_cvt_pk_f16_f32 (gfx950: round-to-nearest pack),
+// pair (round 2) the split is: scale (v_mul x2; the packed v_pk_mul_f32 measured slower beside MFMAs), v_cvt_pk_f16_f32 (gfx950: round-to-nearest pack),
 // two f32 mixed FMAs that read hi as f16 from the low / high half, v_cvt_pk_f16_f32: 5-6 full-rate instructions instead of 4 half-rate
 // ones (-15 % / -20 % on the state-image phase in the micro-benchmark), every destination a full 32-bit write.  Bit-identical to split16:
 // all products are by powers of two, x - hi * 2^11 is exact in fp32, one rounding to f16 at the end of each half.
@@ -80,26 +97,12 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void split16x2(float x0, float x1, h2& hi, h2& lo) {
     const float pre = X3_PRE, neg = -X3_SCALE;
     uint32_t hiu, lou;
-#ifdef GCDM_X3_SPLIT_MIX
-    const float s0 = x0, s1 = x1;
-    asm("v_fma_mixlo_f16 %0, %1, %2, 0 op_sel_hi:[0,0,0]" : "=v"(hiu) : "v"(x0), "s"(pre));
-    asm("v_fma_mixhi_f16 %0, %1, %2, 0 op_sel_hi:[0,0,0]" : "+v"(hiu) : "v"(x1), "s"(pre));
-    asm("v_fma_mixlo_f16 %0, %1, %2, %3 op_sel_hi:[1,0,0]" : "=v"(lou) : "v"(hiu), "s"(neg), "v"(s0));
-    asm("v_fma_mixhi_f16 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(lou) : "v"(hiu), "s"(neg), "v"(s1));
-#else
-#ifdef GCDM_X3_PK
-    f32x2 t;
-    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(t) : "v"((f32x2){x0, x1}), "s"((f32x2){pre, pre}));
-    const float t0 = t[0], t1 = t[1];
-#else
     const float t0 = x0 * pre, t1 = x1 * pre;
-#endif
     float r0, r1;
     asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(hiu) : "v"(t0), "v"(t1));
     asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel_hi:[1,0,0]" : "=v"(r0) : "v"(hiu), "s"(neg), "v"(x0));
     asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r1) : "v"(hiu), "s"(neg), "v"(x1));
     asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(lou) : "v"(r0), "v"(r1));
-#endif
     __builtin_memcpy(&hi, &hiu, 4);
     __builtin_memcpy(&lo, &lou, 4);
 }
@@ -202,20 +205,8 @@ __device__ __forceinline__ void x3_prefetch_b(X3Ring<MT, PD>& ring, const WPool&
 // NOTE: the prefetches run PD k-blocks (A) / one k-block (B) past the end of the contraction without clamping: the packed weight
 // arrays carry X3_TAIL_BLOCKS zero blocks of padding behind the last M-tile, and the LDS reads stay inside the XH8|XL8|VV allocation.
 #define X3_TAIL_BLOCKS 4
-#ifndef GCDM_X3_PD
-#define GCDM_X3_PD 2             // k-blocks of weight prefetch distance in the edge kernel (register ring of PD + 1 sets)
-#endif
-#ifndef GCDM_X3_NO_ILV          // operand requests of the next k-blocks between the MFMAs of the current one (needs GCDM_X3_PD >= 2)
-constexpr bool X3_ILV = GCDM_X3_PD >= 2;
-#else
-constexpr bool X3_ILV = false;
-#endif
-#ifndef GCDM_X3_NO_GATEPF       // vector_out_scale A operands requested ahead of the SiLU that produces their B operand
-#define GCDM_X3_GATEPF 1
-#endif
-#ifndef GCDM_VEC_PER_MFMA
-#define GCDM_VEC_PER_MFMA 6      // instructions of a vector stage issued behind each MFMA of the hosting k-block
-#endif
+constexpr int X3_PD = 2;         // k-blocks of weight prefetch distance in the edge kernel (register ring of PD + 1 sets)
+constexpr int X3_VEC_PER_MFMA = 6;   // instructions of a vector stage issued behind each MFMA of the hosting k-block (0 / 3 / 4 / 10: +-0.3 %)
 
 template <int MT, int PD>
 __device__ __forceinline__ void x3_prefetch(X3Ring<MT, PD>& ring, const h8* __restrict__ wH, const h8* __restrict__ wL, int KB, int lane) {
@@ -325,28 +316,20 @@ __device__ __forceinline__ void tile_gemm_x3z(f32x16 (&am)[MT][NT], f32x16 (&al)
 #pragma unroll
                 for (int n = 0; n < NT; ++n) al[m][n] = MFMA16(ring.alo[r % R][m], bh[r & 1][n], al[m][n]);
         };
-        if constexpr (X3_ILV) {          // (see tile_gemm_x3s)
-            x3_wait_block<2 * MT * (PD - 1)>();
-            __builtin_amdgcn_sched_barrier(0);
-            mfmas();
-            breads();
-            loads();
+        // the next blocks' operand requests ride between this block's MFMAs (see tile_gemm_x3s)
+        static_assert(PD >= 2, "interleaved requests are waited for one block later: two blocks of prefetch distance");
+        x3_wait_block<2 * MT * (PD - 1)>();
+        __builtin_amdgcn_sched_barrier(0);
+        mfmas();
+        breads();
+        loads();
 #pragma unroll
-            for (int i = 0; i < 3 * MT * NT; ++i) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                if (i < 2 * NT) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-                else if (i < 2 * NT + 2 * MT) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-        } else {
-            loads();
-            breads();
-            __builtin_amdgcn_sched_barrier(0);
-            x3_wait_block<2 * MT * PD>();
-            __builtin_amdgcn_sched_barrier(0);
-            mfmas();
-            __builtin_amdgcn_sched_barrier(0);
+        for (int i = 0; i < 3 * MT * NT; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            if (i < 2 * NT) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            else if (i < 2 * NT + 2 * MT) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
         }
+        __builtin_amdgcn_sched_barrier(0);
     });
 }
 
@@ -359,21 +342,9 @@ __device__ __forceinline__ void gate_partial_x3(f32x16 (&gm)[NT], f32x16 (&gl)[N
     for (int m = 0; m < MT; ++m)
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-#ifdef GCDM_ABL_GATE_NOLOAD
-            h8 aH, aL;
-            for (int s = 0; s < 8; ++s) { aH[s] = (_Float16)(0.01f * (lane + m + j)); aL[s] = (_Float16)(0.002f * s); }
-#else
             const h8 aH = wgH[((mt0 + m) * 2 + j) * 64 + lane];
             const h8 aL = wgL[((mt0 + m) * 2 + j) * 64 + lane];
-#endif
             h8 bh[NT], bl[NT];
-#ifdef GCDM_ABL_GATE_NOSPLIT
-            for (int n = 0; n < NT; ++n) {
-                const v4f t0 = {act[m][n][8 * j], act[m][n][8 * j + 1], act[m][n][8 * j + 2], act[m][n][8 * j + 3]};
-                const v4f t1 = {act[m][n][8 * j + 4], act[m][n][8 * j + 5], act[m][n][8 * j + 6], act[m][n][8 * j + 7]};
-                bh[n] = __builtin_bit_cast(h8, t0); bl[n] = __builtin_bit_cast(h8, t1);
-            }
-#else
 #pragma unroll
             for (int n = 0; n < NT; ++n)
 #pragma unroll
@@ -385,7 +356,6 @@ __device__ __forceinline__ void gate_partial_x3(f32x16 (&gm)[NT], f32x16 (&gl)[N
                 }
 #pragma unroll
             for (int n = 0; n < NT; ++n) x3_settle(bh[n], bl[n]);
-#endif
 #pragma unroll
             for (int n = 0; n < NT; ++n) gm[n] = MFMA16(aH, bh[n], (ZERO && m == 0 && j == 0) ? zero : gm[n]);
 #pragma unroll
@@ -442,7 +412,9 @@ __device__ __forceinline__ void gate_partial_x3p(f32x16 (&gm)[NT], f32x16 (&gl)[
 // 16-byte granule (c >> 2) of row e sits at granule index (c >> 2) ^ (e & 7): conflict-free both for the writers (32x32 accumulator
 // layout: lane = edge, 4 consecutive channels per register quad) and for the readers (16x16 layout of the vector-path MFMAs).
 // The 8 channel blocks are folded pairwise in two stages (LDS float atomics run at ~1 lane/clk on gfx950): waves 0-3 store their
-// partial into slot w, (barrier), waves 4-7 add theirs onto slot w-4.  Fixed order -> deterministic.
+// partial into slot w, (barrier), waves 4-7 add theirs onto slot w-4.  Fixed order -> deterministic.  (A symmetric fold -- every wave
+// stores one N-tile and adds the other -- was measured: +0.5 %; waves s and s + 4 share a SIMD, the "idle" wave never cost SIMD time.
+// What pays is that the barrier between the two stages already says "all waves are done reading the operand images": no barrier behind the fold.)
 template <int ET>
 __device__ __forceinline__ int pg_off(int slot, int e, int c4) { return ((slot * ET + e) * 32 + 4 * (c4 ^ (e & 7))); }
 
@@ -459,24 +431,6 @@ __device__ __forceinline__ void put_gate_partial(float* PG, const f32x16 (&gm)[N
             v4f* p = (v4f*)(PG + pg_off<ET>(slot, 32 * n + l31, 2 * t + half));      // channels 8t + 4 half + {0..3}
             *p = add ? *p + v : v;
         }
-}
-
-// (-DGCDM_X3_FOLD_SYM, measured and not kept) One N-tile (32 edges) of a wave's partial, for a symmetric fold: waves s and s + 4 share slot s, in the
-// first stage wave s stores its N-tile 0 and wave s + 4 its N-tile 1, after the barrier each adds its other N-tile onto the half the partner
-// stored.  Same sums, every wave busy in both stages -- but waves s and s + 4 share a SIMD, so the "idle" wave of the two-stage fold never
-// cost SIMD time: +0.5 % tile cycles (more address arithmetic).  What does pay is that the barrier between the two stages already says "all
-// waves are done reading the operand images": the barrier behind the fold is gone (-1.0 % QM9, -0.2 % GEOM), see the kernel.
-template <int ET>
-__device__ __forceinline__ void put_gate_half(float* PG, const f32x16& gm, const f32x16& gl, int slot, int n, int lane, bool add) {
-    const int half = lane >> 5, l31 = lane & 31;
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-        v4f v;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) v[i] = gm[4 * t + i] + gl[4 * t + i] * X3_INV_SCALE;
-        v4f* p = (v4f*)(PG + pg_off<ET>(slot, 32 * n + l31, 2 * t + half));
-        *p = add ? *p + v : v;
-    }
 }
 
 // (node kernels) gate partials PG[slot][c][e], same two-stage fold
@@ -754,7 +708,7 @@ __device__ __forceinline__ void tile_gemm_x3s(f32x16 (&am)[MT][NT], f32x16 (&al)
         constexpr int r = decltype(rc)::value;
         constexpr bool HK = decltype(hooked)::value;
         auto loads = [&] {
-#ifndef GCDM_X3_NOWLOAD                          // (timing ablation only: the GEMM without its weight stream)
+#ifndef GCDM_ABL_NOWLOAD                         // (timing ablation only: the GEMM without its weight stream)
             // uniform base + compile-time block offset + lane: no per-block VALU pointer arithmetic.  Issue order: the operand of the
             // block's FIRST MFMA (ah[0]) last, so that one s_waitcnt covers the whole block instead of one per operand
 #pragma unroll
@@ -791,7 +745,7 @@ __device__ __forceinline__ void tile_gemm_x3s(f32x16 (&am)[MT][NT], f32x16 (&al)
             if (r == 0) { for (int m = 0; m < MT; ++m) for (int n = 0; n < NT; ++n) al[m][n] = zero; }
 #endif
         };
-        if constexpr (X3_ILV && !HK) {
+        if constexpr (!HK) {
             // the next blocks' operand requests ride BETWEEN this block's MFMAs (one per MFMA: B reads first, their latency is the shorter
             // one to cover), issued while the matrix pipe works on the MFMA in front of them, instead of in a burst ahead of the block
             static_assert(PD >= 2, "interleaved requests are waited for one block later: two blocks of prefetch distance");
@@ -816,13 +770,11 @@ __device__ __forceinline__ void tile_gemm_x3s(f32x16 (&am)[MT][NT], f32x16 (&al)
             mfmas();
             if constexpr (HK) {
                 hook(rc);
-#if GCDM_VEC_PER_MFMA > 0
 #pragma unroll
-                for (int i = 0; i < 3 * MT * NT; ++i) {      // one MFMA, then up to GCDM_VEC_PER_MFMA other instructions of the stage, ...
+                for (int i = 0; i < 3 * MT * NT; ++i) {      // one MFMA, then up to X3_VEC_PER_MFMA other instructions of the stage, ...
                     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x002 | 0x004 | 0x080 | 0x400 | 0x020, GCDM_VEC_PER_MFMA, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002 | 0x004 | 0x080 | 0x400 | 0x020, X3_VEC_PER_MFMA, 0);
                 }
-#endif
             }
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -858,11 +810,6 @@ struct EdgeMsgX3Args {
 // ET = 64: 8 waves, wave w owns M-tile w x both N-tiles (every weight byte is loaded once per CU and tile).
 // ET = 32: 4 waves, wave w owns M-tiles 2w, 2w+1 x one N-tile; half the LDS, so two workgroups share a CU and run out of phase
 //          (one in its GEMM while the other is in a VALU phase) at the price of streaming the weights twice per 64 edges.
-#ifdef GCDM_X3_FOLD_KEEP_BARRIER
-#define X3_FOLD_BARRIER true
-#else
-#define X3_FOLD_BARRIER false
-#endif
 template <int SE, int VE, int ET>
 __global__ __launch_bounds__(ET * 8) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_edge_msg_x3(EdgeMsgX3Args ax0) {
     constexpr int NW = ET / 8, MT = 8 / NW, NT = ET / 32;     // waves, M-tiles and N-tiles per wave
@@ -921,7 +868,7 @@ __global__ __launch_bounds__(ET * 8) __attribute__((amdgpu_waves_per_eu(2, 2))) 
     const int G_ = (E + ET - 1) / ET, xcd_ = blockIdx.x & 7, base_ = G_ >> 3, rem_ = G_ & 7;
     const int cnt_ = base_ + (xcd_ < rem_ ? 1 : 0), start_ = xcd_ * base_ + min(xcd_, rem_), stride_ = ax0.wg_stride;
     int it_ = blockIdx.x >> 3;
-    constexpr int PD = GCDM_X3_PD;
+    constexpr int PD = X3_PD;
     X3Ring<MT, PD> ring;
     const WPool wp = make_wpool(ax0.wpool, ax0.wpool_bytes, w0.lane);
     // per-edge constants (streamed from HBM, independent of the edge list) and gathered node rows.  Buffer loads: the per-lane offset is the
@@ -934,11 +881,7 @@ __global__ __launch_bounds__(ET * 8) __attribute__((amdgpu_waves_per_eu(2, 2))) 
     constexpr int ROWS0 = H0 + 3, NH0 = (ROWS0 + PARTS - 1) / PARTS;
     // beta products of the pre-phase: on the matrix pipe for the 16-channel edge width (QM9: -1.8 % tile cycles), the round-2 VALU form
     // (every thread loads the edge's alpha and its rows of W_e) for the 8-channel one, where half of the MFMA's K would be padding (GEOM: +0.5 %)
-#ifdef GCDM_X3_BETA_VALU
-    constexpr bool BETA_MFMA = false;
-#else
     constexpr bool BETA_MFMA = VE == 16;
-#endif
     struct TileIdx {
         int ni, nj;                      // this thread's edge (pre-phase layout: edge = lane, part = wave)
         int ri[NT], cj[NT];              // this lane's GEMM-layout edges (32 n + (lane & 31))
@@ -1268,10 +1211,8 @@ __global__ __launch_bounds__(ET * 8) __attribute__((amdgpu_waves_per_eu(2, 2))) 
         STAMP(3);
         tile_gemm_x3z<MT, NT, PD, KB0C, false, true>(am, al2, ring, wp, o0H, o0L, xh8, xl8, ETP, lane);
         x3_prefetch_b<MT, PD>(ring, wp, wp.off(ax.wH[0] + (size_t)mt0 * 18 * 64), wp.off(ax.wL[0] + (size_t)mt0 * 18 * 64), 18);
-#ifdef GCDM_X3_GATEPF
         GateW<MT> gw0;
         gate_prefetch<MT>(gw0, wp, ax.wg0H, ax.wg0L, mt0);
-#endif
         STAMP(4);
 #pragma unroll
         for (int m = 0; m < MT; ++m)
@@ -1281,28 +1222,18 @@ __global__ __launch_bounds__(ET * 8) __attribute__((amdgpu_waves_per_eu(2, 2))) 
                 for (int r = 0; r < 16; ++r) st[m][n][r] = silu_scaled(am[m][n][r] + al2[m][n][r] * X3_INV_SCALE);
         STAMP(5);
 #ifndef GCDM_ABL_NOGATE
-#ifdef GCDM_X3_GATEPF
         gate_partial_x3p<MT, NT, true>(gm, gl, st, gw0);
-#else
-        gate_partial_x3<MT, NT, true>(gm, gl, st, ax.wg0H, ax.wg0L, mt0, lane);
-#endif
         if (NW == 4) {               // four partials = the four slots the vector waves sum: no fold needed
             put_gate_partial<NT, ET>(PG, gm, gl, wave, lane, false);
         } else {
-#ifndef GCDM_X3_FOLD_SYM
             if (wave < 4) put_gate_partial<NT, ET>(PG, gm, gl, wave, lane, false);
             __syncthreads();         // also: every wave is done reading the msg0 operand images
             if (wave >= 4) put_gate_partial<NT, ET>(PG, gm, gl, wave - 4, lane, true);
-#else
-            if (wave < 4) put_gate_half<ET>(PG, gm[0], gl[0], wave & 3, 0, lane, false); else put_gate_half<ET>(PG, gm[NT - 1], gl[NT - 1], wave & 3, NT - 1, lane, false);
-            __syncthreads();
-            if (wave < 4) put_gate_half<ET>(PG, gm[NT - 1], gl[NT - 1], wave & 3, NT - 1, lane, true); else put_gate_half<ET>(PG, gm[0], gl[0], wave & 3, 0, lane, true);
-#endif
         }
 #endif
         STAMP(6);
     }
-    if (X3_FOLD_BARRIER || NW == 4) __syncthreads();
+    if (NW == 4) __syncthreads();
     STAMP(7);
     // ---- P3: state images ---------------------------------------------------------------------------------------------------
 #ifndef GCDM_ABL_NOSTORE
@@ -1319,22 +1250,6 @@ __global__ __launch_bounds__(ET * 8) __attribute__((amdgpu_waves_per_eu(2, 2))) 
         const GcpW& w = a.mk[k];
         const uint32_t gwH = wp.off(ax.wH[k] + (size_t)mt0 * 18 * 64), gwL = wp.off(ax.wL[k] + (size_t)mt0 * 18 * 64);
         if (k == 0) STAMP(10);
-#ifdef GCDM_X3_UNHOOK
-        // vector stages AHEAD of the wave's scalar GEMM instead of between its MFMAs: the stage registers are dead before the GEMM
-        // starts, which leaves room for a deeper weight ring (GCDM_X3_PD up to X3_TAIL_BLOCKS)
-        if (vhalf == (k & 1)) {
-            VecStage<ET, H0, k == 0> vs;
-            vs.PG = PG; vs.bg = k == 0 ? a.bg0 : a.mk[k == 0 ? 0 : k - 1].bg; vs.FR = FR; vs.VH = VH; vs.VHB = VHB; vs.VV4 = VV4; vs.XH = XH; vs.XL = XL;
-            vs.fA = k == 0 ? ax.vf0H : ax.vf1[k == 0 ? 0 : k - 1]; vs.fB = k == 0 ? ax.vf0L : ax.vf2[k == 0 ? 0 : k - 1];
-            vs.pH = ax.vpH[k]; vs.pL = ax.vpL[k];
-            vs.ve = ve; vs.vq = vq; vs.lane = lane;
-#ifndef GCDM_ABL_NOVEC
-            static_for<0, 16>([&](auto ic) { vs.template run<decltype(ic)::value>(); });
-#endif
-            amax = fmaxf(amax, vs.amax);
-        }
-        tile_gemm_x3s<MT, NT, PD, 18, 16, false>(am, al2, ring, wp, gwH, gwL, xh8, xl8, ETP, lane, [](auto) {});
-#else
         if (vhalf == (k & 1)) {
             VecStage<ET, H0, k == 0> vs;
             vs.PG = PG; vs.bg = k == 0 ? a.bg0 : a.mk[k == 0 ? 0 : k - 1].bg; vs.FR = FR; vs.VH = VH; vs.VHB = VHB; vs.VV4 = VV4; vs.XH = XH; vs.XL = XL;
@@ -1346,12 +1261,9 @@ __global__ __launch_bounds__(ET * 8) __attribute__((amdgpu_waves_per_eu(2, 2))) 
         } else {
             tile_gemm_x3s<MT, NT, PD, 18, 16, false>(am, al2, ring, wp, gwH, gwL, xh8, xl8, ETP, lane, [](auto) {});
         }
-#endif
         if (k < 2) x3_prefetch_b<MT, PD>(ring, wp, wp.off(ax.wH[k < 2 ? k + 1 : 2] + (size_t)mt0 * 18 * 64), wp.off(ax.wL[k < 2 ? k + 1 : 2] + (size_t)mt0 * 18 * 64), 18);
-#ifdef GCDM_X3_GATEPF
         GateW<MT> gwk;
         gate_prefetch<MT>(gwk, wp, ax.wgH[k], ax.wgL[k], mt0);
-#endif
         if (k == 0) STAMP(12);
 #pragma unroll
         for (int m = 0; m < MT; ++m)
@@ -1361,22 +1273,14 @@ __global__ __launch_bounds__(ET * 8) __attribute__((amdgpu_waves_per_eu(2, 2))) 
                 for (int r = 0; r < 16; ++r) am[m][n][r] = silu_scaled(am[m][n][r] + al2[m][n][r] * X3_INV_SCALE);
         if (k == 0) STAMP(13);
 #ifndef GCDM_ABL_NOGATE
-#ifdef GCDM_X3_GATEPF
         gate_partial_x3p<MT, NT, true>(gm, gl, am, gwk);
-#else
-        gate_partial_x3<MT, NT, true>(gm, gl, am, ax.wgH[k], ax.wgL[k], mt0, lane);
-#endif
         // the next tile (clamped to the workgroup's last one: no branch): its index words and per-edge constants are requested behind the last
         // gate contraction (its operands are dead) and arrive under the fold of the gate partials and the state image; the gathers that need the index words are dealt out
         // over the attention phase (load_gather_part) and arrive under the aggregation
         if (k == 2) {
             const int nxt = start_ + min(it_ + stride_, cnt_ - 1);
             ix = load_idx(a, me, nxt);
-#ifdef GCDM_X3_CONST_BURST
-            load_const(std::integral_constant<int, -1>{}, a, me, nxt, in);
-#else
             load_const(std::integral_constant<int, 0>{}, a, me, nxt, in);      // (in three bursts with the fold / the residual add between them)
-#endif
         }
 #ifdef GCDM_ABL_GATE_NOPG
         asm volatile("" ::"v"(gm[0]), "v"(gl[0]));
@@ -1386,24 +1290,16 @@ __global__ __launch_bounds__(ET * 8) __attribute__((amdgpu_waves_per_eu(2, 2))) 
 #endif
             put_gate_partial<NT, ET>(PG, gm, gl, wave, lane, false);
         } else {
-#ifndef GCDM_X3_FOLD_SYM
             if (wave < 4) put_gate_partial<NT, ET>(PG, gm, gl, wave, lane, false);
             __syncthreads();         // also: every wave is done reading the old XH8 / XL8 images
             if (wave >= 4) put_gate_partial<NT, ET>(PG, gm, gl, wave - 4, lane, true);
-#else
-            if (wave < 4) put_gate_half<ET>(PG, gm[0], gl[0], wave & 3, 0, lane, false); else put_gate_half<ET>(PG, gm[NT - 1], gl[NT - 1], wave & 3, NT - 1, lane, false);
-            __syncthreads();
-            if (wave < 4) put_gate_half<ET>(PG, gm[NT - 1], gl[NT - 1], wave & 3, NT - 1, lane, true); else put_gate_half<ET>(PG, gm[0], gl[0], wave & 3, 0, lane, true);
-#endif
         }
 #endif
         if (k == 0) STAMP(14);
         // 4 waves: every wave is done reading the old images; gate partials complete.  8 waves: the barrier inside the fold said the first, and
         // the partials are complete at the barrier behind the state images (last GCP2: behind the attention partials)
-#ifndef GCDM_X3_CONST_BURST
         if (k == 2) load_const(std::integral_constant<int, 1>{}, a, me, start_ + min(it_ + stride_, cnt_ - 1), in);
-#endif
-        if (X3_FOLD_BARRIER || NW == 4) __syncthreads();
+        if (NW == 4) __syncthreads();
         if (k == 0) STAMP(15);
 #pragma unroll
         for (int m = 0; m < MT; ++m)
@@ -1411,9 +1307,7 @@ __global__ __launch_bounds__(ET * 8) __attribute__((amdgpu_waves_per_eu(2, 2))) 
             for (int n = 0; n < NT; ++n)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) st[m][n][r] += am[m][n][r];       // residual add in fp32 (gcpnet.py:701)
-#ifndef GCDM_X3_CONST_BURST
         if (k == 2) load_const(std::integral_constant<int, 2>{}, a, me, start_ + min(it_ + stride_, cnt_ - 1), in);
-#endif
         if (k < 2) {
 #ifndef GCDM_ABL_NOSTORE
             store_state_x3<MT, NT>(XH, XL, 0, st, ETP, mt0, lane, amax);

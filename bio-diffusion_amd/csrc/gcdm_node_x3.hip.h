@@ -250,10 +250,7 @@ __global__ __launch_bounds__(NX_THREADS) void k_node_x3(NodeX3Args ax) {
     const bool validl = (n0 + l31) < N;
     constexpr int HB8 = 32;   // 8-group base of h inside XH8/XL8 (LAYER: groups 0..31 hold agg.s, then the ff hidden activations)
     constexpr int CB = 32;    // channel base of chi inside VV
-#ifndef GCDM_NODE_PD
-#define GCDM_NODE_PD 2
-#endif
-    constexpr int PD = GCDM_NODE_PD;
+    constexpr int PD = 2;     // weight prefetch distance (3 / 4 / 6 / 8: +-0.2 % -- the GEMM phases are bound by the weight stream's bandwidth, not its latency)
     bool over = false;
     float amax = 0.f;
     const uint64_t t_start = ax.prof ? __builtin_amdgcn_s_memtime() : 0;

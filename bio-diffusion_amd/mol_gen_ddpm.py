@@ -11,6 +11,7 @@ molecule and hands them to an optional ``molecule_builder`` (the reference's ``b
 from __future__ import annotations
 
 import io
+import logging
 import os
 import pickle
 import re
@@ -25,6 +26,8 @@ from .gcpnet import GCPNetDynamics
 from .stability import CategoricalDistribution, check_molecular_stability_batch
 from .xyz import save_xyz_file
 from .variational_diffusion import EquivariantVariationalDiffusion, _segment_mean_sub
+
+log = logging.getLogger(__name__)
 
 
 class _Dummy:
@@ -368,20 +371,45 @@ class _MoleculeGenerationDDPM(nn.Module):
 
     @torch.inference_mode()
     def optimize(self, samples: List[Tuple[torch.Tensor, torch.Tensor]], num_timesteps: int, num_nodes: torch.Tensor,
-                 context: Optional[torch.Tensor], node_mask: Optional[torch.Tensor] = None, return_frames: int = 1,
-                 norm_with_original_timesteps: bool = False, **kw) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor]:
-        """qm9_mol_gen_ddpm.py:636-743 without the chain visualisation: property-guided optimisation of existing samples."""
+                 context: Optional[torch.Tensor], node_mask: Optional[torch.Tensor] = None, sampling_output_dir: Optional[str] = None,
+                 optim_property: Optional[str] = None, iteration_index: Optional[int] = None, return_frames: int = 1, id_from: int = 0,
+                 chain_viz_batch_element_idx: int = 0, name: str = os.sep + "chain", norm_with_original_timesteps: bool = False,
+                 verbose: bool = True, **kw) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor]:
+        """qm9_mol_gen_ddpm.py:636-743: property-guided optimisation of existing samples.  ``return_frames > 1`` (:674-731): the chain of molecule
+        ``chain_viz_batch_element_idx`` -- frames in generation order, the last one repeated 10 times -- goes out as one XYZ file per frame under
+        ``<sampling_output_dir>/<optim_property>/<time stamp>/iteration_<i>/chain`` (the reference then renders them with matplotlib / imageio:
+        visualisation, not built), and the returned x / one_hot are frame 0 = the optimised molecules."""
         if not self.condition_on_context:
             raise Exception("Optimization requires a context conditional to optimize (e.g., `alpha`).")
         if context is None:
             if self.props_distr is None:
                 raise ValueError("context required (no props_distr attached)")
             context = self.props_distr.sample_batch(num_nodes)
-        if return_frames != 1:
-            raise NotImplementedError("chain visualisation (return_frames > 1) is not built")
         xh, batch_index, _ = self.ddpm.mol_gen_optimize(samples=samples, num_nodes=num_nodes, node_mask=node_mask, context=context,
                                                         device=self.device, num_timesteps=num_timesteps, return_frames=return_frames,
                                                         norm_with_original_timesteps=norm_with_original_timesteps, **kw)
+        if return_frames > 1:
+            assert all(p is not None for p in (sampling_output_dir, optim_property, iteration_index)), \
+                "Required parameters must be provided to visualize optimized molecules."
+            import time as _time
+            chain = xh[:, batch_index == chain_viz_batch_element_idx, :].flip(0)              # reverse_tensor (:679-680)
+            chain = torch.cat([chain, chain[-1:].repeat(10, 1, 1)], dim=0)
+            xs = chain[:, :, : self.num_x_dims]
+            oh = chain[:, :, self.num_x_dims:-1] if self.include_charges else chain[:, :, self.num_x_dims:]
+            one_hot_c = torch.nn.functional.one_hot(oh.argmax(-1), num_classes=self.num_atom_types)
+            n_sel = torch.tensor([xs.shape[1]], dtype=torch.long)
+            res = check_molecular_stability_batch(chain[-1].contiguous(), oh[-1].argmax(-1), n_sel, self.dataset_info)
+            if verbose:
+                log.info("Found stable molecule to visualize :)" if bool(int(res[0, 0])) else "Did not find stable molecule to visualize :(")
+            out_dir = os.path.join(str(sampling_output_dir), str(optim_property), _time.strftime("%Y%m%d-%H%M%S"), f"iteration_{iteration_index}", "chain")
+            save_xyz_file(path=out_dir, positions=xs.reshape(-1, xs.shape[-1]), one_hot=one_hot_c.reshape(-1, one_hot_c.shape[-1]),
+                          charges=torch.tensor([]), dataset_info=self.dataset_info, id_from=id_from, name=name,
+                          batch_index=torch.arange(xs.shape[0]).repeat_interleave(xs.shape[1]))
+            self.last_chain_dir = out_dir
+            x = xh[0, :, : self.num_x_dims]
+            one_hot = xh[0, :, self.num_x_dims:-1] if self.include_charges else xh[0, :, self.num_x_dims:]
+            charges = torch.round(chain[:, :, -1:]).long() if self.include_charges else torch.zeros(0, dtype=torch.long, device=self.device)   # (:705-709)
+            return x, one_hot, charges, batch_index
         x = xh[:, : self.num_x_dims]
         one_hot = xh[:, self.num_x_dims:-1] if self.include_charges else xh[:, self.num_x_dims:]
         charges = xh[:, -1:] if self.include_charges else torch.zeros(0, device=self.device)

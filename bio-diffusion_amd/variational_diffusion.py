@@ -567,7 +567,7 @@ class EquivariantVariationalDiffusion(nn.Module):
 
     def _mol_gen_sample_modules(self, num_samples, num_nodes, device, return_frames, num_timesteps, node_mask, context, fix_noise,
                                 fix_self_conditioning_noise, norm_with_original_timesteps, noise_fn, step_callback, generate_x_only: bool = False,
-                                seed: int = 1234):
+                                seed: int = 1234, init_xh: Optional[torch.Tensor] = None):
         """mol_gen_sample (:1282-1412) step by step through the reference-signature methods of this class -- torch algebra on the device around
         one network evaluation per step on whichever HIP path the configuration / mask selects.  Serves masked nodes inside the loop and the
         configurations the fused sampling kernels are not built for; ~10x slower per step than the fused loop.  ``noise_fn(k)``: raw draw k;
@@ -577,12 +577,12 @@ class EquivariantVariationalDiffusion(nn.Module):
         dyn = self.dynamics_network
         try:
             return self._mol_gen_sample_modules_once(num_samples, num_nodes, device, return_frames, num_timesteps, node_mask, context, fix_noise,
-                                                     fix_self_conditioning_noise, norm_with_original_timesteps, noise_fn, step_callback, generate_x_only, seed)
+                                                     fix_self_conditioning_noise, norm_with_original_timesteps, noise_fn, step_callback, generate_x_only, seed, init_xh)
         except F16RangeError:
             log.warning("An activation left the f16 range of the split-precision kernels; re-running the sampling loop with fp32 MFMA.")
             try:
                 out = self._mol_gen_sample_modules_once(num_samples, num_nodes, device, return_frames, num_timesteps, node_mask, context, fix_noise,
-                                                        fix_self_conditioning_noise, norm_with_original_timesteps, noise_fn, step_callback, generate_x_only, seed)
+                                                        fix_self_conditioning_noise, norm_with_original_timesteps, noise_fn, step_callback, generate_x_only, seed, init_xh)
             finally:
                 if getattr(dyn, "_handle", None) is not None:
                     dyn.set_mfma_mode(1)
@@ -590,7 +590,7 @@ class EquivariantVariationalDiffusion(nn.Module):
             return out
 
     def _mol_gen_sample_modules_once(self, num_samples, num_nodes, device, return_frames, num_timesteps, node_mask, context, fix_noise,
-                                     fix_self_conditioning_noise, norm_with_original_timesteps, noise_fn, step_callback, generate_x_only, seed):
+                                     fix_self_conditioning_noise, norm_with_original_timesteps, noise_fn, step_callback, generate_x_only, seed, init_xh=None):
         num_timesteps = self.T if num_timesteps is None else num_timesteps
         assert 0 < return_frames <= num_timesteps, "Number of frames cannot be greater than number of timesteps."
         assert num_timesteps % return_frames == 0, "Number of frames must be evenly divisible by number of timesteps."
@@ -613,8 +613,18 @@ class EquivariantVariationalDiffusion(nn.Module):
             return noise_fn(k[0] - 1)
 
         m = node_mask.float().unsqueeze(-1)
-        raw = draw()
-        if raw is None:
+        raw = None
+        if init_xh is not None:
+            # optimisation loop (mol_gen_optimize :1451-1464): z = normalize(samples), no initial draw; the reference's assert_mean_zero_with_mask
+            xin = init_xh.to(device, torch.float32)
+            nv, nb = cfg_get(self.diffusion_cfg, "norm_values"), cfg_get(self.diffusion_cfg, "norm_biases")
+            z = torch.cat((xin[:, : self.num_x_dims] / nv[0], (xin[:, self.num_x_dims:] - nb[1]) / nv[1] * m), dim=-1)
+            self.assert_mean_zero_with_mask(z[:, : self.num_x_dims], node_mask)
+        else:
+            raw = draw()
+        if init_xh is not None:
+            pass
+        elif raw is None:
             z = self.sample_combined_position_feature_noise(torch.zeros_like(bi) if fix_noise else bi, node_mask, generate_x_only=generate_x_only,
                                                             generator=gen, num_graphs=1 if fix_noise else num_samples)
         else:
@@ -677,10 +687,11 @@ class EquivariantVariationalDiffusion(nn.Module):
         masked = node_mask is not None and not bool(node_mask.all())
         if masked or getattr(self.dynamics_network, "fused_unsupported", None) is not None or getattr(self.dynamics_network, "path", "auto") == "modules":
             # general loop: masked nodes inside the loop, or a configuration the fused sampling kernels are not built for
-            if _init_xh is not None or _t_norm is not None:
-                raise NotImplementedError("property-guided optimisation runs on the fused path only")
+            if _t_norm is not None:
+                raise NotImplementedError("an explicit time normalisation runs on the fused path only")
             return self._mol_gen_sample_modules(num_samples, num_nodes, torch.device(device), return_frames, num_timesteps, node_mask, context,
-                                                fix_noise, fix_self_conditioning_noise, norm_with_original_timesteps, noise_fn, step_callback, seed=seed)
+                                                fix_noise, fix_self_conditioning_noise, norm_with_original_timesteps, noise_fn, step_callback, seed=seed,
+                                                init_xh=_init_xh)
         self_cond_on = bool(getattr(self.dynamics_network, "self_condition", False))
         if fix_noise or self_cond_on:
             lanes = 1                  # fix_noise: the noise is centred over the whole flat batch; self-conditioning: not sliced (yet)
@@ -1233,14 +1244,18 @@ class EquivariantVariationalDiffusion(nn.Module):
         """Optimise existing samples with the generative model (variational_diffusion.py:1416-1546): the samples
         ``[(x [n,3], one_hot [n,F]), ...]`` are normalised and taken as z at t = num_timesteps / T_norm, denoised for ``num_timesteps``
         steps and decoded.  As in the reference z carries no charge column (``"integer": torch.tensor([])``, :1457), so the model must
-        have ``include_charges=False`` (the property-conditional QM9 models).  ``noise_fn(k)``: k = 0 is the first step's draw."""
-        if return_frames != 1 or generate_x_only:
-            raise NotImplementedError("mol_gen_optimize (HIP): return_frames>1 / generate_x_only are not built")
+        have ``include_charges=False`` (the property-conditional QM9 models).  ``noise_fn(k)``: k = 0 is the first step's draw.
+        ``return_frames > 1``: [frames, N, 3 + F] -- frame (s * return_frames) // T after the step to s, frame 0 the decoded sample (:1490-1497,
+        1540-1546).  Configurations off the fused path (and ``dynamics_network.path = "modules"``) run the general loop."""
+        if generate_x_only:
+            # nothing to mirror: the reference's own call raises -- normalize(..., generate_x_only=True) does `h.float()` on the {"categorical", "integer"}
+            # dict mol_gen_optimize hands it (variational_diffusion.py:716 via :1454-1459: AttributeError)
+            raise NotImplementedError("mol_gen_optimize: generate_x_only raises in the reference too (variational_diffusion.py:716 via :1454: `h.float()` on a dict)")
         if self.include_charges:
             raise NotImplementedError("mol_gen_optimize builds z without the charge column (reference :1457): include_charges must be False")
         if len(samples) != len(num_nodes):
             raise ValueError("one (x, h) pair per molecule")
         xh = torch.cat([torch.cat((x.to(torch.float32), h.to(torch.float32)), dim=-1) for x, h in samples], dim=0)
-        return self.mol_gen_sample(num_samples=len(samples), num_nodes=num_nodes, device=device, num_timesteps=num_timesteps,
+        return self.mol_gen_sample(num_samples=len(samples), num_nodes=num_nodes, device=device, return_frames=return_frames, num_timesteps=num_timesteps,
                                    node_mask=node_mask, context=context, norm_with_original_timesteps=norm_with_original_timesteps,
                                    noise_fn=noise_fn, seed=seed, _init_xh=xh)

@@ -648,12 +648,15 @@ def get_repaint_schedule(resamplings: int, jump_length: int, num_timesteps: int)
 
 def mol_gen_optimize(P: Params, cfg: OracleConfig, x: Tensor, h_cat: Tensor, num_nodes: Tensor, noise,
                      context: Optional[Tensor] = None, num_timesteps: Optional[int] = None,
-                     norm_with_original_timesteps: bool = False, dtype=torch.float32) -> Tuple[Tensor, Tensor]:
-    """EquivariantVariationalDiffusion.mol_gen_optimize, variational_diffusion.py:1416-1546 (return_frames=1, no self-conditioning):
+                     norm_with_original_timesteps: bool = False, dtype=torch.float32, return_frames: int = 1) -> Tuple[Tensor, Tensor]:
+    """EquivariantVariationalDiffusion.mol_gen_optimize, variational_diffusion.py:1416-1546:
     the given samples are normalised and used as z at t = num_timesteps / T_norm, then denoised for num_timesteps steps and decoded.
-    As in the reference the charge column is not part of z (`"integer": torch.tensor([])`, :1457), so include_charges must be False."""
+    As in the reference the charge column is not part of z (`"integer": torch.tensor([])`, :1457), so include_charges must be False.
+    return_frames > 1 (:1490-1497, 1526, 1540-1546): frame (s * return_frames) // T holds unnormalize_z of the latent after the step to s
+    whenever (s * return_frames) % T == 0, frame 0 is overwritten by the decoded sample, and the CoG re-projection is skipped; -> [frames, N, 3 + F]."""
     assert not cfg.include_charges
     T = cfg.num_timesteps if num_timesteps is None else num_timesteps
+    assert 0 < return_frames <= T and T % return_frames == 0
     Tn = cfg.num_timesteps if norm_with_original_timesteps else T
     B = len(num_nodes)
     bi = num_nodes_to_batch_index(num_nodes)
@@ -666,15 +669,20 @@ def mol_gen_optimize(P: Params, cfg: OracleConfig, x: Tensor, h_cat: Tensor, num
     z = torch.cat((xn, hn), dim=-1)
     assert assert_mean_zero_with_mask(z[:, :3], bi, B) < 1e-2                       # :1464
     self_cond = None
+    frames = torch.zeros((return_frames,) + tuple(z.shape), dtype=dtype)
     for s in reversed(range(T)):
         z, _ = sample_p_zs_given_zt(P, cfg, gam, s / Tn, (s + 1) / Tn, z, bi, B, mask, ctx, noise, xh_self_cond=self_cond)
+        if (s * return_frames) % T == 0:                                            # :1490-1497
+            frames[(s * return_frames) // T] = unnormalize_z(cfg, z, mask)
         if cfg.self_condition:                                                      # :1500-1512
             self_cond, _ = sample_p_zs_given_zt(P, cfg, gam, 0.0, s / Tn, z, bi, B, mask, ctx, noise)
     xo, one_hot, charges = sample_p_xh_given_z0(P, cfg, gam, z, bi, B, mask, ctx, noise, xh_self_cond=self_cond)
-    cog = torch.zeros(B, 3, dtype=dtype).index_add_(0, bi, xo).abs().max().item()
-    if cog > 5e-2:                                                                  # :1527-1537
-        xo = centralize(xo, bi, B, mask)
-    return torch.cat((xo, one_hot.to(dtype)), dim=-1), bi
+    if return_frames == 1:
+        cog = torch.zeros(B, 3, dtype=dtype).index_add_(0, bi, xo).abs().max().item()
+        if cog > 5e-2:                                                              # :1527-1537
+            xo = centralize(xo, bi, B, mask)
+    frames[0] = torch.cat((xo, one_hot.to(dtype)), dim=-1)
+    return (frames[0] if return_frames == 1 else frames), bi
 
 
 

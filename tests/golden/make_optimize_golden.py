@@ -43,11 +43,11 @@ def main():
     out = dict(num_nodes=nn_, ctx=ctx_b, x=torch.cat([s[0] for s in samples]), h=torch.cat([s[1] for s in samples]),
                weight_check=net.state_dict()["gcp_embedding.node_embedding.scalar_out.0.weight"].float()
                if "gcp_embedding.node_embedding.scalar_out.0.weight" in net.state_dict() else next(iter(net.state_dict().values())).float())
-    for tag, T, orig in (("a", 10, False), ("b", 8, True)):
+    for tag, T, orig, frames in (("a", 10, False, 1), ("b", 8, True, 1), ("c", 10, False, 5)):      # c: chain frames (return_frames = 5, :1490-1497, 1540-1546)
         with rh.NoiseTape(4321) as tape, torch.no_grad():
             xh, bi, _ = ddpm.mol_gen_optimize(samples=[(x.clone(), h.clone()) for x, h in samples], num_nodes=nn_, device="cpu",
-                                              num_timesteps=T, context=ctx_b, norm_with_original_timesteps=orig)
-        out[f"{tag}_T"], out[f"{tag}_orig"], out[f"{tag}_out"] = T, int(orig), xh
+                                              num_timesteps=T, context=ctx_b, norm_with_original_timesteps=orig, return_frames=frames)
+        out[f"{tag}_T"], out[f"{tag}_orig"], out[f"{tag}_out"], out[f"{tag}_frames"] = T, int(orig), xh, frames
         out[f"{tag}_calls"] = np.array(tape.calls, dtype=np.int64)
         print(tag, "T", T, "orig", orig, "out", tuple(xh.shape), "randn calls", len(tape.calls), tape.calls[:3])
     out["noise_seed"] = 4321

@@ -963,6 +963,38 @@ def test_mol_gen_optimize_matches_oracle(orig):
     x2, oh2, ch2, bi3 = model.optimize(samples=[(x.cuda(), h_.cuda()) for x, h_ in samples], num_timesteps=Tp, num_nodes=nn_, context=ctx_b.cuda(),
                                        norm_with_original_timesteps=orig, noise_fn=lambda k: draws[k])
     assert (x2.cpu() - want[:, :3]).abs().max().item() <= TOL * scale and torch.equal(oh2.cpu(), want[:, 3:]) and ch2.numel() == 0
+    wantf, _ = O.mol_gen_optimize(W, ocfg, X, Hc, nn_, O.TapeNoise(77), context=ctx_b, num_timesteps=Tp, norm_with_original_timesteps=orig, return_frames=3)
+    # the whole-model driver with chain frames (:674-731): XYZ files of molecule 1's chain (3 frames + the last one 10 more times), frame 0 returned
+    import tempfile, glob as _glob
+    with tempfile.TemporaryDirectory() as td:
+        x3, oh3, ch3, _ = model.optimize(samples=[(x.cuda(), h_.cuda()) for x, h_ in samples], num_timesteps=Tp, num_nodes=nn_, context=ctx_b.cuda(),
+                                         norm_with_original_timesteps=orig, noise_fn=lambda k: draws[k], return_frames=3, sampling_output_dir=td,
+                                         optim_property="alpha", iteration_index=0, chain_viz_batch_element_idx=1, verbose=False)
+        files = sorted(_glob.glob(os.path.join(model.last_chain_dir, "*.xyz")))
+        assert len(files) == 13 and ch3.numel() == 0
+        assert len(open(files[0]).read().splitlines()) == int(nn_[1]) + 2            # XYZ: count, blank, one line per atom
+    # chain frames (return_frames = 3 of 9 steps, :1490-1497, 1540-1546; the oracle's frames are pinned by the reference's own in
+    # optimize_small_qm9cond.npz, run c): fused loop, and the general loop on the module path
+    assert (x3.cpu() - wantf[0, :, :3]).abs().max().item() <= TOL * max(1.0, wantf.abs().max().item()) and torch.equal(oh3.cpu(), wantf[0, :, 3:])
+    for path in ("auto", "modules"):
+        net.path = path
+        try:
+            fr, _, _ = model_ddpm.mol_gen_optimize(samples=[(x.cuda(), h_.cuda()) for x, h_ in samples], num_nodes=nn_, device="cuda", num_timesteps=Tp,
+                                                   context=ctx_b.cuda(), norm_with_original_timesteps=orig, noise_fn=lambda k: draws[k], return_frames=3)
+        finally:
+            net.path = "auto"
+        fr = fr.cpu()
+        assert fr.shape == wantf.shape == (3, N, 3 + F)
+        assert (fr - wantf).abs().max().item() <= TOL * max(1.0, wantf.abs().max().item()), path
+        assert torch.equal(fr[0, :, 3:], wantf[0, :, 3:])
+        if path == "modules":                      # ... and the frame-less call on the module path equals the fused one
+            net.path = "modules"
+            try:
+                o2, _, _ = model_ddpm.mol_gen_optimize(samples=[(x.cuda(), h_.cuda()) for x, h_ in samples], num_nodes=nn_, device="cuda", num_timesteps=Tp,
+                                                       context=ctx_b.cuda(), norm_with_original_timesteps=orig, noise_fn=lambda k: draws[k])
+            finally:
+                net.path = "auto"
+            assert (o2.cpu()[:, :3] - want[:, :3]).abs().max().item() <= TOL * scale and torch.equal(o2.cpu()[:, 3:], want[:, 3:])
 
 
 def test_philox_noise_statistics_and_determinism():

