@@ -610,7 +610,7 @@ class EquivariantVariationalDiffusion(nn.Module):
             if noise_fn is None:
                 return None
             k[0] += 1
-            return noise_fn(k[0] - 1)
+            return noise_fn(k[0] - 1).to(device, torch.float32)
 
         m = node_mask.float().unsqueeze(-1)
         raw = None
