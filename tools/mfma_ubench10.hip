@@ -224,6 +224,38 @@ struct FinStage {
     }
 };
 
+// the same NUMBER of VALU instructions per stage as FinStage on average (12), but plain independent v_fma_f32 (what mfma_ubench5 hides at ~65 %)
+struct FmaStage {
+    float x[12];
+    float c, d;
+    __device__ __forceinline__ void run(int) {
+#pragma unroll
+        for (int i = 0; i < 12; ++i) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(x[i]) : "v"(c), "v"(d));
+    }
+};
+// transcendental-only filler: 6 x (v_exp_f32, v_rcp_f32) per stage
+struct TransStage {
+    float x[12];
+    __device__ __forceinline__ void run(int) {
+#pragma unroll
+        for (int i = 0; i < 6; ++i) { asm volatile("v_exp_f32 %0, %0" : "+v"(x[i])); asm volatile("v_rcp_f32 %0, %0" : "+v"(x[6 + i])); }
+    }
+};
+// split-only filler: 2 pairs per stage (12 instructions: 2 mul, cvt_pk, 2 fma_mix, cvt_pk each)
+struct SplitStage {
+    float x[8];
+    unsigned acc;
+    float pre, neg;
+    __device__ __forceinline__ void run(int k) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            h2 hi, lo;
+            split16x2(x[(2 * i + 4 * (k & 1)) & 7], x[(2 * i + 1 + 4 * (k & 1)) & 7], hi, lo, pre, neg);
+            acc ^= __builtin_bit_cast(unsigned, hi) + __builtin_bit_cast(unsigned, lo);
+        }
+    }
+};
+
 template <int VAR>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void kb(int n, float pre, float neg, float inv, const h8* __restrict__ W, float* out,
                                                                                      unsigned long long* ticks) {
@@ -263,6 +295,29 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             __syncthreads();
             finish<2>(p, st, wp, GW, YH, YL, PG, wave, lane, pre, neg, inv);
             __syncthreads();
+        } else if (VAR >= 5) {                          // F: the S loop with synthetic fillers of ONE kind (which kinds hide under the wave's own MFMAs?)
+            FmaStage fm; TransStage tr; SplitStage sp;
+            for (int i = 0; i < 12; ++i) { fm.x[i] = 0.001f * (lane + i); tr.x[i] = 0.01f * (lane + i); }
+            for (int i = 0; i < 8; ++i) sp.x[i] = 0.37f * (lane + 1) + 0.011f * i;
+            fm.c = 1.0001f; fm.d = 0.0003f; sp.pre = pre; sp.neg = neg; sp.acc = 0;
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf) {
+                f32x16 am[1][1], al[1][1];
+                constexpr bool ILV = (VAR & 1) == 1;            // odd: between the MFMAs; even: the same instructions behind the GEMM
+                auto filler = [&](int k) { if (k < 16) { if (VAR <= 6) fm.run(k); else if (VAR <= 8) tr.run(k); else sp.run(k); } };
+                if (ILV) gemm<1, 1, 4>(am, al, wp, wH + (uint32_t)wave * KB * 1024, wL + (uint32_t)wave * KB * 1024, xh + 32 * hf, xl + 32 * hf, lane, filler);
+                else {
+                    gemm<1, 1>(am, al, wp, wH + (uint32_t)wave * KB * 1024, wL + (uint32_t)wave * KB * 1024, xh + 32 * hf, xl + 32 * hf, lane);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int k = 0; k < 16; ++k) filler(k);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) p[hf][r] = am[0][0][r] + al[0][0][r] * inv;
+                __syncthreads();
+            }
+            p[0][0] += fm.x[0] + fm.x[11] + tr.x[0] + tr.x[11] + sp.x[0] + __builtin_bit_cast(float, sp.acc & 0x3f800000u);
         } else if (VAR >= 2) {                          // S: same-wave skew -- GEMM of one half with the finish work of the other half between its MFMAs
 #pragma unroll
             for (int hf = 0; hf < 2; ++hf) {
@@ -334,6 +389,12 @@ int main() {
     run<2>("S same-wave skew, 1 MFMA : 4", 256);
     run<3>("S same-wave skew, 1 MFMA : 6", 256);
     run<4>("S same-wave skew, 1 MFMA : 8", 256);
+    run<6>("F fma fillers (192/slot) behind the GEMM", 256);
+    run<5>("F fma fillers between the MFMAs", 256);
+    run<8>("F exp/rcp fillers (192/slot) behind the GEMM", 256);
+    run<7>("F exp/rcp fillers between the MFMAs", 256);
+    run<10>("F split fillers (192/slot) behind the GEMM", 256);
+    run<9>("F split fillers between the MFMAs", 256);
     run<0>("L lockstep, one workgroup", 1);
     run<1>("D de-phased, one workgroup", 1);
     return 0;
