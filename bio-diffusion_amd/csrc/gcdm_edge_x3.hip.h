@@ -206,6 +206,10 @@ __device__ __forceinline__ void x3_prefetch_b(X3Ring<MT, PD>& ring, const WPool&
 // arrays carry X3_TAIL_BLOCKS zero blocks of padding behind the last M-tile, and the LDS reads stay inside the XH8|XL8|VV allocation.
 #define X3_TAIL_BLOCKS 4
 constexpr int X3_PD = 2;         // k-blocks of weight prefetch distance in the edge kernel (register ring of PD + 1 sets)
+#ifndef GCDM_STAMP_K
+#define GCDM_STAMP_K 0              // which residual GCP2 (0..2) carries the per-phase stamps 10..17 of a -DGCDM_STAMPS build
+#endif
+constexpr int X3_TAIL_PER_MFMA = 14;  // tail skew: instructions of N-tile 0's SiLU issued behind each of N-tile 1's last MFMAs (8: +0.3 %)
 constexpr int X3_VEC_PER_MFMA = 6;   // instructions of a vector stage issued behind each MFMA of the hosting k-block (0 / 3 / 4 / 10: +-0.3 %)
 
 template <int MT, int PD>
@@ -277,9 +281,48 @@ __device__ __forceinline__ void static_for(F&& f) {
     }
 }
 
-template <int MT, int NT, int PD, int KB, bool ZAM, bool ZAL>
+struct NoTail {
+    __device__ __forceinline__ void operator()() const {}
+};
+
+// TAIL SKEW (round 4) of a two-N-tile GEMM: the last two k-blocks r0, r0 + 1 run N-tile 0 first (6 MFMAs), then N-tile 1 (6 MFMAs) with `tail()` -- the
+// SiLU of N-tile 0's finished accumulators -- issued between them: a wave's own VALU / transcendental instructions cost ~1-3 clk between its MFMAs
+// instead of 4 / ~11 in a VALU phase (profiles/r04_overlap_experiments.md).  Both blocks' A operands are in the ring anyway (PD = 2), the B operands
+// take the two halves of the double buffer (bh / bl [r0 & 1] must already hold block r0); every accumulator sees its MFMAs in the same order as in
+// the plain loop: same bits.
+template <int PD, int R0, class Tail>
+__device__ __forceinline__ void x3_tail_skew(f32x16 (&am)[1][2], f32x16 (&al)[1][2], X3Ring<1, PD>& ring, h8 (&bh)[2][2], h8 (&bl)[2][2], const h8* sh,
+                                             const h8* sl, int TP, Tail&& tail) {
+    static_assert(PD >= 2, "tail skew: two k-blocks of A operands resident");
+    constexpr int r0 = R0, r1 = R0 + 1, R_ = PD + 1;
+#pragma unroll
+    for (int n = 0; n < 2; ++n) { bh[r1 & 1][n] = sh[r1 * 2 * TP + n * 32]; bl[r1 & 1][n] = sl[r1 * 2 * TP + n * 32]; }
+    x3_wait_block<0>();
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int n = 0; n < 2; ++n) {
+        am[0][n] = MFMA16(ring.ah[r0 % R_][0], bh[r0 & 1][n], am[0][n]);
+        al[0][n] = MFMA16(ring.ah[r0 % R_][0], bl[r0 & 1][n], al[0][n]);
+        al[0][n] = MFMA16(ring.alo[r0 % R_][0], bh[r0 & 1][n], al[0][n]);
+        am[0][n] = MFMA16(ring.ah[r1 % R_][0], bh[r1 & 1][n], am[0][n]);
+        al[0][n] = MFMA16(ring.ah[r1 % R_][0], bl[r1 & 1][n], al[0][n]);
+        al[0][n] = MFMA16(ring.alo[r1 % R_][0], bh[r1 & 1][n], al[0][n]);
+        if (n == 0) __builtin_amdgcn_sched_barrier(0);
+    }
+    tail();
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002 | 0x400, X3_TAIL_PER_MFMA, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+template <int MT, int NT, int PD, int KB, bool ZAM, bool ZAL, class Tail = NoTail>
 __device__ __forceinline__ void tile_gemm_x3z(f32x16 (&am)[MT][NT], f32x16 (&al)[MT][NT], X3Ring<MT, PD>& ring, const WPool& wp, uint32_t wH,
-                                              uint32_t wL, const h8* xh8, const h8* xl8, int TP, int lane) {
+                                              uint32_t wL, const h8* xh8, const h8* xl8, int TP, int lane, Tail&& tail = NoTail{}) {
+    constexpr bool SKEW = !std::is_same<std::decay_t<Tail>, NoTail>::value && NT == 2 && MT == 1 && KB >= 3;
+    constexpr int KBL = SKEW ? KB - 2 : KB;              // k-blocks of the plain loop
     constexpr int R = PD + 1;
     constexpr int wstride = KB * 64;
     // weights: uniform base (SGPR) + compile-time block offset + lane -- no per-block 64-bit VALU pointer arithmetic
@@ -290,13 +333,20 @@ __device__ __forceinline__ void tile_gemm_x3z(f32x16 (&am)[MT][NT], f32x16 (&al)
     const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int n = 0; n < NT; ++n) { bh[0][n] = sh[n * 32]; bl[0][n] = sl[n * 32]; }
-    static_for<0, KB>([&](auto rc) {
+    static_for<0, KBL>([&](auto rc) {
         constexpr int r = decltype(rc)::value;
         auto loads = [&] {
+            if constexpr (r + PD < KB) {             // (the skewed tail needs blocks KB-2, KB-1 and nothing behind them)
 #pragma unroll
             for (int m = MT - 1; m >= 0; --m) ring.alo[(r + PD) % R][m] = wp.template ldk<r + PD>(wL + m * wstride * 16);
 #pragma unroll
             for (int m = MT - 1; m >= 0; --m) ring.ah[(r + PD) % R][m] = wp.template ldk<r + PD>(wH + m * wstride * 16);
+            } else if constexpr (!SKEW) {
+#pragma unroll
+            for (int m = MT - 1; m >= 0; --m) ring.alo[(r + PD) % R][m] = wp.template ldk<r + PD>(wL + m * wstride * 16);
+#pragma unroll
+            for (int m = MT - 1; m >= 0; --m) ring.ah[(r + PD) % R][m] = wp.template ldk<r + PD>(wH + m * wstride * 16);
+            }
         };
         auto breads = [&] {
 #pragma unroll
@@ -331,6 +381,7 @@ __device__ __forceinline__ void tile_gemm_x3z(f32x16 (&am)[MT][NT], f32x16 (&al)
         }
         __builtin_amdgcn_sched_barrier(0);
     });
+    if constexpr (SKEW) x3_tail_skew<PD, KB - 2>(am, al, ring, bh, bl, sh, sl, TP, tail);
 }
 
 // gate partial from registers: contraction over the channels this wave holds (two 16-deep blocks per M-tile)
@@ -692,9 +743,9 @@ struct VecStage {
 
 // Scalar GEMM of a residual GCP2 with the vector stages in its shadow: k-blocks [0, SPLIT) carry hook(stage r) between their MFMAs
 // (vector waves; the others pass a no-op), then a workgroup barrier (the extended-K rows are complete), then k-blocks [SPLIT, KB).
-template <int MT, int NT, int PD, int KB, int SPLIT, bool HOOKED, class Hook>
+template <int MT, int NT, int PD, int KB, int SPLIT, bool HOOKED, class Hook, class Tail = NoTail>
 __device__ __forceinline__ void tile_gemm_x3s(f32x16 (&am)[MT][NT], f32x16 (&al)[MT][NT], X3Ring<MT, PD>& ring, const WPool& wp, uint32_t wH,
-                                              uint32_t wL, const h8* xh8, const h8* xl8, int TP, int lane, Hook&& hook) {
+                                              uint32_t wL, const h8* xh8, const h8* xl8, int TP, int lane, Hook&& hook, Tail&& tail = NoTail{}) {
     constexpr int R = PD + 1;
     constexpr int wstride = KB * 64;
     const int boff = (lane >> 5) * TP + (lane & 31);
@@ -783,7 +834,11 @@ __device__ __forceinline__ void tile_gemm_x3s(f32x16 (&am)[MT][NT], f32x16 (&al)
     __syncthreads();
 #pragma unroll
     for (int n = 0; n < NT; ++n) { bh[SPLIT & 1][n] = sh[SPLIT * 2 * TP + n * 32]; bl[SPLIT & 1][n] = sl[SPLIT * 2 * TP + n * 32]; }
-    static_for<SPLIT, KB>([&](auto rc) { body(rc, std::false_type{}); });
+    if constexpr (std::is_same<std::decay_t<Tail>, NoTail>::value || NT != 2 || MT != 1 || KB - SPLIT != 2) {
+        static_for<SPLIT, KB>([&](auto rc) { body(rc, std::false_type{}); });
+    } else {
+        x3_tail_skew<PD, SPLIT>(am, al, ring, bh, bl, sh, sl, TP, tail);        // (see x3_tail_skew)
+    }
 }
 
 struct EdgeMsgX3Args {
@@ -1209,7 +1264,15 @@ __global__ __launch_bounds__(ET * 8) __attribute__((amdgpu_waves_per_eu(2, 2))) 
                     for (int t = 0; t < 4; ++t) am[m][n][4 * q + t] = in.pqi[m][n][q][t] + in.pqj[m][n][q][t];
 #endif
         STAMP(3);
-        tile_gemm_x3z<MT, NT, PD, KB0C, false, true>(am, al2, ring, wp, o0H, o0L, xh8, xl8, ETP, lane);
+        constexpr int SILU0_N0 = (NT == 2 && MT == 1) ? 1 : 0;       // N-tile 0's SiLU rides in the GEMM's tail (x3_tail_skew)
+        if constexpr (SILU0_N0) {
+            tile_gemm_x3z<MT, NT, PD, KB0C, false, true>(am, al2, ring, wp, o0H, o0L, xh8, xl8, ETP, lane, [&]() {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) st[0][0][r] = silu_scaled(am[0][0][r] + al2[0][0][r] * X3_INV_SCALE);
+            });
+        } else {
+            tile_gemm_x3z<MT, NT, PD, KB0C, false, true>(am, al2, ring, wp, o0H, o0L, xh8, xl8, ETP, lane);
+        }
         x3_prefetch_b<MT, PD>(ring, wp, wp.off(ax.wH[0] + (size_t)mt0 * 18 * 64), wp.off(ax.wL[0] + (size_t)mt0 * 18 * 64), 18);
         GateW<MT> gw0;
         gate_prefetch<MT>(gw0, wp, ax.wg0H, ax.wg0L, mt0);
@@ -1217,7 +1280,7 @@ __global__ __launch_bounds__(ET * 8) __attribute__((amdgpu_waves_per_eu(2, 2))) 
 #pragma unroll
         for (int m = 0; m < MT; ++m)
 #pragma unroll
-            for (int n = 0; n < NT; ++n)
+            for (int n = SILU0_N0; n < NT; ++n)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) st[m][n][r] = silu_scaled(am[m][n][r] + al2[m][n][r] * X3_INV_SCALE);
         STAMP(5);
@@ -1249,29 +1312,36 @@ __global__ __launch_bounds__(ET * 8) __attribute__((amdgpu_waves_per_eu(2, 2))) 
         constexpr int k = decltype(kc)::value;
         const GcpW& w = a.mk[k];
         const uint32_t gwH = wp.off(ax.wH[k] + (size_t)mt0 * 18 * 64), gwL = wp.off(ax.wL[k] + (size_t)mt0 * 18 * 64);
-        if (k == 0) STAMP(10);
+        if (k == GCDM_STAMP_K) STAMP(10);
+        [[maybe_unused]] auto silu_n0 = [&]() {             // SiLU of N-tile 0, issued between the last MFMAs of N-tile 1 (tile_gemm_x3s, tail skew)
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) am[m][0][r] = silu_scaled(am[m][0][r] + al2[m][0][r] * X3_INV_SCALE);
+        };
         if (vhalf == (k & 1)) {
             VecStage<ET, H0, k == 0> vs;
             vs.PG = PG; vs.bg = k == 0 ? a.bg0 : a.mk[k == 0 ? 0 : k - 1].bg; vs.FR = FR; vs.VH = VH; vs.VHB = VHB; vs.VV4 = VV4; vs.XH = XH; vs.XL = XL;
             vs.fA = k == 0 ? ax.vf0H : ax.vf1[k == 0 ? 0 : k - 1]; vs.fB = k == 0 ? ax.vf0L : ax.vf2[k == 0 ? 0 : k - 1];
             vs.pH = ax.vpH[k]; vs.pL = ax.vpL[k];
             vs.ve = ve; vs.vq = vq; vs.lane = lane;
-            tile_gemm_x3s<MT, NT, PD, 18, 16, true>(am, al2, ring, wp, gwH, gwL, xh8, xl8, ETP, lane, [&](auto rc) { vs.template run<decltype(rc)::value>(); });
+            tile_gemm_x3s<MT, NT, PD, 18, 16, true>(am, al2, ring, wp, gwH, gwL, xh8, xl8, ETP, lane, [&](auto rc) { vs.template run<decltype(rc)::value>(); }, silu_n0);
             amax = fmaxf(amax, vs.amax);
         } else {
-            tile_gemm_x3s<MT, NT, PD, 18, 16, false>(am, al2, ring, wp, gwH, gwL, xh8, xl8, ETP, lane, [](auto) {});
+            tile_gemm_x3s<MT, NT, PD, 18, 16, false>(am, al2, ring, wp, gwH, gwL, xh8, xl8, ETP, lane, [](auto) {}, silu_n0);
         }
         if (k < 2) x3_prefetch_b<MT, PD>(ring, wp, wp.off(ax.wH[k < 2 ? k + 1 : 2] + (size_t)mt0 * 18 * 64), wp.off(ax.wL[k < 2 ? k + 1 : 2] + (size_t)mt0 * 18 * 64), 18);
         GateW<MT> gwk;
         gate_prefetch<MT>(gwk, wp, ax.wgH[k], ax.wgL[k], mt0);
-        if (k == 0) STAMP(12);
+        if (k == GCDM_STAMP_K) STAMP(12);
+        constexpr int SILU_N0 = (NT == 2 && MT == 1) ? 1 : 0;      // N-tile 0 was done inside the GEMM's tail
 #pragma unroll
         for (int m = 0; m < MT; ++m)
 #pragma unroll
-            for (int n = 0; n < NT; ++n)
+            for (int n = SILU_N0; n < NT; ++n)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) am[m][n][r] = silu_scaled(am[m][n][r] + al2[m][n][r] * X3_INV_SCALE);
-        if (k == 0) STAMP(13);
+        if (k == GCDM_STAMP_K) STAMP(13);
 #ifndef GCDM_ABL_NOGATE
         gate_partial_x3p<MT, NT, true>(gm, gl, am, gwk);
         // the next tile (clamped to the workgroup's last one: no branch): its index words and per-edge constants are requested behind the last
@@ -1295,12 +1365,12 @@ __global__ __launch_bounds__(ET * 8) __attribute__((amdgpu_waves_per_eu(2, 2))) 
             if (wave >= 4) put_gate_partial<NT, ET>(PG, gm, gl, wave - 4, lane, true);
         }
 #endif
-        if (k == 0) STAMP(14);
+        if (k == GCDM_STAMP_K) STAMP(14);
         // 4 waves: every wave is done reading the old images; gate partials complete.  8 waves: the barrier inside the fold said the first, and
         // the partials are complete at the barrier behind the state images (last GCP2: behind the attention partials)
         if (k == 2) load_const(std::integral_constant<int, 1>{}, a, me, start_ + min(it_ + stride_, cnt_ - 1), in);
         if (NW == 4) __syncthreads();
-        if (k == 0) STAMP(15);
+        if (k == GCDM_STAMP_K) STAMP(15);
 #pragma unroll
         for (int m = 0; m < MT; ++m)
 #pragma unroll
@@ -1368,9 +1438,9 @@ __global__ __launch_bounds__(ET * 8) __attribute__((amdgpu_waves_per_eu(2, 2))) 
             __builtin_amdgcn_sched_barrier(0);
             store_state<MT, NT, false>(XS4, 0, st, ETP, mt0, lane, 0);
         }
-        if (k == 0) STAMP(16);
+        if (k == GCDM_STAMP_K) STAMP(16);
         __syncthreads();
-        if (k == 0) STAMP(17);
+        if (k == GCDM_STAMP_K) STAMP(17);
     });
     STAMP(18);
     over |= amax > X3_RANGE;
