@@ -525,23 +525,15 @@ int gcdm_set_gamma(gcdm_handle* h, const float* host_gamma, int64_t numel) {
     return 0;
 }
 
-int gcdm_finalize_weights(gcdm_handle* h) {
-    if (!h) return -1;
-    DeviceGuard guard(h->cfg.device);
+// One packing pass with the exponent split k (packed weights carry 2^(11-k), X3Const).  Leaves in g_split_absmax the largest magnitude that
+// actually went into an f16 image -- matrices AND what the host folds into them (X3_C factors, the scalar_out biases that ride as the weight
+// column of the constant-1 slot) -- but NOT the parameters that stay fp32 (node-level biases, vector_up tables, ...).
+static int finalize_pass(gcdm_handle* h, int k_shift) {
     const int S = GCDM_S, V = GCDM_V, Se = h->Se, Ve = h->Ve, H0 = h->H0, L = h->L;
     Pool pool;
     g_split_absmax = 0.f;
-    // exponent split of the f16 images: the smallest k whose packed weights 2^(11-k) W stay inside f16 (1.5 x head room for the constants the
-    // host folds into some matrices: X3_C).  Every released / synthetic model so far has k = 0.
-    {
-        float wmax = 0.f;
-        for (const auto& kv : h->host_w)
-            for (float v : kv.second) wmax = (fabsf(v) <= wmax) ? wmax : (v == v ? fabsf(v) : INFINITY);
-        int k = 0;
-        while (k < X3_MAX_SHIFT && 1.5f * wmax * ldexpf(1.0f, 11 - k) >= 65504.0f) ++k;
-        h->x3_shift = k;
-        g_split_w = ldexpf(1.0f, 11 - k);
-    }
+    h->x3_shift = k_shift;
+    g_split_w = ldexpf(1.0f, 11 - k_shift);
     // ---- edge embedding (1,1) -> (Se,Ve), bottleneck 1: H = max(1, Ve) = Ve ------------------------
     size_t o_ws, o_bs, o_wd, o_wdf, o_kap, o_wg, o_bg, o_wd1, o_wdf1, o_kap1, o_exwH, o_exwL, o_exgH, o_exgL;
     {
@@ -797,6 +789,25 @@ int gcdm_finalize_weights(gcdm_handle* h) {
     // the packed images hold 2^(11-k) W in f16: if even k = X3_MAX_SHIFT cannot hold the largest packed weight (or one is NaN) -> fp32 MFMA only
     h->x3_weights_ok = g_split_absmax * g_split_w < 65504.0f;
     g_split_w = 2048.0f;
+    return 0;
+}
+
+int gcdm_finalize_weights(gcdm_handle* h) {
+    if (!h) return -1;
+    DeviceGuard guard(h->cfg.device);
+    // Exponent split of the f16 images: the smallest k whose packed images 2^(11-k) W stay inside f16.  What counts is the largest value that is
+    // actually PACKED, which only the packing itself knows (the host folds constants into some matrices, most biases never enter an image): pack once
+    // with k = 0 -- every released / synthetic model so far stops there -- and, if that overflowed, once more with the k the measured maximum
+    // asks for.  (Round 3 took the maximum over ALL parameters x 1.5: a large fp32-only bias then cost activation range for nothing.)
+    int st = finalize_pass(h, 0);
+    if (st != 0) return st;
+    if (!h->x3_weights_ok) {
+        const float packed_max = g_split_absmax;        // (thread-local, set by the pass above)
+        int k = 0;
+        while (k < X3_MAX_SHIFT && !(packed_max * ldexpf(1.0f, 11 - k) < 65504.0f)) ++k;
+        st = finalize_pass(h, k);
+        if (st != 0) return st;
+    }
     h->finalized = true;
     h->host_w.clear();
     return 0;

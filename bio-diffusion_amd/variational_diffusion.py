@@ -766,6 +766,7 @@ class EquivariantVariationalDiffusion(nn.Module):
                 log.warning("An activation left the f16 range of the split-precision kernels; resuming from step %d with fp32 MFMA.", st0["s"])
                 dyn.set_mfma_mode(0)
                 fell_back = True
+                self.last_range_resume_step = st0["s"]
             return st0["s"]
 
         try:
@@ -817,6 +818,8 @@ class EquivariantVariationalDiffusion(nn.Module):
         if fell_back:
             fl |= _native.FLAG_F16_RANGE          # reported in last_flags: part of this sample was computed with fp32 MFMA
         self.last_range_rewinds = 0 if guard is None else guard.rewinds
+        if not fell_back:
+            self.last_range_resume_step = None
         if fl & _native.FLAG_MEAN_NOT_ZERO:
             raise AssertionError("Mean is not zero: the supplied samples are not centred (assert_mean_zero_with_mask, relative error >= 1e-2)")
         if fl & _native.FLAG_NAN_VEL:
@@ -1181,6 +1184,7 @@ class EquivariantVariationalDiffusion(nn.Module):
                 for w in sb.sl:
                     w["lane"].lib.gcdm_set_option(w["lane"].h, b"mfma_mode", 0)
                 fell_back = True
+                self.last_range_resume_step = st0["s"]
             fence()
             return st0["s"]
 
@@ -1221,6 +1225,8 @@ class EquivariantVariationalDiffusion(nn.Module):
         if fell_back:
             fl |= _native.FLAG_F16_RANGE              # reported in last_flags: part of this sample was computed with fp32 MFMA
         self.last_range_rewinds = 0 if guard is None else guard.rewinds
+        if not fell_back:
+            self.last_range_resume_step = None
         drift = [bool(int(v) & _native.FLAG_COG_DRIFT) for v in fl_all]
         if any(drift) and not all(drift):
             sb.recentre_undrifted(drift)

@@ -479,6 +479,41 @@ def test_large_weights_keep_the_split_precision_mode(big, shift):
     assert net.mfma_mode == 1 and net._lib.gcdm_get_option(net._handle, b"x3_shift") == 0
 
 
+@pytest.mark.parametrize("bias", [1.0e4, 1.0e5])
+def test_split_precision_envelope_at_large_activations(bias):
+    """The worst clean point of the round-4 envelope sweep (tests/gpu_envelope.py): with no LayerNorm in the production configuration
+    (use_gcp_norm false) a trained checkpoint's activations are bounded by nothing but its weights, so the last feed-forward bias of EVERY layer is
+    set to +-1e4 / +-1e5 (h grows to ~1e6, the feed-forward hidden activations beyond): the exponent split stays k = 0 (a bias that never enters an
+    f16 image must not cost activation range -- round 3 counted it), the range flag stays clear, and against the oracle in fp64 the split-precision
+    forward is as accurate as plain fp32 (bar: 4 x the fp32 oracle's own distance from fp64 + 1e-6 max|out|)."""
+    d = _dims("qm9")
+    cfgs = pkg.default_cfgs("qm9", ())
+    net = pkg.GCPNetDynamics(**cfgs)
+    W = synth.make_weights(synth.dynamics_shapes(d["S"], d["V"], d["Se"], d["Ve"], d["L"], synth.dims_h_in(d)), seed=29, scale_2d=0.25)
+    for l in range(d["L"]):
+        b = W[f"interaction_layers.{l}.feedforward_network.0.scalar_out.2.bias"]
+        b.copy_(torch.where(torch.arange(b.numel()) % 2 == 0, bias, -bias).to(b.dtype))
+    net.load_state_dict(W)
+    net = net.cuda().eval()
+    net._ensure_handle(torch.device("cuda"))
+    net.sync_weights()
+    assert net.mfma_mode == 1 and net._lib.gcdm_get_option(net._handle, b"x3_shift") == 0
+    xh, t, bi, nn_, _ = synth.make_inputs([19, 7, 30, 12], synth.dims_feat(d), seed=6)
+    ocfg = _ocfg("qm9")
+    r32 = O.dynamics_forward(W, ocfg, xh, t, bi, None, None).double()
+    r64 = O.dynamics_forward({k_: v.double() for k_, v in W.items()}, ocfg, xh.double(), t.double(), bi, None, None)
+    out = _fwd(net, xh, t, bi).double()
+    assert (net.read_flags() & pkg._native.FLAG_F16_RANGE) == 0 and torch.isfinite(out).all()
+    scale = r64.abs().max().item()
+    e_hip, e_ref = (out - r64).abs().max().item(), (r32 - r64).abs().max().item()
+    print(f"bias {bias:g}: max|out| {scale:.3e}  |f16x3 - fp64| {e_hip:.2e}  |fp32 oracle - fp64| {e_ref:.2e}")
+    assert e_hip <= 4.0 * e_ref + 1e-6 * scale
+    net.set_mfma_mode(0)
+    e32 = (_fwd(net, xh, t, bi).double() - r64).abs().max().item()
+    net.set_mfma_mode(1)
+    assert e32 <= 4.0 * e_ref + 1e-6 * scale
+
+
 def test_weights_outside_every_exponent_split_use_fp32_mfma():
     """Beyond the largest shift (|W| >= ~1400 with the head room of the folded constants) or a non-finite weight: gcdm_finalize_weights switches
     the handle to fp32 MFMA, refuses mode 1, and the forward still matches the oracle."""
