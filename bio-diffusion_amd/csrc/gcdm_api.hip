@@ -3,6 +3,7 @@
 #include "gcdm_kernels.hip.h"
 #include "gcdm_edge_x3.hip.h"
 #include "gcdm_node_x3.hip.h"
+#include "gcdm_node_x3w.hip.h"
 #include "gcdm_embed_x3.hip.h"
 #include "gcdm_stability.hip.h"
 #include "../../include/gcdm_hip.h"
@@ -84,6 +85,8 @@ struct gcdm_handle {
     int tile() const { return edge_tile ? edge_tile : 64; }
     int cus = 256;                   // compute units of the device (persistent edge-message workgroups: one per CU)
     int persistent = 1;              // option "persistent" / env GCDM_PERSISTENT=0: one workgroup per tile (round 2 schedule; A/B runs)
+    int node_tile = 0;               // option "node_tile" / env GCDM_NODE_TILE: nodes per workgroup of the split-precision layer node kernel (64: k_node_x3w,
+                                     // 32: k_node_x3, 0 = automatic: whichever needs less time for this plan's node count, see node_tile_for)
     bool x3_weights_ok = true;       // every GEMM weight fits the split-precision images at some exponent split k <= X3_MAX_SHIFT; else mfma_mode 1 is refused
     int x3_shift = 0;                // k: packed weights carry 2^(11-k), activation images 2^(k-11) (X3Const, gcdm_edge_x3.hip.h)
     X3Const x3c() const { const float w = ldexpf(1.0f, 11 - x3_shift); return X3Const{1.0f / w, w, 1.0f / w, 6.0e4f * w}; }
@@ -488,6 +491,7 @@ int gcdm_create(const GcdmConfig* cfg, gcdm_handle** out) {
     if (const char* et = getenv("GCDM_EDGE_TILE")) h->edge_tile = (atoi(et) == 32) ? 32 : 64;
     if (const char* mm = getenv("GCDM_MFMA")) h->mfma_x3 = (std::strcmp(mm, "f16x3") == 0) ? 1 : 0;
     if (const char* pe = getenv("GCDM_PERSISTENT")) h->persistent = atoi(pe) ? 1 : 0;
+    if (const char* nt = getenv("GCDM_NODE_TILE")) h->node_tile = atoi(nt) == 32 ? 32 : atoi(nt) == 64 ? 64 : 0;
     DeviceGuard guard(cfg->device);
     {
         int n = 0;
@@ -780,7 +784,7 @@ static int finalize_pass(gcdm_handle* h, int k_shift) {
             set_lds_attr(h, k_edge_msg<64, 16, 32>, EdgeGeo<32>::LDS_BYTES) || set_lds_attr(h, k_edge_msg<16, 8, 32>, EdgeGeo<32>::LDS_BYTES) ||
             set_lds_attr(h, k_edge_msg_x3<64, 16, 64>, EdgeGeo<64>::LDS_BYTES_X3) || set_lds_attr(h, k_edge_msg_x3<16, 8, 64>, EdgeGeo<64>::LDS_BYTES_X3) ||
             set_lds_attr(h, k_edge_msg_x3<64, 16, 32>, EdgeGeo<32>::LDS_BYTES_X3) || set_lds_attr(h, k_edge_msg_x3<16, 8, 32>, EdgeGeo<32>::LDS_BYTES_X3) ||
-            set_lds_attr(h, k_node_x3<true>, NK_LDS_BYTES) || set_lds_attr(h, k_node_x3<false>, NK_LDS_BYTES) ||
+            set_lds_attr(h, k_node_x3<true>, NK_LDS_BYTES) || set_lds_attr(h, k_node_x3<false>, NK_LDS_BYTES) || set_lds_attr(h, k_node_x3w, NW_LDS_BYTES) ||
             set_lds_attr(h, k_node<true>, NK_LDS_BYTES) || set_lds_attr(h, k_node<false>, NK_LDS_BYTES) ||
             set_lds_attr(h, k_node_x3<true, 4>, NK_LDS_BYTES) || set_lds_attr(h, k_node<true, 4>, NK_LDS_BYTES))
             return -1;
@@ -927,6 +931,17 @@ int gcdm_debug_set_layer_limit(gcdm_handle* h, int32_t n) {
     return 0;
 }
 
+// Tile size of the split-precision layer node kernel.  A 64-node tile streams each weight byte for twice the nodes, but takes ~1.55x the time of a
+// 32-node tile (its load / vector / epilogue phases double, only its GEMM phases do not: 54-71 us against 37-42 us, tests/gpu_node_time.py), and
+// the launch is a whole number of rounds over the CUs: 64-node tiles win where they save a round (GEOM 256 x 44 on one handle: 2 -> 1; a 512-molecule
+// QM9 slice: 2 -> 1), and lose where they do not (QM9 1024 x 19 on one handle: 3 rounds of 32 against 2 of 64).  Same bits either way.
+static int node_tile_for(const gcdm_handle* h, int N) {
+    if (h->node_tile) return h->node_tile;
+    const int cus = h->cus > 0 ? h->cus : 256;
+    const int r32 = ((N + 31) / 32 + cus - 1) / cus, r64 = ((N + 63) / 64 + cus - 1) / cus;
+    return 1.55f * r64 < (float)r32 ? 64 : 32;
+}
+
 int gcdm_forward(gcdm_handle* h, const float* xh, const float* t, const float* context, float* out, uint32_t* flags, void* stream_) {
     return gcdm_forward_sc(h, xh, nullptr, t, context, out, flags, stream_);
 }
@@ -995,6 +1010,7 @@ int gcdm_forward_sc(gcdm_handle* h, const float* xh, const float* xh_sc, const f
             if (next_layer < h->L) { nx.wpqH = h->layers[next_layer].wpqH; nx.wpqL = h->layers[next_layer].wpqL; nx.vdH = h->layers[next_layer].vdH; nx.vdL = h->layers[next_layer].vdL; nx.bpqx = h->layers[next_layer].bpqx; }
             if (embed && h->sc) hipLaunchKernelGGL((k_node_x3<true, 4>), dim3(ngrid), dim3(NX_THREADS), NK_LDS_BYTES, st, nx);
             else if (embed) hipLaunchKernelGGL(k_node_x3<true>, dim3(ngrid), dim3(NX_THREADS), NK_LDS_BYTES, st, nx);
+            else if (node_tile_for(h, N) == 64 && !nx.prof) hipLaunchKernelGGL(k_node_x3w, dim3((N + NW_T - 1) / NW_T), dim3(512), NW_LDS_BYTES, st, nx);
             else hipLaunchKernelGGL(k_node_x3<false>, dim3(ngrid), dim3(NX_THREADS), NK_LDS_BYTES, st, nx);
         } else {
             if (embed && h->sc) hipLaunchKernelGGL((k_node<true, 4>), dim3(ngrid), dim3(256), NK_LDS_BYTES, st, na);
@@ -1274,6 +1290,11 @@ int gcdm_set_option(gcdm_handle* h, const char* name, int32_t value) {
     if (k == "flat_next") { h->flat_next = value ? 1 : 0; return 0; }
     if (k == "node_base") { if (value < 0) return fail(h, "gcdm_set_option(node_base): >= 0"); h->node_base = (uint32_t)value; return 0; }
     if (k == "persistent") { h->persistent = value ? 1 : 0; return 0; }
+    if (k == "node_tile") {
+        if (value != 0 && value != 32 && value != 64) return fail(h, "gcdm_set_option: node_tile must be 0 (automatic), 32 or 64");
+        h->node_tile = value;
+        return 0;
+    }
     if (k == "edge_tile") {
         if (value != 0 && value != 32 && value != 64) return fail(h, "gcdm_set_option(edge_tile): 0 (automatic), 32 or 64");
         h->edge_tile = value;
@@ -1294,6 +1315,7 @@ int gcdm_get_option(const gcdm_handle* h, const char* name) {
     if (k == "node_base") return (int)h->node_base;
     if (k == "x3_shift") return h->x3_shift;
     if (k == "persistent") return h->persistent;
+    if (k == "node_tile") return h->node_tile;
     return -1;
 }
 

@@ -192,6 +192,8 @@ int gcdm_debug_set_layer_limit(gcdm_handle* h, int32_t num_layers_to_run);
  * current one the 64-edge tile (every weight byte read once per 64 edges) is the faster one for both edge widths, DESIGN.md 3.4.
  * "persistent": 1 (default; env GCDM_PERSISTENT) / 0 -- the split-precision edge-message kernel as one workgroup per CU (two at 32-edge tiles) that walks
  * the tile list with the next tile's operands prefetched, whenever there are more tiles than that; 0: one workgroup per tile (A/B runs).  Same bits.
+ * "node_tile": nodes per workgroup of the split-precision per-layer node kernel: 64 (every streamed weight byte feeds two 32-node MFMA tiles), 32, or
+ * 0 = automatic (default; env GCDM_NODE_TILE): whichever needs fewer CU rounds for the plan's node count.  Same bits.
  * "cog_fix": 1 (default) / 0, see gcdm_unnormalize_z.
  * "fix_noise" (0/1): the x-part of every noise draw is centred over the whole flat batch instead of per molecule, as the reference's
  * `fix_noise=True` does (variational_diffusion.py:832-834, 1323-1325; used by sample_sweep_conditionally, src/models/__init__.py:200-226).

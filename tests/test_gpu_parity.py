@@ -488,6 +488,34 @@ def test_large_weights_keep_the_split_precision_mode(big, shift):
     assert net.mfma_mode == 1 and net._lib.gcdm_get_option(net._handle, b"x3_shift") == 0
 
 
+@pytest.mark.parametrize("case,num_nodes", [("qm9", [19] * 70 + [3, 29, 1]), ("geom", [44, 181, 3, 90, 17, 64, 65, 63]), ("qm9cond", [7, 19, 4, 12, 23])])
+def test_node_tile_sizes_agree_bitwise(case, num_nodes):
+    """The 64-node tiles of the split-precision layer node kernel (k_node_x3w, round 4) run every contraction in the k-block order of the 32-node kernel:
+    outputs of a full forward are bit-identical for both tile sizes -- node counts that are no multiple of 64, rows cut by edge-tile boundaries, a
+    partial node mask, the context-conditional width -- and the automatic choice is one of the two."""
+    d = _dims(case)
+    net, W, cfgs = _net(case, seed=33, scale=0.5, mode=1)
+    lib, h = net._lib, net._handle
+    xh, t, bi, nn_, ctx = synth.make_inputs(num_nodes, synth.dims_feat(d), seed=8, n_ctx=d["n_ctx"])
+    dev = torch.device("cuda")
+    mask = torch.ones(len(bi), dtype=torch.bool)
+    outs = {}
+    for masked in (False, True):
+        if masked:
+            mask[1::5] = False
+            mask[0] = True
+        batch = dict(batch=bi.to(dev), mask=mask.to(dev), props_context=None if ctx is None else ctx.to(dev))
+        for nt in (32, 64, 0):
+            assert lib.gcdm_set_option(h, b"node_tile", nt) == 0 and lib.gcdm_get_option(h, b"node_tile") == nt
+            _, out = net(batch, xh.to(dev), t.to(dev))
+            torch.cuda.synchronize()
+            outs[(masked, nt)] = out.cpu()
+        assert torch.isfinite(outs[(masked, 32)]).all()
+        assert torch.equal(outs[(masked, 32)], outs[(masked, 64)]) and torch.equal(outs[(masked, 32)], outs[(masked, 0)])
+    assert lib.gcdm_set_option(h, b"node_tile", 48) != 0
+    lib.gcdm_set_option(h, b"node_tile", 0)
+
+
 @pytest.mark.parametrize("bias", [1.0e4, 1.0e5])
 def test_split_precision_envelope_at_large_activations(bias):
     """The worst clean point of the round-4 envelope sweep (tests/gpu_envelope.py): with no LayerNorm in the production configuration
