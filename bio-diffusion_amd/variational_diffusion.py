@@ -840,12 +840,15 @@ class EquivariantVariationalDiffusion(nn.Module):
         The reference method raises on every call (:1650, :1177); this is that method with the two tokens repaired (include/gcdm_hip.h,
         DESIGN.md 7), pinned by tests/golden/inpaint_small_qm9.npz.  ``noise_fn(k)``: the k-th raw draw in the reference's order -- z_T, then
         per step [known part, model step, self-conditioning estimate if any], one per jump back, and the final decode."""
-        if generate_x_only:
-            raise NotImplementedError("inpaint (HIP): generate_x_only is not built")
         num_timesteps = self.T if num_timesteps is None else num_timesteps
         assert 0 < return_frames <= num_timesteps, "Number of frames cannot be greater than number of timesteps."
         assert num_timesteps % return_frames == 0, "Number of frames must be evenly divisible by number of timesteps."
         assert jump_length == 1 or return_frames == 1, "Chain visualization is only implemented for `jump_length=1`"
+        if (generate_x_only or getattr(self.dynamics_network, "fused_unsupported", None) is not None
+                or getattr(self.dynamics_network, "path", "auto") == "modules"):
+            # position-only diffusion (a dynamics network without node features) and configurations off the fused kernels: the general loop
+            return self._inpaint_modules(molecule, node_mask_fixed, num_resamplings, jump_length, return_frames, num_timesteps, context,
+                                         generate_x_only, noise_fn, seed)
         num_nodes = torch.as_tensor(molecule["num_nodes"])
         device = torch.device(molecule["x"].device)
         dyn, lib, h = self._native(device)
@@ -934,6 +937,118 @@ class EquivariantVariationalDiffusion(nn.Module):
             log.warning("CoG drift above 5e-2. Projected the positions down.")
         self.last_flags = fl
         return out if return_frames == 1 else frames
+
+    def sample_p_zt_given_zs(self, zs, batch_index, node_mask, gamma_t, gamma_s, generate_x_only: bool = False, noise: Optional[torch.Tensor] = None,
+                             generator: Optional[torch.Generator] = None):
+        """The forward jump z_s -> z_t of RePaint (variational_diffusion.py:1163-1201) WITH the reference's crashing token repaired: `:1177` indexes
+        a [B, 1] factor with the [N] node mask; every sibling gathers per-molecule factors with `[batch_index]`, and so does this.  ``gamma_*``:
+        [B, 1] (the reference inflates them to [B, 1] as well)."""
+        _, sigma_t_given_s, alpha_t_given_s = self.sigma_and_alpha_t_given_s(gamma_t, gamma_s, zs)
+        B = int(gamma_t.shape[0])
+        if noise is None:
+            eps = self.sample_combined_position_feature_noise(batch_index, node_mask, generate_x_only=generate_x_only, generator=generator, num_graphs=B)
+        else:
+            m = node_mask.float().unsqueeze(-1)
+            eps = torch.cat([_segment_mean_sub(noise[:, : self.num_x_dims] * m, batch_index, B, node_mask), noise[:, self.num_x_dims:] * m], dim=-1)
+        zt = alpha_t_given_s[batch_index] * zs + sigma_t_given_s[batch_index] * eps
+        zx = _segment_mean_sub(zt[:, : self.num_x_dims], batch_index, B, node_mask)
+        return zx if generate_x_only else torch.cat([zx, zt[:, self.num_x_dims:]], dim=-1)
+
+    def _inpaint_modules(self, molecule, node_mask_fixed, num_resamplings, jump_length, return_frames, num_timesteps, context, generate_x_only,
+                         noise_fn, seed):
+        """inpaint (:1582-1789, the two repairs of the fused method's docstring) step by step through the reference-signature methods of this class:
+        torch algebra on the device around one network evaluation per step.  Serves ``generate_x_only`` (position-only diffusion: the molecule is
+        its positions, z = z_x, [N, 3] out -- the dynamics network must be built without node features, as for mol_gen_sample) and configurations
+        the fused kernels are not built for.  ``noise_fn(k)``: raw draws in the reference's order; otherwise a device generator seeded with ``seed``."""
+        device = torch.device(molecule["x"].device)
+        nx = self.num_x_dims
+        if generate_x_only and getattr(self.dynamics_network, "num_atom_types", 0) + int(getattr(self.dynamics_network, "include_charges", False)) > 0:
+            raise ValueError("generate_x_only needs a dynamics network built without node features (num_atom_types = 0, include_charges = False); "
+                             "the reference fails on the feature width of this one too (gcpnet.py:1093-1110)")
+        num_nodes = torch.as_tensor(molecule["num_nodes"])
+        B = len(num_nodes)
+        bi = num_nodes_to_batch_index(B, num_nodes.to(device), device=device)
+        if "batch_index" in molecule and not torch.equal(molecule["batch_index"].to(device), bi):
+            raise ValueError("molecule['batch_index'] must be the contiguous index implied by molecule['num_nodes']")
+        ones = torch.ones_like(bi).bool()
+        fixed = node_mask_fixed.to(device).bool()
+        if context is not None:
+            context = context.to(device)[bi]
+        if generate_x_only:
+            xh0 = molecule["x"].to(device, torch.float32).clone()
+        else:
+            parts = [molecule["x"], molecule["one_hot"]] + ([molecule["charges"]] if self.include_charges else [])
+            xh0 = torch.cat([p_.to(device, torch.float32) for p_ in parts], dim=-1)
+
+        def fixed_mean(x):                                   # scatter(x[fixed], batch_index[fixed], reduce="mean"), one row per molecule (0 where none is fixed)
+            f = fixed.float().unsqueeze(-1)
+            sums = torch.zeros((B, x.shape[1]), device=device).index_add_(0, bi, x * f)
+            cnt = torch.zeros(B, device=device).index_add_(0, bi, fixed.float()).clamp(min=1)
+            return sums / cnt[:, None]
+
+        xh0[:, :nx] = xh0[:, :nx] - fixed_mean(xh0[:, :nx])[bi]                    # :1625-1633
+        k = [0]
+        gen = None
+        if noise_fn is None:
+            gen = torch.Generator(device=device)
+            gen.manual_seed(int(seed))
+
+        def draw():
+            if noise_fn is None:
+                return None
+            k[0] += 1
+            return noise_fn(k[0] - 1).to(device, torch.float32)
+
+        raw = draw()
+        if raw is None:
+            z = self.sample_combined_position_feature_noise(bi, ones, generate_x_only=generate_x_only, generator=gen, num_graphs=B)
+        else:
+            z = torch.cat((_segment_mean_sub(raw[:, :nx], bi, B, ones), raw[:, nx:]), dim=-1)
+        out = torch.zeros((return_frames,) + tuple(z.shape), device=device)
+        schedule = repaint_schedule(num_resamplings, jump_length, num_timesteps)
+        self_cond_on = bool(cfg_get(self.diffusion_cfg, "self_condition", False))
+        self_cond = None
+        s = num_timesteps - 1
+        fm = fixed.float().unsqueeze(-1)
+        for i, num_denoise_steps in enumerate(schedule):
+            for j in range(num_denoise_steps):
+                s_arr = torch.full((B, 1), s / num_timesteps, device=device)
+                t_arr = torch.full((B, 1), (s + 1) / num_timesteps, device=device)
+                gamma_s = self.gamma(s_arr)
+                rk = draw()
+                if rk is None and gen is not None:
+                    rk = torch.randn(xh0.shape, device=device, generator=gen)
+                z_known, _ = self.compute_noised_representation(xh0, bi, ones, gamma_s, generate_x_only=generate_x_only, eps=rk)
+                z_unknown = self.sample_p_zs_given_zt(s=s_arr, t=t_arr, z=z, batch_index=bi, node_mask=ones, context=context,
+                                                      generate_x_only=generate_x_only, xh_self_cond=self_cond, noise=draw(), generator=gen)
+                if self_cond_on:
+                    self_cond = self.sample_p_zs_given_zt(s=torch.zeros_like(s_arr), t=s_arr, z=z_unknown, batch_index=bi, node_mask=ones, context=context,
+                                                          generate_x_only=generate_x_only, self_condition=True, noise=draw(), generator=gen)
+                shift = fixed_mean(z_unknown[:, :nx]) - fixed_mean(z_known[:, :nx])       # :1680-1697
+                z_known = torch.cat((z_known[:, :nx] + shift[bi], z_known[:, nx:]), dim=-1)
+                z = z_known * fm + z_unknown * (1 - fm)
+                self.assert_mean_zero_with_mask(z[:, :nx], ones)
+                if (num_denoise_steps > jump_length or i == len(schedule) - 1) and (s * return_frames) % num_timesteps == 0:
+                    out[(s * return_frames) // num_timesteps] = self.unnormalize_z(z, ones, generate_x_only=generate_x_only)
+                if j == num_denoise_steps - 1 and i < len(schedule) - 1:                  # go back `jump_length` steps (:1717-1737)
+                    t = s + jump_length
+                    gamma_t = self.gamma(torch.full((B, 1), t / num_timesteps, device=device))
+                    z = self.sample_p_zt_given_zs(z, bi, ones, gamma_t, gamma_s, generate_x_only=generate_x_only, noise=draw(), generator=gen)
+                    s = t
+                s -= 1
+        x, h = self.sample_p_xh_given_z0(z_0=z, batch_index=bi, node_mask=ones, batch_size=B, context=context, generate_x_only=generate_x_only,
+                                         xh_self_cond=self_cond, noise=draw(), generator=gen)
+        self.assert_mean_zero_with_mask(x, ones)
+        if return_frames == 1:
+            cog = torch.zeros(B, nx, device=device).index_add_(0, bi, x).abs().max().item()
+            if cog > 5e-2:
+                x = _segment_mean_sub(x, bi, B, ones)
+        if generate_x_only:
+            out[0] = x
+        else:
+            out[0] = torch.cat([x, h["categorical"].to(x.dtype)] + ([h["integer"].to(x.dtype)] if self.include_charges else []), dim=-1)
+        self.last_flags = 0
+        return out.squeeze(0)
 
     # ---- several independent batches in flight (evaluation driver) -------------------------------------------------------------
     class _Lane:

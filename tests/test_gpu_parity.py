@@ -763,6 +763,20 @@ def test_inpaint_matches_oracle(selfcond):
         if kw["return_frames"] > 1:
             assert (out[1:] - want[1:]).abs().max().item() <= TOL * scale and want[1:].abs().max().item() > 0
     assert torch.equal(mol["x"].cpu(), x)                          # the caller's molecule is not modified
+    # the general loop (module path: what configurations off the fused kernels and generate_x_only take) gives the oracle's numbers too
+    net.path = "modules"
+    try:
+        for kw in runs:
+            want = O.inpaint(W, ocfg, x, oh, ch, nn_, fixed, O.TapeNoise(1234), **kw)
+            tape = O.TapeNoise(1234)
+            out = ddpm.inpaint(mol, fixed.cuda(), noise_fn=lambda k, _t=tape: torch.cat((_t(N, 3), _t(N, F_)), dim=-1), **kw).cpu()
+            scale = max(1.0, want.abs().max().item())
+            last, lw = (out, want) if kw["return_frames"] == 1 else (out[0], want[0])
+            assert out.shape == want.shape and (last[:, :3] - lw[:, :3]).abs().max().item() <= TOL * scale and torch.equal(last[:, 3:], lw[:, 3:])
+            if kw["return_frames"] > 1:
+                assert (out[1:] - want[1:]).abs().max().item() <= TOL * scale
+    finally:
+        net.path = "auto"
     # Philox noise: deterministic, finite, seed-dependent; the schedule method is the reference's
     a = ddpm.inpaint(mol, fixed.cuda(), num_resamplings=2, jump_length=2, num_timesteps=6, seed=5).clone()
     b = ddpm.inpaint(mol, fixed.cuda(), num_resamplings=2, jump_length=2, num_timesteps=6, seed=5)

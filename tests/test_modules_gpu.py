@@ -366,6 +366,45 @@ def test_position_only_sampling_matches_reference_golden(golden_dir):
         ddpm_full.mol_gen_sample(num_samples=2, num_nodes=torch.tensor([3, 4]), device=DEV, num_timesteps=2, generate_x_only=True)
 
 
+def test_position_only_inpainting_matches_reference_golden(golden_dir):
+    """`inpaint(..., generate_x_only=True)` (variational_diffusion.py:1582-1789 with the two repairs of make_inpaint_golden.py) around a dynamics network
+    built without node features, against the repaired reference's own runs on the same noise tape (make_inpaint_xonly_golden.py): a jump schedule and
+    chain frames, within 4 |ref32 - ref64| + 1e-4 max|x|; the caller's molecule is left untouched (the reference shifts it in place)."""
+    g = np.load(os.path.join(golden_dir, "inpaint_xonly_qm9.npz"))
+    cfgs = _xonly_cfgs()
+    net = pkg.GCPNetDynamics(**cfgs)
+    want = {k: tuple(int(x) for x in sh.split(",")) if sh else () for k, sh in zip(g["keys"].tolist(), g["shapes"].tolist())}
+    shapes = {k: tuple(v.shape) for k, v in net.state_dict().items()}
+    assert shapes == want and list(shapes) == list(want)
+    net.load_state_dict(synth.make_weights(shapes, seed=int(g["weight_seed"]), scale_2d=float(g["weight_scale"])))
+    net = net.to(DEV)
+    ddpm = pkg.EquivariantVariationalDiffusion(net, cfgs["diffusion_cfg"], cfgs["dataloader_cfg"], pkg.dataset_info("qm9")).to(DEV).eval()
+    nn_ = torch.tensor(g["num_nodes"])
+    N = int(nn_.sum())
+    x, fixed = torch.tensor(g["x"]), torch.tensor(g["fixed"])
+    for name in ("jump", "frames"):
+        R, J, T, Fr = (int(v) for v in g[f"{name}_kw"])
+        tape = O.TapeNoise(int(g["noise_seed"]))
+        seen = []
+        def noise_fn(k, _t=tape, _s=seen):
+            assert k == len(_s)
+            _s.append(k)
+            return _t(N, 3)
+        mol = dict(x=x.to(DEV), num_nodes=nn_)
+        out = ddpm.inpaint(mol, fixed.to(DEV), num_resamplings=R, jump_length=J, num_timesteps=T, return_frames=Fr, generate_x_only=True, noise_fn=noise_fn).cpu().double()
+        r32, r64 = torch.tensor(g[f"{name}_out32"]).double(), torch.tensor(g[f"{name}_out64"])
+        assert out.shape == r32.shape and len(seen) == int(g[f"{name}_draws"])          # the reference's number of randn calls
+        bound = 4.0 * (r32 - r64).abs().max().item() + 1e-4 * r64.abs().max().item()
+        assert (out - r32).abs().max().item() <= bound, name
+        assert torch.equal(mol["x"].cpu(), x)
+    # seeded device noise: reproducible, seed-dependent
+    mol = dict(x=x.to(DEV), num_nodes=nn_)
+    a = ddpm.inpaint(mol, fixed.to(DEV), num_resamplings=2, jump_length=2, num_timesteps=6, generate_x_only=True, seed=3)
+    b = ddpm.inpaint(mol, fixed.to(DEV), num_resamplings=2, jump_length=2, num_timesteps=6, generate_x_only=True, seed=3)
+    c = ddpm.inpaint(mol, fixed.to(DEV), num_resamplings=2, jump_length=2, num_timesteps=6, generate_x_only=True, seed=4)
+    assert torch.equal(a, b) and torch.isfinite(a).all() and not torch.equal(a, c) and tuple(a.shape) == (N, 3)
+
+
 def test_module_path_sampling_loop_matches_oracle():
     """The general sampling loop (reference-signature sample_p_zs_given_zt / sample_p_xh_given_z0 of this package, network on the module
     path) against the oracle's mol_gen_sample on the same tape: production configuration forced onto the module path, 10 steps."""

@@ -9,7 +9,7 @@ export TMPDIR=/tmp
 cd /tmp
 # --lanes 1: whole-batch launches, i.e. what bench.py's roofline object measures (the timed loop of the default run uses 2 slices)
 # GCDM_MFMA=f32 in the environment profiles the exact-fp32 MFMA kernel family instead of the default split-precision one
-B="python $ROOT/bench.py --workload $WL --lanes 1 --steps 6 --warmup 2 --no-cpu-baseline --no-fp32-timing --no-other-configs --no-extras"
+B="python $ROOT/bench.py --workload $WL --lanes 1 --steps 6 --warmup 2 --no-cpu-baseline --no-fp32-timing --no-other-configs --no-extras --no-full-sample"
 run() { local name=$1; shift; (timeout 280 rocprofv3 --kernel-trace "$@" --output-format csv -d $OUT/${TAG}_$name -- $B > $OUT/${TAG}_$name.log 2>&1; echo "$name exit=$?"); }
 run stats --stats
 run pmc1 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F16 SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS SQ_INSTS_VALU

@@ -21,8 +21,8 @@ cp $OUT/${TAG}_pmc_summary_qm9_x3.json $OUT/${TAG}_pmc_summary_geom_x3.json prof
 for d in ${TAG} ${TAG}g ${TAG}f32; do f=$(ls -t $OUT/${d}_stats/*/*kernel_stats.csv 2>/dev/null | head -1); [ -n "$f" ] && cp "$f" $OUT/${d}_kernel_stats.csv; done
 # raw counter dumps are large: keep the summaries and the per-kernel stats only
 rm -rf $OUT/${TAG}_pmc[1-4] $OUT/${TAG}g_pmc[1-4] $OUT/${TAG}f32_pmc1 $OUT/${TAG}_stats $OUT/${TAG}g_stats $OUT/${TAG}f32_stats
-timeout 280 python bench.py --steps 100 --warmup 5 > $OUT/${TAG}_bench_qm9.json 2> $OUT/${TAG}_bench_qm9.err
-timeout 200 python bench.py --workload geom --steps 100 --warmup 5 --no-cpu-baseline > $OUT/${TAG}_bench_geom.json 2> $OUT/${TAG}_bench_geom.err
+timeout 400 python bench.py --steps 100 --warmup 5 > $OUT/${TAG}_bench_qm9.json 2> $OUT/${TAG}_bench_qm9.err
+timeout 250 python bench.py --workload geom --steps 100 --warmup 5 --no-cpu-baseline > $OUT/${TAG}_bench_geom.json 2> $OUT/${TAG}_bench_geom.err
 timeout 200 python bench.py --lanes 1 --steps 100 --warmup 5 --no-cpu-baseline --no-other-configs > $OUT/${TAG}_bench_qm9_lanes1.json 2> $OUT/${TAG}_bench_lanes1.err
 # in-kernel phase stamps need the -DGCDM_STAMPS build (tools/build_variants.sh stamps:-DGCDM_STAMPS -> build/ab/libgcdm_stamps.so)
 if [ -f build/ab/libgcdm_stamps.so ]; then
