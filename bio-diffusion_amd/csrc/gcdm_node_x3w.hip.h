@@ -33,20 +33,21 @@ constexpr int NW_LDS_BYTES = NW_OFF_WUP + (GCDM_V * 16 + GCDM_V) * 4;
 static_assert(NW_LDS_BYTES <= 160 * 1024, "k_node_x3w: LDS budget");
 constexpr int NW_PG3_ROW = 57;                        // first VH row of gate-partial slot 3
 
-// gate-partial element (slot, channel c, node e): slots 0-2 in VV rows 0-95, slot 3 in VH rows 57-88
-__device__ __forceinline__ float* nw_pg(float* VV, float* VH, int slot, int c, int e) {
-    return slot < 3 ? VV + (slot * 32 + c) * NW_TP + e : VH + (NW_PG3_ROW + c) * NW_TP + e;
+// gate-partial slot base (element (c, e) at base[c * NW_TP + e]): slots 0-2 in VV rows 0-95, slot 3 in VH rows 57-88
+__device__ __forceinline__ float* nw_pg_slot(float* VV, float* VH, int slot) {
+    return slot < 3 ? VV + slot * 32 * NW_TP : VH + NW_PG3_ROW * NW_TP;
 }
 
 template <int NT>
 __device__ __forceinline__ void nw_put_gate_partial(float* VV, float* VH, const f32x16 (&gm)[NT], const f32x16 (&gl)[NT], int slot, int lane, bool add) {
     const int half = lane >> 5, l31 = lane & 31;
+    float* base = nw_pg_slot(VV, VH, slot);
 #pragma unroll
     for (int n = 0; n < NT; ++n)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int c = (r & 3) + 8 * (r >> 2) + 4 * half;
-            float* p = nw_pg(VV, VH, slot, c, 32 * n + l31);
+            float* p = base + c * NW_TP + 32 * n + l31;
             const float v = gm[n][r] + gl[n][r] * X3_INV_SCALE;
             *p = add ? *p + v : v;
         }
@@ -69,7 +70,7 @@ __device__ __forceinline__ void nw_vec_finish(float* VV, float* VHm, WFn wup, BF
         if (c < V_out) {
             float g = bgf(i, c);
 #pragma unroll
-            for (int w = 0; w < 4; ++w) g += *nw_pg(VV, VHm, w, c, e);
+            for (int w = 0; w < 4; ++w) g += nw_pg_slot(VV, VHm, w)[c * TP + e];
             const float sg = fast_sigmoid(g);
             float ox = 0.f, oy = 0.f, oz = 0.f;
 #pragma unroll
