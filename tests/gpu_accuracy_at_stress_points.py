@@ -1,6 +1,6 @@
 """Accuracy of the two matrix modes at the stress points of tests/gpu_envelope.py, against the CPU oracle in fp64 on the SAME input (one network
 evaluation on the latent of step 500 of the fp32-mode trajectory): is a split-precision / fp32 discrepancy rounding noise of the same class as
-plain fp32's, or a loss of accuracy?   python tests/gpu_chaos_check.py"""
+plain fp32's, or a loss of accuracy?   python tests/gpu_accuracy_at_stress_points.py"""
 import importlib
 import os
 import sys
