@@ -473,7 +473,17 @@ def main():
         set_mode(1)
         run_steps(3)
 
+    if sliced is not None:      # finish the sliced sample (decode)
+        sliced.final()
+        torch.cuda.synchronize(dev)
+        sliced_flags = int(sliced.flags.max().item())
+        sliced_finite = bool(torch.isfinite(sliced.out).all().item())
+        sliced.close()
+        sliced = None
+    else:
+        sliced_flags, sliced_finite = 0, True
     # a complete sample through the public entry point (1000 steps + decode, same slices, Philox): the wall time `value` extrapolates to
+    # (after the timed loop's own slices are closed: the call slices the batch on the same extra handles)
     full_sample = None
     if world == 1 and args.streams == 1 and not args.no_full_sample:
         log("full 1000-step sample ...")
@@ -487,15 +497,6 @@ def main():
                        "vs_extrapolated": (B / fs) / (B / (ms_per_step * 1e-3 * NET_EVALS_PER_SAMPLE)),
                        "what": "one complete mol_gen_sample call (1000 denoise steps + decode, host clock, same slices and matrix mode as the timed loop)"}
 
-    if sliced is not None:      # finish the sliced sample (decode)
-        sliced.final()
-        torch.cuda.synchronize(dev)
-        sliced_flags = int(sliced.flags.max().item())
-        sliced_finite = bool(torch.isfinite(sliced.out).all().item())
-        sliced.close()
-        sliced = None
-    else:
-        sliced_flags, sliced_finite = 0, True
     # BASELINE.json configs[2] / configs[3] as extra fields of the one JSON line: short runs (same window rule), before the per-kernel event
     # timing below
     other_configs = None
