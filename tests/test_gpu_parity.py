@@ -384,6 +384,11 @@ def test_repeat_launch_bit_identity_full_batch(tile):
     first = _fwd(net, xh, t, bi)
     for _ in range(12):
         assert torch.equal(_fwd(net, xh, t, bi), first)
+    # the 64-node tiles of the layer node kernel (round 4; this batch picks 32 on its own): same bits, launch after launch
+    assert lib.gcdm_set_option(h, b"node_tile", 64) == 0
+    for _ in range(8):
+        assert torch.equal(_fwd(net, xh, t, bi), first)
+    assert lib.gcdm_set_option(h, b"node_tile", 0) == 0
     assert lib.gcdm_set_option(h, b"edge_tile", 0) == 0
 
 
