@@ -38,6 +38,8 @@
 #undef GCDM_ABL_GATE_NOPG
 #undef GCDM_ABL_NOSTORE
 #undef GCDM_ABL_NOAGG
+#undef GCDM_ABL_VECFMA
+#undef GCDM_ABL_VECNONE
 #endif
 #ifdef GCDM_ABL_NOSILU
 __device__ __forceinline__ float silu_scaled(float xs) { return xs; }
@@ -822,8 +824,8 @@ __device__ __forceinline__ void tile_gemm_x3s(f32x16 (&am)[MT][NT], f32x16 (&al)
             if constexpr (HK) {
                 hook(rc);
 #pragma unroll
-                for (int i = 0; i < 3 * MT * NT; ++i) {      // one MFMA, then up to X3_VEC_PER_MFMA other instructions of the stage, ...
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                for (int i = 0; i < 3 * MT * NT; ++i) {      // one MFMA, then up to X3_VEC_PER_MFMA other instructions of the stage, ... (12 groups of 4 / 6, 9 of 5,
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);     //  or no pattern at all: +2.0 / +0.7 / +1.3 / +0.2 % tile cycles, round 4)
                     __builtin_amdgcn_sched_group_barrier(0x002 | 0x004 | 0x080 | 0x400 | 0x020, X3_VEC_PER_MFMA, 0);
                 }
             }
@@ -840,6 +842,14 @@ __device__ __forceinline__ void tile_gemm_x3s(f32x16 (&am)[MT][NT], f32x16 (&al)
         x3_tail_skew<PD, SPLIT>(am, al, ring, bh, bl, sh, sl, TP, tail);        // (see x3_tail_skew)
     }
 }
+
+struct AblFmaFill {                   // (GCDM_ABL_VECFMA: 24 independent FMAs per hooked stage)
+    float x[24];
+    __device__ __forceinline__ void run() {
+#pragma unroll
+        for (int i = 0; i < 24; ++i) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(x[i]) : "v"(1.0001f), "v"(0.0003f));
+    }
+};
 
 struct EdgeMsgX3Args {
     X3Const x3c;                      // MUST stay the first member (X3_KARG)
@@ -1325,7 +1335,16 @@ __global__ __launch_bounds__(ET * 8) __attribute__((amdgpu_waves_per_eu(2, 2))) 
             vs.fA = k == 0 ? ax.vf0H : ax.vf1[k == 0 ? 0 : k - 1]; vs.fB = k == 0 ? ax.vf0L : ax.vf2[k == 0 ? 0 : k - 1];
             vs.pH = ax.vpH[k]; vs.pL = ax.vpL[k];
             vs.ve = ve; vs.vq = vq; vs.lane = lane;
+#ifdef GCDM_ABL_VECFMA       // (timing ablation: the hooked stages replaced by the same number of INDEPENDENT fp32 FMAs -- is it the instruction count or the stages' dependency structure?)
+            AblFmaFill fx_;
+            for (int i = 0; i < 24; ++i) fx_.x[i] = 0.001f * (lane + i);
+            tile_gemm_x3s<MT, NT, PD, 18, 16, true>(am, al2, ring, wp, gwH, gwL, xh8, xl8, ETP, lane, [&](auto) { fx_.run(); }, silu_n0);
+            amax = fmaxf(amax, fx_.x[0] * 1e-30f + fx_.x[23] * 1e-30f);
+#elif defined(GCDM_ABL_VECNONE)
+            tile_gemm_x3s<MT, NT, PD, 18, 16, true>(am, al2, ring, wp, gwH, gwL, xh8, xl8, ETP, lane, [&](auto) {}, silu_n0);
+#else
             tile_gemm_x3s<MT, NT, PD, 18, 16, true>(am, al2, ring, wp, gwH, gwL, xh8, xl8, ETP, lane, [&](auto rc) { vs.template run<decltype(rc)::value>(); }, silu_n0);
+#endif
             amax = fmaxf(amax, vs.amax);
         } else {
             tile_gemm_x3s<MT, NT, PD, 18, 16, false>(am, al2, ring, wp, gwH, gwL, xh8, xl8, ETP, lane, [](auto) {}, silu_n0);
