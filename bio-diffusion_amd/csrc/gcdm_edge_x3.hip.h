@@ -580,7 +580,7 @@ __device__ __forceinline__ void split4(const float (&x)[4], h4& hi, h4& lo, floa
 
 __device__ __forceinline__ h8 cat44(h4 a, h4 b) { return (h8){a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]}; }
 
-template <int ET, int H0, bool FIRST>
+template <int ET, int H0, bool FIRST, bool PIPE = false>
 struct VecStage {
     static constexpr int ETP = ET + 1;
     static constexpr int NSTAGES = 16;
@@ -635,6 +635,44 @@ struct VecStage {
             *p = v;
             if (m == 0) va[x] = v; else vb[x] = v;
         }
+    }
+    // software-pipelined form (PIPE, round 4): the small MFMAs of a step are issued one stage (= one k-block of the hosting GEMM) ahead of the VALU
+    // instructions that read their results, so that the wave never waits in order for a matrix result.  Costs 24 more live registers: used where the
+    // kernel has them (the 8-channel edge width, GEOM: tile 62.4 k -> 61.9 k cycles, same bits); the 16-channel instantiation would spill (+2 %).
+    f32x4 fam[2], fal[2];
+    v4f vold[2];
+    f32x4 pam, pal;
+    __device__ __forceinline__ void issue_f(int b, int x) {
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+            fam[m] = MFMA1632(w1[m], bh[b], z);
+            fal[m] = MFMA1632(w2[m], bh[b], z);
+            vold[m] = VV4[(x * 8 + 4 * m + vq) * ETP + ve];
+        }
+    }
+    __device__ __forceinline__ void consume_f(int x) {
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            const v4f sg = m == 0 ? g0 : g1;
+            v4f v = vold[m];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[i] += (fam[m][i] + fal[m][i] * X3_INV_SCALE) * sg[i];
+            VV4[(x * 8 + 4 * m + vq) * ETP + ve] = v;
+            if (m == 0) va[x] = v; else vb[x] = v;
+        }
+    }
+    __device__ __forceinline__ void issue_p() {
+        h8 xh = cat44(sh0, sh1), xl = cat44(sl0, sl1);
+        x3_settle(xh, xl);
+        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+        pam = MFMA1632(pa[0], xh, z);
+        pal = MFMA1632(pa[0], xl, z);
+        pal = MFMA1632(pa[1], xh, pal);
+    }
+    __device__ __forceinline__ void consume_p(int x) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) o[x][i] = pam[i] + pal[i] * X3_INV_SCALE;
     }
     __device__ __forceinline__ void load_vh(int x) {                                              // msg0: hidden channels 8q .. 8q+7 of component x
 #pragma unroll
@@ -721,6 +759,24 @@ struct VecStage {
             else if constexpr (I == 4) { split_vh(0); finish_x(0, 1); load_vh(2); }
             else if constexpr (I == 5) { split_vh(0); finish_x(0, 2); }
             else pre_stage<I, 6>();   // ... then vector_down of the first residual GCP2
+        } else if constexpr (PIPE) {
+            if constexpr (I == 0) {
+                w1[0] = fA[lane]; w1[1] = fA[64 + lane]; w2[0] = fB[lane]; w2[1] = fB[64 + lane];
+                g0 = gate_sum(0);
+            } else if constexpr (I == 1) {
+                g0 = sig4(g0);
+                g1 = gate_sum(1);
+#pragma unroll
+                for (int x = 0; x < 3; ++x) bh[x] = VHB[(x * 3 + min(vq, 2)) * ET + ve];
+            } else if constexpr (I == 2) { g1 = sig4(g1); issue_f(0, 0); }
+            else if constexpr (I == 3) { consume_f(0); issue_f(1, 1); }
+            else if constexpr (I == 4) { consume_f(1); issue_f(2, 2); }
+            else if constexpr (I == 5) { consume_f(2); pa[0] = pH[lane]; pa[1] = pL[lane]; split_vv(0); }
+            else if constexpr (I == 6) { issue_p(); split_vv(1); }
+            else if constexpr (I == 7) { consume_p(0); issue_p(); split_vv(2); }
+            else if constexpr (I == 8) { consume_p(1); issue_p(); }
+            else if constexpr (I == 9) consume_p(2);
+            else pre_stage<I, 6>();              // (stages 10 .. 14: norms, extended-K group, hidden-vector images: as before)
         } else {
             if constexpr (I == 0) {
                 w1[0] = fA[lane]; w1[1] = fA[64 + lane]; w2[0] = fB[lane]; w2[1] = fB[64 + lane];
@@ -739,7 +795,12 @@ struct VecStage {
     }
     // vector part of the LAST GCP2 (no GEMM left to hide it in)
     __device__ __forceinline__ void finish_only() {
-        run<0>(); run<1>(); run<2>(); run<3>(); run<4>(); run<5>();
+        if constexpr (PIPE && !FIRST) {
+            run<0>(); run<1>(); run<2>(); run<3>(); run<4>();
+            consume_f(2);                    // (stage 5 of the pipelined form without the first step of a following pre part)
+        } else {
+            run<0>(); run<1>(); run<2>(); run<3>(); run<4>(); run<5>();
+        }
     }
 };
 
@@ -1330,7 +1391,7 @@ __global__ __launch_bounds__(ET * 8) __attribute__((amdgpu_waves_per_eu(2, 2))) 
                 for (int r = 0; r < 16; ++r) am[m][0][r] = silu_scaled(am[m][0][r] + al2[m][0][r] * X3_INV_SCALE);
         };
         if (vhalf == (k & 1)) {
-            VecStage<ET, H0, k == 0> vs;
+            VecStage<ET, H0, k == 0, VE == 8> vs;
             vs.PG = PG; vs.bg = k == 0 ? a.bg0 : a.mk[k == 0 ? 0 : k - 1].bg; vs.FR = FR; vs.VH = VH; vs.VHB = VHB; vs.VV4 = VV4; vs.XH = XH; vs.XL = XL;
             vs.fA = k == 0 ? ax.vf0H : ax.vf1[k == 0 ? 0 : k - 1]; vs.fB = k == 0 ? ax.vf0L : ax.vf2[k == 0 ? 0 : k - 1];
             vs.pH = ax.vpH[k]; vs.pL = ax.vpL[k];
@@ -1428,7 +1489,7 @@ __global__ __launch_bounds__(ET * 8) __attribute__((amdgpu_waves_per_eu(2, 2))) 
             }
             __syncthreads();
             if (vhalf == 1) {             // the vector part of the last GCP2 (no GEMM left to hide it in)
-                VecStage<ET, H0, false> vs;
+                VecStage<ET, H0, false, VE == 8> vs;       // (pipelined where it pays: GEOM -0.5 %; the 16-channel instantiation measures +1.1 % with it)
                 vs.PG = PG; vs.bg = a.mk[2].bg; vs.FR = FR; vs.VH = VH; vs.VHB = VHB; vs.VV4 = VV4; vs.XH = XH; vs.XL = XL;
                 vs.fA = ax.vf1[2]; vs.fB = ax.vf2[2]; vs.pH = nullptr; vs.pL = nullptr;
                 vs.ve = ve; vs.vq = vq; vs.lane = lane;
