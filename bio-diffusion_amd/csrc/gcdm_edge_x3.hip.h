@@ -175,6 +175,17 @@ struct BufView {
         const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, soff, 0);
         return __builtin_bit_cast(v4f, v);
     }
+    // per-edge constants: read once per launch by one workgroup (136 MB per layer at QM9 1024 x 19, streaming through the L2 that also has to keep the
+    // layer's 2.9 MB of weights).  AUX = 2 is the non-temporal hint: QM9 tile 62.77 k -> 62.34 k cycles, step -0.9 %; GEOM (a quarter of the bytes per
+    // edge) +0.25 % -- so the 64-channel edge width uses it, the 16-channel one does not (round 4; same bits).  Non-temporal STORES of the aggregated
+    // rows were measured too: +1.7 % (QM9), +-0 (GEOM) -- not used.
+    template <int AUX>
+    __device__ __forceinline__ float ld1s(uint32_t voff, uint32_t soff) const { return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, voff, soff, AUX)); }
+    template <int AUX>
+    __device__ __forceinline__ v4f ld4s(uint32_t voff, uint32_t soff) const {
+        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, soff, AUX);
+        return __builtin_bit_cast(v4f, v);
+    }
 };
 __device__ __forceinline__ BufView make_view(const void* pool, uint32_t bytes) {
     BufView b;
@@ -1001,6 +1012,7 @@ __global__ __launch_bounds__(ET * 8) __attribute__((amdgpu_waves_per_eu(2, 2))) 
     // edge (node) index, array base and row stride are scalars -- no 64-bit VALU address arithmetic per load
     const BufView ws = make_view(ax0.wspool, ax0.wspool_bytes);
     const BufView wv = make_view(ax0.wpool, ax0.wpool_bytes);
+    constexpr int SAUX = SE == 64 ? 2 : 0;               // cache policy of the streamed per-edge constants (BufView::ld1s)
     constexpr int EPN = (SE / 4) / PARTS;                // e' float4 groups per thread (QM9 2, GEOM: parts 0..3 one each)
     constexpr int EPN1 = EPN > 0 ? EPN : 1;
     const uint32_t rowE = (uint32_t)E * 4u, rowN = (uint32_t)N * 4u;
@@ -1040,30 +1052,30 @@ __global__ __launch_bounds__(ET * 8) __attribute__((amdgpu_waves_per_eu(2, 2))) 
         if constexpr (P < 0 || P == 0) {
             const uint32_t o = ws.off(a.FR);
 #pragma unroll
-            for (int r = 0; r < 9; ++r) in.fr[r] = w.need_fr ? ws.ld1(ve4, o + r * rowE) : 0.f;
+            for (int r = 0; r < 9; ++r) in.fr[r] = w.need_fr ? ws.template ld1s<SAUX>(ve4, o + r * rowE) : 0.f;
         }
         if constexpr (P < 0 || P == 1) {
             const uint32_t o = ws.off(a.EP4);
 #pragma unroll
             for (int i = 0; i < EPN1; ++i)
-                in.epv[i] = ws.ld4(ve16 + (uint32_t)min(w.part + PARTS * i, SE / 4 - 1) * (rowE * 4u), o);          // the group index depends on the lane's part
+                in.epv[i] = ws.template ld4s<SAUX>(ve16 + (uint32_t)min(w.part + PARTS * i, SE / 4 - 1) * (rowE * 4u), o);          // the group index depends on the lane's part
         }
         if constexpr ((P < 0 || P == 2) && !BETA_MFMA) {
             const uint32_t o = ws.off(a.AL);
 #pragma unroll
-            for (int c = 0; c < VE; ++c) in.al[c] = ws.ld1(ve4, o + c * rowE);
+            for (int c = 0; c < VE; ++c) in.al[c] = ws.template ld1s<SAUX>(ve4, o + c * rowE);
         }
         if constexpr ((P < 0 || P == 1) && BETA_MFMA) {
             if (w.wave >= ET / 8 - ET / 32) {         // the LAST waves contract beta: they are the first to leave the previous tile's segment sums
                 // (the half of K this lane holds rides in the per-lane offset: a lane-dependent scalar offset would cost a waterfall loop per load)
                 const uint32_t eg4 = (uint32_t)min(e0 + 32 * (w.wave - (ET / 8 - ET / 32)) + (w.lane & 31), E - 1) * 4u + (uint32_t)(8 * (w.lane >> 5)) * rowE, o = ws.off(a.AL);
 #pragma unroll
-                for (int j = 0; j < 8; ++j) in.av[j] = ws.ld1(eg4, o + (uint32_t)j * rowE);
+                for (int j = 0; j < 8; ++j) in.av[j] = ws.template ld1s<SAUX>(eg4, o + (uint32_t)j * rowE);
             }
         }
         if constexpr (P < 0 || P == 2) {
             const uint32_t oU = ws.off(a.U);
-            in.u0 = ws.ld1(ve4, oU); in.u1 = ws.ld1(ve4, oU + rowE); in.u2 = ws.ld1(ve4, oU + 2 * rowE);
+            in.u0 = ws.template ld1s<SAUX>(ve4, oU); in.u1 = ws.template ld1s<SAUX>(ve4, oU + rowE); in.u2 = ws.template ld1s<SAUX>(ve4, oU + 2 * rowE);
         }
     };
     // node rows (need the index words), in GCH chunks: the 16 PQ4 rows (16 B per lane each: 16 clk of the L1 path per wave instruction) and the
