@@ -228,41 +228,9 @@ def test_long_horizon_sampling_matches_reference_golden(mode, fixture, golden_di
     print(f"long horizon ({'f16x3' if mode else 'f32'}): worst err / bound over the checkpoints = {worst:.3f}")
 
 
-_CONFIG0_ORACLE = {}
-
-
-@pytest.mark.parametrize("mode", MODES)
-def test_free_running_sampling_config0_size(mode):
-    """BASELINE.json configs[0] shape (64 QM9 molecules x 19 atoms): 24 free-running steps + decode against the oracle on the same tape
-    (the full 1000-step runs of this shape are tests/cpu_full_config0.py / bench.py; 24 steps keep the CPU oracle's share of the GPU suite at about half a minute
-    on the slower hosts of the pool)."""
-    net, W, cfgs = _net("qm9", seed=47, scale=0.25, mode=mode)
-    ocfg = _ocfg("qm9")
-    ddpm = pkg.EquivariantVariationalDiffusion(net, cfgs["diffusion_cfg"], cfgs["dataloader_cfg"], pkg.dataset_info("qm9")).cuda()
-    nn_ = torch.tensor([19] * 64)
-    N, F, Tp = int(nn_.sum()), ocfg.num_node_scalar_features, 24
-    if "want" not in _CONFIG0_ORACLE:            # the CPU oracle takes ~30-60 s for these 24 steps: once for both matrix modes
-        torch.set_num_threads(min(32, os.cpu_count() or 1))
-        _CONFIG0_ORACLE["want"] = O.mol_gen_sample(W, ocfg, nn_, O.TapeNoise(77), num_timesteps=Tp)
-    want, bi = _CONFIG0_ORACLE["want"]
-    tape = O.TapeNoise(77)
-    draws = [torch.cat((tape(N, 3), tape(N, F)), dim=-1) for _ in range(Tp + 2)]
-    out, bi2, _ = ddpm.mol_gen_sample(num_samples=len(nn_), num_nodes=nn_, device="cuda", num_timesteps=Tp, noise_fn=lambda k: draws[k])
-    out = out.cpu()
-    assert torch.equal(bi2.cpu(), bi) and (ddpm.last_flags & pkg._native.FLAG_F16_RANGE) == 0
-    scale = max(1.0, want[:, :3].abs().max().item())
-    assert (out[:, :3] - want[:, :3]).abs().max().item() <= TOL * scale
-    # discrete outputs: untrained weights drive the charge channel to O(1e3) after a few dozen coarse steps, so the 1e-4 * scale deviation the latent is
-    # allowed is a sizeable fraction of the rounding unit and a near-tie can fall either way.  (Skipping the atoms on which an fp64 run of the
-    # oracle disagrees with its fp32 run does not remove them: a tie the oracle resolves alike in both precisions can still be 1e-5 away
-    # from flipping -- tried on the 16-molecule 1000-step golden.)  Counted, bounded and printed instead: identical on >= 99 % of the 1216
-    # atoms, charges never off by more than one unit; the exact discrete pins are the reference goldens (long_*.npz, sampler_*.npz).
-    nt = ocfg.num_atom_types
-    same_t = (out[:, 3:3 + nt].argmax(1) == want[:, 3:3 + nt].argmax(1))
-    dq = (out[:, 3 + nt] - want[:, 3 + nt]).abs()
-    print(f"config0 size, {Tp} steps: {int((~same_t).sum())} atom types and {int((dq != 0).sum())} charges of {len(dq)} differ from the oracle (near-ties)")
-    assert same_t.float().mean().item() >= 0.99
-    assert dq.max().item() <= 1.0 and (dq == 0).float().mean().item() >= 0.99
+# (test_free_running_sampling_config0_size -- 24 free-running steps of the configs[0] shape against the CPU oracle, with a relaxed discrete check -- is folded
+#  into test_long_horizon_sampling_matches_reference_golden[long_config0_qm9.npz]: the reference's own full 1000-step run of that shape, no oracle time on
+#  the GPU box, discrete outputs equal on every atom the reference's fp32 and fp64 runs decide alike.)
 
 
 @pytest.mark.parametrize("case,num_nodes", [
