@@ -1010,7 +1010,7 @@ int gcdm_forward_sc(gcdm_handle* h, const float* xh, const float* xh_sc, const f
             if (next_layer < h->L) { nx.wpqH = h->layers[next_layer].wpqH; nx.wpqL = h->layers[next_layer].wpqL; nx.vdH = h->layers[next_layer].vdH; nx.vdL = h->layers[next_layer].vdL; nx.bpqx = h->layers[next_layer].bpqx; }
             if (embed && h->sc) hipLaunchKernelGGL((k_node_x3<true, 4>), dim3(ngrid), dim3(NX_THREADS), NK_LDS_BYTES, st, nx);
             else if (embed) hipLaunchKernelGGL(k_node_x3<true>, dim3(ngrid), dim3(NX_THREADS), NK_LDS_BYTES, st, nx);
-            else if (node_tile_for(h, N) == 64 && !nx.prof) hipLaunchKernelGGL(k_node_x3w, dim3((N + NW_T - 1) / NW_T), dim3(512), NW_LDS_BYTES, st, nx);
+            else if (node_tile_for(h, N) == 64) hipLaunchKernelGGL(k_node_x3w, dim3((N + NW_T - 1) / NW_T), dim3(512), NW_LDS_BYTES, st, nx);
             else hipLaunchKernelGGL(k_node_x3<false>, dim3(ngrid), dim3(NX_THREADS), NK_LDS_BYTES, st, nx);
         } else {
             if (embed && h->sc) hipLaunchKernelGGL((k_node<true, 4>), dim3(ngrid), dim3(256), NK_LDS_BYTES, st, na);

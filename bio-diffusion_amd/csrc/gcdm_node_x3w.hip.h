@@ -140,6 +140,8 @@ __global__ __launch_bounds__(512) void k_node_x3w(NodeX3Args ax) {
     const bool valid = (n0 + e) < N;
     bool over = false;
     float amax = 0.f;
+    const uint64_t t_start = ax.prof ? __builtin_amdgcn_s_memtime() : 0;
+    (void)t_start;
 
     for (int i = tid; i < GCDM_V * 16 + GCDM_V; i += 512) WUP[i] = i < GCDM_V * 16 ? a.ff.wup[i] : a.ff.bg[i - GCDM_V * 16];
     for (int r = part; r < 9; r += PARTS) FR[r * TP + e] = a.FBAR[(size_t)r * N + nid];
@@ -278,7 +280,9 @@ __global__ __launch_bounds__(512) void k_node_x3w(NodeX3Args ax) {
 #pragma unroll
         for (int k = 0; k < 96 / PARTS; ++k) VV[(CB * 3 + part + PARTS * k) * TP + e] = cv[k];
     }
+    NSTAMP(1);
     __syncthreads();
+    NSTAMP(2);
     // ---- feed-forward GCP2 ----------------------------------------------------------------------------------------------------------------------
     {
         const GcpW& w = a.ff;
@@ -287,15 +291,19 @@ __global__ __launch_bounds__(512) void k_node_x3w(NodeX3Args ax) {
             nw_vecmat_unit<2, 2>(vm_ff, VV, 0, unit, lane, amax, [&](int row, int x, int nd, float v) {
                 if (row < 19) VH[(row * 3 + x) * TP + nd] = v;
             });
+        NSTAMP(3);
         __syncthreads();
         over |= gcp2_pre_tail_x3<NW_T, 16, 512>(VH, FR, XH, XL, 32, 34, 36, tid);
+        NSTAMP(4);
         __syncthreads();
+        NSTAMP(5);
         acc_bias(w.b);
         gemm(integral_constant<int, 16>{}, ax.ff.wH, ax.ff.wL, 34, 0, 0);                 // K' blocks 0..15: agg.s
         __syncthreads();                                                                 // every wave is done reading the agg.s images
         over |= store_state_x3<1, 2>(XH, XL, 0, hst, TP, wave, lane);                    // h images over them
         __syncthreads();
         gemm(integral_constant<int, 18>{}, ax.ff.wH, ax.ff.wL, 34, 16, 0);                // K' blocks 16..33: h, norms, frame scalars
+        NSTAMP(6);
 #pragma unroll
         for (int n = 0; n < 2; ++n)
 #pragma unroll
@@ -303,16 +311,19 @@ __global__ __launch_bounds__(512) void k_node_x3w(NodeX3Args ax) {
         __syncthreads();                                                                 // every wave is done reading the h images
         over |= store_state_x3<1, 2>(XH, XL, 0, am, TP, wave, lane);                     // hidden activations of Linear-SiLU-Linear
         __syncthreads();
+        NSTAMP(7);
         acc_bias(w.b2);
         const GateWn gw = load_gate(ax.ff.wgH, ax.ff.wgL);
         vm_pos.load(ax.pos.vmH, ax.pos.vmL, lane);
         gemm(integral_constant<int, 16>{}, ax.ff.w2H, ax.ff.w2L, 16, 0, 0);
+        NSTAMP(8);
 #pragma unroll
         for (int n = 0; n < 2; ++n)
 #pragma unroll
             for (int r = 0; r < 16; ++r) am[0][n][r] += al[0][n][r] * X3_INV_SCALE;       // nonlinearities (None, None)
         fold_gate_w(gw, am);
         __syncthreads();
+        NSTAMP(9);
         float ml[2];
 #pragma unroll
         for (int n = 0; n < 2; ++n) ml[n] = a.mask ? a.mask[min(n0 + 32 * n + l31, N - 1)] : 1.f;   // masked nodes: h, chi, x <- 0 after the layer (gcpnet.py:914-928)
@@ -328,7 +339,9 @@ __global__ __launch_bounds__(512) void k_node_x3w(NodeX3Args ax) {
             VV[((CB + c) * 3 + 1) * TP + e] = (VV[((CB + c) * 3 + 1) * TP + e] + oy) * me;
             VV[((CB + c) * 3 + 2) * TP + e] = (VV[((CB + c) * 3 + 2) * TP + e] + oz) * me;
         });
+        NSTAMP(10);
         __syncthreads();
+        NSTAMP(11);
     }
     // ---- position update GCP2 -------------------------------------------------------------------------------------------------------------------
     {
@@ -341,9 +354,11 @@ __global__ __launch_bounds__(512) void k_node_x3w(NodeX3Args ax) {
         __syncthreads();
         over |= gcp2_pre_tail_x3<NW_T, 8, 512>(VH, FR, XH, XL, 32, 33, 36, tid);
         __syncthreads();
+        NSTAMP(12);
         acc_bias(w.b);
         const GateWn gw = load_gate(ax.pos.wgH, ax.pos.wgL);
         gemm(integral_constant<int, 18>{}, ax.pos.wH, ax.pos.wL, 18, 0, 0);              // K' = 256 + 8 + 16 -> 288
+        NSTAMP(13);
 #pragma unroll
         for (int n = 0; n < 2; ++n)
 #pragma unroll
@@ -359,6 +374,7 @@ __global__ __launch_bounds__(512) void k_node_x3w(NodeX3Args ax) {
         });
         __syncthreads();
         if (part < 3 && valid) a.XC[(size_t)part * N + nid] = XP[part * TP + e];
+        NSTAMP(14);
     }
     // ---- write the node state back (h from the register master, chi from LDS) ---------------------------------------------------------------------
 #pragma unroll
@@ -373,6 +389,7 @@ __global__ __launch_bounds__(512) void k_node_x3w(NodeX3Args ax) {
         for (int r = part; r < 96; r += PARTS) a.CHI[(size_t)r * N + nid] = VV[(CB * 3 + r) * TP + e];
     }
 
+    NSTAMP(15);
     if (a.has_next) {
         // ---- node-level halves of the next layer's msg0 ([P | Q], 16 M-tiles): wave w computes M-tiles 2w and 2w + 1, one after the other ----------
         VecMatW<3, 1> vm_next;
@@ -402,6 +419,7 @@ __global__ __launch_bounds__(512) void k_node_x3w(NodeX3Args ax) {
                     }
                 }
         }
+        NSTAMP(16);
         // vector halves of the next layer's msg0: [W_down; W_frames][:, block] . chi for the row (I) and col (J) block -- 2 x (H0 + 3) rows
         {
             const int rows = a.H0 + 3;
@@ -443,6 +461,7 @@ __global__ __launch_bounds__(512) void k_node_x3w(NodeX3Args ax) {
             over |= !(fabsf(v) <= 3.0e38f);
         }
     }
+    NSTAMP(17);
     over |= amax > X3_RANGE;
     if (__any(over) && lane == 0) atomicOr(a.flags_dev, GCDM_FLAG_F16_RANGE_BIT);
 }
