@@ -19,6 +19,10 @@ python profiles/pmc_summarize.py $OUT/${TAG}_pmc1 $OUT/${TAG}_pmc2 $OUT/${TAG}_p
 python profiles/pmc_summarize.py $OUT/${TAG}g_pmc1 $OUT/${TAG}g_pmc2 $OUT/${TAG}g_pmc3 $OUT/${TAG}g_pmc4 > $OUT/${TAG}_pmc_summary_geom_x3.json
 cp $OUT/${TAG}_pmc_summary_qm9_x3.json $OUT/${TAG}_pmc_summary_geom_x3.json profiles/
 for d in ${TAG} ${TAG}g ${TAG}f32; do f=$(ls -t $OUT/${d}_stats/*/*kernel_stats.csv 2>/dev/null | head -1); [ -n "$f" ] && cp "$f" $OUT/${d}_kernel_stats.csv; done
+# the bench lines below recompute roofline.frac from the committed kernel statistics: those of THIS box and build (profiles/<tag>_bench_{qm9,geom}_x3_kernel_stats.csv)
+[ -f $OUT/${TAG}_kernel_stats.csv ] && cp $OUT/${TAG}_kernel_stats.csv profiles/${TAG}_bench_qm9_x3_kernel_stats.csv
+[ -f $OUT/${TAG}g_kernel_stats.csv ] && cp $OUT/${TAG}g_kernel_stats.csv profiles/${TAG}_bench_geom_x3_kernel_stats.csv
+[ -f $OUT/${TAG}f32_kernel_stats.csv ] && cp $OUT/${TAG}f32_kernel_stats.csv profiles/${TAG}_bench_qm9_f32_kernel_stats.csv
 # raw counter dumps are large: keep the summaries and the per-kernel stats only
 rm -rf $OUT/${TAG}_pmc[1-4] $OUT/${TAG}g_pmc[1-4] $OUT/${TAG}f32_pmc1 $OUT/${TAG}_stats $OUT/${TAG}g_stats $OUT/${TAG}f32_stats
 timeout 400 python bench.py --steps 100 --warmup 5 > $OUT/${TAG}_bench_qm9.json 2> $OUT/${TAG}_bench_qm9.err
