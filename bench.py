@@ -283,7 +283,9 @@ def eval_driver_config(pkg, dev, rank, in_flight, steps=100):
 
     def run(T_):
         if in_flight == 1:
-            ddpm.mol_gen_sample(num_samples=wl["B"], num_nodes=sizes[0], device=dev, num_timesteps=T_, seed=7 + rank)
+            # (two slices: what the model's sample() does for plain batches of >= DEFAULT_LANES_MIN_SAMPLES molecules)
+            ddpm.mol_gen_sample(num_samples=wl["B"], num_nodes=sizes[0], device=dev, num_timesteps=T_, seed=7 + rank,
+                                lanes=2 if wl["B"] >= pkg.mol_gen_ddpm.DEFAULT_LANES_MIN_SAMPLES else 1)
         else:
             ddpm.mol_gen_sample_concurrent(sizes, dev, num_timesteps=T_, seeds=[7 + rank + b for b in range(in_flight)])
         torch.cuda.synchronize(dev)

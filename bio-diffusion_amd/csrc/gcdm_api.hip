@@ -99,6 +99,23 @@ struct gcdm_handle {
     bool profile_node = false;       // enable == 3: phase time stamps of the layer node kernel (debug_read("phase_node"))
     std::vector<hipEvent_t> ev;      // 2 per layer
     int ev_used = 0;
+    // One denoise step as a hipGraph (option "step_graph", default on).  A step is ~25 launches (QM9) whose arguments are the same at every
+    // step except four scalars and the Philox draw index; those live in a device table (StepRow) indexed by a device cursor, so ONE instantiated
+    // graph serves all steps of a sample: gcdm_sample_step enqueues one graph launch instead of 25 kernels (host cost 0.5 ms -> ~0.03 ms per
+    // step; what small batches and several slices / batches in flight are bound by).  Same kernels, same arguments: bit-identical results.
+    int step_graph = 1;
+    bool step_graph_failed = false;  // capture / instantiation failed once on this handle: launch directly from then on
+    bool capturing = false;
+    struct StepGraph {
+        hipGraph_t graph = nullptr;
+        hipGraphExec_t exec = nullptr;
+        const float* z = nullptr; const float* ctx = nullptr; const uint32_t* flags = nullptr;
+        uint64_t seed = 0; int num_steps = 0;
+    } sg;
+    hipStream_t cap_stream = nullptr;  // capture happens here (the caller's stream may be the null stream, which cannot capture)
+    StepRow* d_rows = nullptr; int rows_steps = 0;
+    int* d_cursor = nullptr; int cursor_expected = -1;
+    int64_t graph_launches = 0;        // option "graph_launches" (read-only): steps served by the graph since the handle was created
 };
 
 namespace {
@@ -106,6 +123,16 @@ namespace {
 int fail(gcdm_handle* h, const std::string& msg) {
     if (h) h->err = msg;
     return -1;
+}
+
+// Anything a captured step has baked in changed (plan, weights, gamma table, an option): drop the instantiated graph
+void drop_step_graph(gcdm_handle* h) {
+    if (!h) return;
+    if (h->sg.exec) (void)hipGraphExecDestroy(h->sg.exec);
+    if (h->sg.graph) (void)hipGraphDestroy(h->sg.graph);
+    h->sg = gcdm_handle::StepGraph{};
+    h->rows_steps = 0;
+    h->cursor_expected = -1;
 }
 
 #define HIP_OK(h, expr)                                                                              \
@@ -492,6 +519,7 @@ int gcdm_create(const GcdmConfig* cfg, gcdm_handle** out) {
     if (const char* mm = getenv("GCDM_MFMA")) h->mfma_x3 = (std::strcmp(mm, "f16x3") == 0) ? 1 : 0;
     if (const char* pe = getenv("GCDM_PERSISTENT")) h->persistent = atoi(pe) ? 1 : 0;
     if (const char* nt = getenv("GCDM_NODE_TILE")) h->node_tile = atoi(nt) == 32 ? 32 : atoi(nt) == 64 ? 64 : 0;
+    if (const char* sg = getenv("GCDM_STEP_GRAPH")) h->step_graph = atoi(sg) ? 1 : 0;
     DeviceGuard guard(cfg->device);
     {
         int n = 0;
@@ -510,6 +538,10 @@ int gcdm_destroy(gcdm_handle* h) {
     if (h->wpool) (void)hipFree(h->wpool);
     if (h->d_flags) (void)hipFree(h->d_flags);
     if (h->d_gmean) (void)hipFree(h->d_gmean);
+    drop_step_graph(h);
+    if (h->d_rows) (void)hipFree(h->d_rows);
+    if (h->d_cursor) (void)hipFree(h->d_cursor);
+    if (h->cap_stream) (void)hipStreamDestroy(h->cap_stream);
     delete h;
     return 0;
 }
@@ -526,6 +558,7 @@ int gcdm_set_weight(gcdm_handle* h, const char* key, const float* host_data, int
 int gcdm_set_gamma(gcdm_handle* h, const float* host_gamma, int64_t numel) {
     if (!h || !host_gamma || numel != (int64_t)h->cfg.num_timesteps + 1) return fail(h, "gcdm_set_gamma: expected num_timesteps+1 values");
     h->gamma.assign(host_gamma, host_gamma + numel);
+    drop_step_graph(h);
     return 0;
 }
 
@@ -814,6 +847,7 @@ int gcdm_finalize_weights(gcdm_handle* h) {
     }
     h->finalized = true;
     h->host_w.clear();
+    drop_step_graph(h);
     return 0;
 }
 
@@ -822,6 +856,7 @@ int gcdm_plan_batch(gcdm_handle* h, int32_t B, const int32_t* nn) { return gcdm_
 int gcdm_plan_batch_masked(gcdm_handle* h, int32_t B, const int32_t* nn, const uint8_t* node_mask) {
     if (!h || B <= 0 || !nn) return fail(h, "gcdm_plan_batch: bad argument");
     DeviceGuard guard(h->cfg.device);
+    drop_step_graph(h);
     std::vector<int> noff(B + 1, 0);
     int64_t E = 0;
     int max_n = 0;
@@ -927,6 +962,7 @@ int64_t gcdm_num_edges(const gcdm_handle* h) { return h ? h->E : -1; }
 
 int gcdm_debug_set_layer_limit(gcdm_handle* h, int32_t n) {
     if (!h) return -1;
+    drop_step_graph(h);
     h->layer_limit = n;
     return 0;
 }
@@ -1148,23 +1184,93 @@ int gcdm_sample_step(gcdm_handle* h, float* z, const float* context, int32_t s_i
 
 // One ancestral transition z_t -> z_s (sample_p_zs_given_zt, variational_diffusion.py:1204-1278) for arbitrary normalised times s < t:
 // network evaluation at t (with the self-conditioning input `sc`, or none), then the fused update into z_out.
-static int transition(gcdm_handle* h, const float* z_in, float* z_out, const float* sc, const float* context, float s, float t,
-                      const float* noise, uint64_t seed, uint32_t draw, uint32_t* flags, void* stream_) {
-    hipStream_t st = (hipStream_t)stream_;
-    if (fill_t(h, t, st)) return -1;
-    if (gcdm_forward_sc(h, z_in, sc, h->TBUF, context, h->EPS, flags, stream_)) return -1;
+// The three coefficients of z_s = z_t / alpha_coef - c_eps * eps + sigma * noise: sigma_and_alpha_t_given_s (:342-367), sigma (:318-325)
+static StepRow step_row(const gcdm_handle* h, float s, float t, uint32_t draw) {
     const float gs = gamma_lookup(h, s), gt = gamma_lookup(h, t);
-    // sigma_and_alpha_t_given_s (:342-367), sigma (:318-325)
     const float s2ts = -expm1f(softplusf(gs) - softplusf(gt));
     const float alpha_ts = expf(0.5f * (logsigmoidf(-gt) - logsigmoidf(-gs)));
     const float sts = sqrtf(s2ts), sig_s = sqrtf(sigmoidf_(gs)), sig_t = sqrtf(sigmoidf_(gt));
+    StepRow r{};
+    r.t = t;
+    r.alpha_coef = alpha_ts;
+    r.c_eps = s2ts / alpha_ts / sig_t;
+    r.sigma = sts * sig_s / sig_t;
+    r.draw = draw;
+    return r;
+}
+
+static int transition(gcdm_handle* h, const float* z_in, float* z_out, const float* sc, const float* context, float s, float t,
+                      const float* noise, uint64_t seed, uint32_t draw, uint32_t* flags, void* stream_) {
+    hipStream_t st = (hipStream_t)stream_;
+    if (h->capturing) {       // the step being captured into a graph: t and the coefficients come from the device table at run time
+        DeviceGuard guard(h->cfg.device);
+        hipLaunchKernelGGL(k_fill_row, dim3((h->N + 255) / 256), dim3(256), 0, st, h->TBUF, h->N, h->d_rows, h->d_cursor);
+    } else if (fill_t(h, t, st)) {
+        return -1;
+    }
+    if (gcdm_forward_sc(h, z_in, sc, h->TBUF, context, h->EPS, flags, stream_)) return -1;
+    const StepRow r = step_row(h, s, t, draw);
     StepArgs sa{};
+    if (h->capturing) { sa.rows = h->d_rows; sa.cursor = h->d_cursor; }
     sa.z = const_cast<float*>(z_in); sa.z_out = z_out; sa.eps = h->EPS; sa.noise = noise; sa.seed = seed; sa.draw = draw; sa.mode = 0;
-    sa.alpha_coef = alpha_ts;
-    sa.c_eps = s2ts / alpha_ts / sig_t;
-    sa.sigma = sts * sig_s / sig_t;
+    sa.alpha_coef = r.alpha_coef;
+    sa.c_eps = r.c_eps;
+    sa.sigma = r.sigma;
     sa.user_flags = flags; sa.flags_dev = h->d_flags;
     return launch_sample(h, sa, st);
+}
+
+// One step through the handle's instantiated graph (see gcdm_handle::step_graph).  Returns 1 when the step was enqueued, 0 when the caller should
+// launch directly (not eligible, or capture failed on this handle), -1 on error.
+static int step_via_graph(gcdm_handle* h, float* z, const float* context, int32_t s_index, int32_t num_steps, uint64_t seed, uint32_t* flags,
+                          hipStream_t st) {
+    if (!h->step_graph || h->step_graph_failed || h->fix_noise || h->profile || h->profile_phases || h->profile_node || h->layer_limit >= 0 || h->sc ||
+        h->d_mask || !h->N)
+        return 0;
+    DeviceGuard guard(h->cfg.device);
+    auto give_up = [&](const char* what, hipError_t e) {
+        h->step_graph_failed = true;
+        h->capturing = false;
+        h->err = std::string("step graph disabled on this handle (") + what + ": " + hipGetErrorString(e) + "); launching directly";
+        (void)hipGetLastError();
+        drop_step_graph(h);
+        return 0;
+    };
+    hipError_t e;
+    if (!h->cap_stream && (e = hipStreamCreateWithFlags(&h->cap_stream, hipStreamNonBlocking)) != hipSuccess) return give_up("hipStreamCreate", e);
+    if (!h->d_cursor && (e = hipMalloc(&h->d_cursor, sizeof(int))) != hipSuccess) return give_up("hipMalloc", e);
+    if (h->rows_steps != num_steps) {              // the table of this step count (s = i / num_steps, t = (i + 1) / num_steps, as gcdm_sample_step_to)
+        std::vector<StepRow> rows((size_t)num_steps);
+        for (int i = 0; i < num_steps; ++i) rows[i] = step_row(h, (float)i / (float)num_steps, (float)(i + 1) / (float)num_steps, (uint32_t)i);
+        if (h->d_rows) { (void)hipStreamSynchronize(st); (void)hipFree(h->d_rows); h->d_rows = nullptr; }     // (a graph still reading the old table is behind st)
+        if ((e = hipMalloc(&h->d_rows, rows.size() * sizeof(StepRow))) != hipSuccess) return give_up("hipMalloc", e);
+        if ((e = hipMemcpy(h->d_rows, rows.data(), rows.size() * sizeof(StepRow), hipMemcpyHostToDevice)) != hipSuccess) return give_up("hipMemcpy", e);
+        if (h->sg.exec) { (void)hipGraphExecDestroy(h->sg.exec); (void)hipGraphDestroy(h->sg.graph); h->sg = gcdm_handle::StepGraph{}; }
+        h->rows_steps = num_steps;
+    }
+    if (!h->sg.exec || h->sg.z != z || h->sg.ctx != context || h->sg.flags != flags || h->sg.seed != seed || h->sg.num_steps != num_steps) {
+        if (h->sg.exec) { (void)hipGraphExecDestroy(h->sg.exec); (void)hipGraphDestroy(h->sg.graph); h->sg = gcdm_handle::StepGraph{}; }
+        if ((e = hipStreamBeginCapture(h->cap_stream, hipStreamCaptureModeThreadLocal)) != hipSuccess) return give_up("hipStreamBeginCapture", e);
+        h->capturing = true;
+        const int rc = transition(h, z, z, nullptr, context, 0.f, 1.f / (float)num_steps, nullptr, seed, 0u, flags, (void*)h->cap_stream);
+        hipLaunchKernelGGL(k_cursor_dec, dim3(1), dim3(1), 0, h->cap_stream, h->d_cursor);
+        h->capturing = false;
+        hipGraph_t g = nullptr;
+        e = hipStreamEndCapture(h->cap_stream, &g);
+        if (rc != 0 || e != hipSuccess || !g) {
+            if (g) (void)hipGraphDestroy(g);
+            return give_up("capture of one step", e);
+        }
+        hipGraphExec_t ex = nullptr;
+        if ((e = hipGraphInstantiate(&ex, g, nullptr, nullptr, 0)) != hipSuccess) { (void)hipGraphDestroy(g); return give_up("hipGraphInstantiate", e); }
+        h->sg.graph = g; h->sg.exec = ex; h->sg.z = z; h->sg.ctx = context; h->sg.flags = flags; h->sg.seed = seed; h->sg.num_steps = num_steps;
+        h->cursor_expected = -1;
+    }
+    if (h->cursor_expected != s_index) hipLaunchKernelGGL(k_cursor_set, dim3(1), dim3(1), 0, st, h->d_cursor, (int)s_index);
+    if ((e = hipGraphLaunch(h->sg.exec, st)) != hipSuccess) return give_up("hipGraphLaunch", e);
+    h->cursor_expected = s_index - 1;
+    h->graph_launches += 1;
+    return 1;
 }
 
 int gcdm_sample_step_to(gcdm_handle* h, const float* z_in, float* z_out, const float* context, int32_t s_index, int32_t num_steps,
@@ -1172,6 +1278,10 @@ int gcdm_sample_step_to(gcdm_handle* h, const float* z_in, float* z_out, const f
     if (!h || !z_in || !z_out || num_steps <= 0 || s_index < 0 || s_index >= num_steps) return fail(h, "gcdm_sample_step: bad argument");
     if ((int64_t)h->gamma.size() != (int64_t)h->cfg.num_timesteps + 1) return fail(h, "gcdm_sample_step: gamma table not set");
     // s = s_index / num_steps, t = (s_index + 1) / num_steps (variational_diffusion.py:1335-1341); t [N] = t[batch_index] (:1239)
+    if (z_in == z_out && !noise) {
+        const int g = step_via_graph(h, z_out, context, s_index, num_steps, seed, flags, (hipStream_t)stream_);
+        if (g != 0) return g < 0 ? -1 : 0;
+    }
     return transition(h, z_in, z_out, nullptr, context, (float)s_index / (float)num_steps, (float)(s_index + 1) / (float)num_steps, noise, seed,
                       (uint32_t)s_index, flags, stream_);
 }
@@ -1278,6 +1388,8 @@ int gcdm_unnormalize_z(gcdm_handle* h, const float* z, float* out, void* stream_
 int gcdm_set_option(gcdm_handle* h, const char* name, int32_t value) {
     if (!h || !name) return fail(h, "gcdm_set_option: bad argument");
     const std::string k(name);
+    drop_step_graph(h);                     // every option below is baked into a captured step
+    if (k == "step_graph") { h->step_graph = value ? 1 : 0; h->step_graph_failed = false; return 0; }
     if (k == "mfma_mode") {                 // 0: fp32 MFMA, 1: split-precision f16 x3 (fp32-equivalent, 5.3x the matrix rate)
         if (value != 0 && value != 1) return fail(h, "gcdm_set_option(mfma_mode): 0 or 1");
         if (value == 1 && !h->x3_weights_ok) return fail(h, "gcdm_set_option(mfma_mode): a weight of this model is >= 2047 in magnitude (or not finite), outside the split-precision images at every exponent split; only mode 0 (fp32 MFMA) is available");
@@ -1316,6 +1428,8 @@ int gcdm_get_option(const gcdm_handle* h, const char* name) {
     if (k == "x3_shift") return h->x3_shift;
     if (k == "persistent") return h->persistent;
     if (k == "node_tile") return h->node_tile;
+    if (k == "step_graph") return (h->step_graph && !h->step_graph_failed) ? 1 : 0;
+    if (k == "graph_launches") return (int)(h->graph_launches & 0x7fffffff);
     return -1;
 }
 
@@ -1328,6 +1442,7 @@ int gcdm_profile_enable(gcdm_handle* h, int32_t enable) {
     }
     if (enable >= 2 && !GCDM_HAVE_STAMPS)
         return fail(h, "gcdm_profile_enable: in-kernel phase stamps need a library built with -DGCDM_STAMPS (tools/build_variants.sh stamps:-DGCDM_STAMPS)");
+    drop_step_graph(h);
     h->profile = enable != 0;
     h->profile_phases = enable == 2;
     h->profile_node = enable == 3;

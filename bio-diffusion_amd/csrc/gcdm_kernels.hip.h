@@ -1161,7 +1161,17 @@ __device__ __forceinline__ float philox_normal(uint64_t seed, uint32_t draw, uin
     return (col & 1) ? r * s : r * co;
 }
 
+// Step-dependent scalars of one ancestral transition, one row per step index, resident on the device: the kernels of a CAPTURED step (hipGraph,
+// gcdm_api.hip: StepGraph) read row [*cursor] instead of taking the values as launch arguments, so one instantiated graph serves every step.
+struct StepRow {
+    float t;                            // network time of the step (what k_fill writes into t [N])
+    float alpha_coef, c_eps, sigma;     // as in StepArgs
+    uint32_t draw;                      // Philox draw index of the step's noise
+    uint32_t pad[3];
+};
+
 struct StepArgs {
+    const StepRow* rows; const int* cursor;   // captured step: alpha_coef / c_eps / sigma / draw come from rows[*cursor] (else null)
     float* z;            // [N][D] in/out
     float* z_out;        // step / init: where the new latent goes (null = in place)
     uint32_t node_base;  // flat index of node 0 in the whole batch (Philox counter), for plans that are slices of a flat batch
@@ -1181,6 +1191,14 @@ __global__ __launch_bounds__(256) void k_fill(float* p, int n, float v) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i < n) p[i] = v;
 }
+
+// k_fill with the value from the step table (captured steps), and the cursor's own two kernels
+__global__ __launch_bounds__(256) void k_fill_row(float* p, int n, const StepRow* rows, const int* cursor) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) p[i] = rows[*cursor].t;
+}
+__global__ void k_cursor_set(int* cursor, int v) { *cursor = v; }
+__global__ void k_cursor_dec(int* cursor) { *cursor -= 1; }
 
 // whole-batch CoG re-projection if any molecule drifted (variational_diffusion.py:1389-1402)
 __global__ __launch_bounds__(64) void k_cog_fix(float* out, const int* noff, int D, const uint32_t* flags_dev, uint32_t* user_flags) {
@@ -1311,6 +1329,10 @@ __global__ __launch_bounds__(64) void k_inpaint_combine(const float* __restrict_
 __global__ __launch_bounds__(64) void k_sample(StepArgs a) {
     extern __shared__ __attribute__((aligned(16))) float ns[];  // [n][D] noise, then results
     const int b = blockIdx.x, o = a.noff[b], n = a.noff[b + 1] - o, D = a.D;
+    if (a.rows) {
+        const StepRow r = a.rows[*a.cursor];
+        a.alpha_coef = r.alpha_coef; a.c_eps = r.c_eps; a.sigma = r.sigma; a.draw = r.draw;
+    }
     for (int idx = threadIdx.x; idx < n * D; idx += 64) {
         const int i = idx / D, c = idx - i * D;
         ns[idx] = a.noise ? a.noise[(size_t)(o + i) * D + c] : philox_normal(a.seed, a.draw, a.node_base + (uint32_t)(o + i), (uint32_t)c);

@@ -30,6 +30,8 @@ from .variational_diffusion import EquivariantVariationalDiffusion, _segment_mea
 log = logging.getLogger(__name__)
 
 
+DEFAULT_LANES_MIN_SAMPLES = 64     # sample(): plain batches of at least this many molecules are drawn as two slices (see sample)
+
 class _Dummy:
     """Placeholder for globals (omegaconf containers, functools.partial(torch.optim.AdamW), ...) found in the
     ``hyper_parameters`` of a Lightning checkpoint; only ``state_dict`` is used."""
@@ -230,8 +232,11 @@ class _MoleculeGenerationDDPM(nn.Module):
         else:
             context = None
         plain = not any(k in kw for k in ("lanes", "noise_fn", "step_callback", "_init_xh")) and kw.get("return_frames", 1) == 1
-        if plain and not fix_noise and num_samples >= 256 and (node_mask is None or bool(node_mask.all())):
-            kw["lanes"] = 2            # big plain batches: two slices of the flat batch on two streams (same samples up to fp summation order, +4-5 %)
+        if plain and not fix_noise and num_samples >= DEFAULT_LANES_MIN_SAMPLES and (node_mask is None or bool(node_mask.all())):
+            # plain batches: two slices of the flat batch on two handles / streams (same samples up to fp summation order).  One slice's node kernels
+            # and launch tails run under the other's edge kernels: +4-5 % at 1024 QM9 molecules, +17 % at the evaluation driver's 100, +23 % at 64;
+            # GEOM-Drugs +-0 at 64, -5 % at 32 (tools/ab_lanes.sh) -- hence the threshold
+            kw["lanes"] = 2
         xh, batch_index, _ = self.ddpm.mol_gen_sample(num_samples=num_samples, num_nodes=num_nodes, node_mask=node_mask,
                                                       context=context, fix_noise=fix_noise, fix_self_conditioning_noise=fix_noise,
                                                       device=self.device, num_timesteps=num_timesteps, **kw)

@@ -194,6 +194,12 @@ int gcdm_debug_set_layer_limit(gcdm_handle* h, int32_t num_layers_to_run);
  * the tile list with the next tile's operands prefetched, whenever there are more tiles than that; 0: one workgroup per tile (A/B runs).  Same bits.
  * "node_tile": nodes per workgroup of the split-precision per-layer node kernel: 64 (every streamed weight byte feeds two 32-node MFMA tiles), 32, or
  * 0 = automatic (default; env GCDM_NODE_TILE): whichever needs fewer CU rounds for the plan's node count.  Same bits.
+ * "step_graph": 1 (default; env GCDM_STEP_GRAPH) / 0 -- gcdm_sample_step with on-device (Philox) noise enqueues ONE hipGraph launch per step instead
+ * of the step's ~25 kernels: the step is captured once per (z, context, flags, seed, num_steps) and every option / plan / weight state, the four
+ * scalars and the draw index that differ between steps are read by the captured kernels from a device table at a device cursor (any step order: a
+ * jump costs one 1-thread launch).  Same kernels and arguments, bit-identical latents; host cost per step 0.5-0.9 ms -> 0.01-0.03 ms.  Steps with a
+ * caller-supplied noise pointer, fix_noise, self-conditioning, profiling or a layer limit launch directly, as does a handle on which capture or
+ * instantiation failed once (gcdm_last_error says why; gcdm_get_option("step_graph") then reports 0).  "graph_launches" (read-only): steps served so far.
  * "cog_fix": 1 (default) / 0, see gcdm_unnormalize_z.
  * "fix_noise" (0/1): the x-part of every noise draw is centred over the whole flat batch instead of per molecule, as the reference's
  * `fix_noise=True` does (variational_diffusion.py:832-834, 1323-1325; used by sample_sweep_conditionally, src/models/__init__.py:200-226).
