@@ -651,7 +651,12 @@ def main():
         # split-precision mode issues three f16 MFMAs per fp32 multiply-add block: the fp32-equivalent roof is the f16 peak / 3
         peak = PEAK_F16_MFMA_TFLOPS / 3.0 if x3 else PEAK_FP32_MFMA_TFLOPS
         pmc = load_pmc_summary(args.workload, x3)
-        node_name = "k_node_x3<false" if x3 else "k_node<false"
+        # which layer node kernel a whole-batch launch of this plan runs (node_tile_for, csrc/gcdm_api.hip: 64-node tiles where they save a round of CUs)
+        cus_ = torch.cuda.get_device_properties(dev).multi_processor_count
+        nt_opt = lib.gcdm_get_option(h, b"node_tile")
+        r32_, r64_ = -(-(-(-N // 32)) // cus_), -(-(-(-N // 64)) // cus_)
+        node_tile_eff = nt_opt if nt_opt in (32, 64) else (64 if 1.55 * r64_ < r32_ else 32)
+        node_name = ("k_node_x3w" if node_tile_eff == 64 else "k_node_x3<false") if x3 else "k_node<false"
         pmc_node = load_pmc_summary(args.workload, x3, node_name)
         prof_edge_ms = prof_node_ms = prof_src = None
         if B == wl["B"] and args.streams == 1:          # the committed profiles are of the workload's own batch
@@ -693,7 +698,7 @@ def main():
                          "profiles_avg_launch_ms": prof_edge_ms, "profiles_source": prof_src,
                          # whole-step view with the headline's own clock (same slices, driver-contract window): every algorithmic FLOP of a step / ms_per_step / peak
                          "step_frac": alg_total / (ms_per_step * 1e-3) / 1e12 / peak,
-                         "node_kernel": {"kernel": node_name.replace("<false", "<false, 2>") if x3 else "k_node<false>", "avg_launch_ms": node_ms, "launches_per_step": d["L"],
+                         "node_kernel": {"kernel": node_name.replace("<false", "<false, 2>") if x3 else "k_node<false>", "nodes_per_workgroup": node_tile_eff if x3 else 32, "avg_launch_ms": node_ms, "launches_per_step": d["L"],
                                          "algorithmic_flop_per_launch": alg_node_layer, "achieved": node_achieved, "peak": peak, "unit": "TFLOP/s",
                                          "frac": (node_achieved / peak) if node_achieved else None, "traffic": pmc_node.get("hbm_bytes_per_launch"),
                                          "mfma_busy_frac_pmc": pmc_node.get("mfma_busy_frac"),
