@@ -7,6 +7,7 @@ after selected early steps, and the final decode.  -> tests/golden/long_full_qm9
     python tests/golden/make_long_golden.py ragged16     -> tests/golden/long_ragged16_qm9.npz: 16 molecules of 5 ... 27 atoms (~40 min of CPU)
     python tests/golden/make_long_golden.py config0      -> tests/golden/long_config0_qm9.npz: BASELINE.json configs[0], 64 molecules x 19 atoms (hours of CPU)
     python tests/golden/make_long_golden.py geom8        -> tests/golden/long_geom8.npz: 8 GEOM-Drugs-sized molecules of 18 ... 72 atoms, GEOM architecture
+    python tests/golden/make_long_golden.py cond6        -> tests/golden/long_cond6_qm9.npz: 6 molecules on the alpha-CONDITIONAL QM9 model (BASELINE.json configs[2]'s architecture), context per molecule stored
 
 Only data is stored (inputs = num_nodes + seeds, outputs); the weights are re-created from `synth.make_weights(..., seed=LONG_WEIGHT_SEED,
 scale_2d=0.25)` and the noise from `TapeNoise(LONG_NOISE_SEED)` wherever the fixture is used.
@@ -47,14 +48,21 @@ if len(sys.argv) > 1 and sys.argv[1] == "geom8":                # 8 GEOM-Drugs-s
     SIZES = [44, 31, 58, 18, 72, 40, 27, 52]
     CHECKPOINTS = [999, 900, 700, 500, 300, 100, 0]
     OUT_NAME = "long_geom8.npz"
+COND, CASE, CONTEXT_SEED = (), None, None
+if len(sys.argv) > 1 and sys.argv[1] == "cond6":                # the property-conditional model (configs[2]): context [B, 1] ~ N(0, 1) per molecule, broadcast to the atoms
+    COND, CASE, CONTEXT_SEED = ("alpha",), "qm9cond", 2
+    LONG_WEIGHT_SEED, LONG_NOISE_SEED = 83, 1357
+    SIZES = [9, 19, 4, 23, 14, 17]
+    CHECKPOINTS = [999, 900, 700, 500, 300, 100, 0]
+    OUT_NAME = "long_cond6_qm9.npz"
 
 
 def run(dtype):
     prev = torch.get_default_dtype()
     torch.set_default_dtype(dtype)          # the reference hard-wires the default dtype in localize / scalarize
     try:
-        cfgs = rh.load_reference_cfgs(DATASET, ())
-        d = synth.DATASET_DIMS[DATASET]
+        cfgs = rh.load_reference_cfgs(DATASET, COND)
+        d = synth.DATASET_DIMS[CASE or DATASET]
         net = rh.build_reference_dynamics(cfgs, seed=0)
         shapes = synth.dynamics_shapes(d["S"], d["V"], d["Se"], d["Ve"], d["L"], synth.dims_h_in(d))
         net.load_state_dict(synth.make_weights(shapes, seed=LONG_WEIGHT_SEED, scale_2d=0.25))
@@ -73,8 +81,12 @@ def run(dtype):
 
         ddpm.sample_p_zs_given_zt = spy
         t0 = time.time()
+        ctx = None
+        if COND:
+            # [B, 1] per molecule: mol_gen_sample expands it itself, context[batch_index] (variational_diffusion.py:1317-1320)
+            ctx = torch.randn((len(SIZES), 1), generator=torch.Generator().manual_seed(CONTEXT_SEED), dtype=torch.float32).to(dtype)
         with rh.NoiseTape(LONG_NOISE_SEED) as tape, torch.no_grad():
-            xh, bi, _ = ddpm.mol_gen_sample(num_samples=len(nn_), num_nodes=nn_, device="cpu")
+            xh, bi, _ = ddpm.mol_gen_sample(num_samples=len(nn_), num_nodes=nn_, device="cpu", context=ctx)
         print(f"{dtype}: {time.time() - t0:.0f} s, {len(tape.calls)} randn calls, max|x| = {xh[:, :3].abs().max().item():.3e}", flush=True)
         return xh, zs
     finally:
@@ -85,8 +97,10 @@ def main():
     assert rh.reference_available(), "reference checkout not found"
     x32, z32 = run(torch.float32)
     x64, z64 = run(torch.float64)
-    out = dict(dataset=DATASET, num_nodes=np.array(SIZES), weight_seed=LONG_WEIGHT_SEED, weight_scale=0.25, noise_seed=LONG_NOISE_SEED, T=1000,
+    out = dict(dataset=CASE or DATASET, num_nodes=np.array(SIZES), weight_seed=LONG_WEIGHT_SEED, weight_scale=0.25, noise_seed=LONG_NOISE_SEED, T=1000,
                checkpoints=np.array(CHECKPOINTS), final32=x32.float().numpy(), final64=x64.double().numpy())
+    if COND:
+        out["context"] = torch.randn((len(SIZES), 1), generator=torch.Generator().manual_seed(CONTEXT_SEED), dtype=torch.float32).numpy()
     for s in CHECKPOINTS:
         out[f"z32_{s}"] = z32[s].float().numpy()
         out[f"z64_{s}"] = z64[s].double().numpy()

@@ -168,7 +168,7 @@ def test_edge_list_and_geometry_match_reference_golden(golden_dir):
         net.debug_set_layer_limit(-1)
 
 
-@pytest.mark.parametrize("fixture", ["long_full_qm9.npz", "long_ragged16_qm9.npz", "long_geom8.npz", "long_config0_qm9.npz"])
+@pytest.mark.parametrize("fixture", ["long_full_qm9.npz", "long_ragged16_qm9.npz", "long_geom8.npz", "long_config0_qm9.npz", "long_cond6_qm9.npz"])
 @pytest.mark.parametrize("mode", MODES)
 def test_long_horizon_sampling_matches_reference_golden(mode, fixture, golden_dir):
     """SURVEY section 7 contract (iii): the FULL 1000-step free-running sample on the noise tape of tests/golden/long_full_qm9.npz
@@ -177,16 +177,18 @@ def test_long_horizon_sampling_matches_reference_golden(mode, fixture, golden_di
     outputs equal the reference's wherever its fp32 and fp64 runs agree.  Both matrix modes (f16x3 must hold this WITHOUT the fp32 re-run).
     Four fixtures: 4 molecules (n = 5, 19, 3, 11); a ragged batch of 16 molecules of 5 ... 27 atoms (275 atoms, rows cut by tile boundaries); round 4:
     8 GEOM-Drugs-sized molecules of 18 ... 72 atoms on the GEOM architecture (342 atoms, 16 802 edges), and BASELINE.json configs[0] itself -- 64 QM9
-    molecules x 19 atoms (the reference's own full run of that shape, hours of CPU in the build container; no CPU oracle time on the GPU box)."""
+    molecules x 19 atoms (the reference's own full run of that shape, hours of CPU in the build container; no CPU oracle time on the GPU box); and
+    6 molecules on the alpha-CONDITIONAL model (configs[2]'s architecture) with the stored per-molecule context."""
     path = os.path.join(golden_dir, fixture)
     if not os.path.exists(path):
         pytest.skip(f"{fixture} is not generated yet (tests/golden/make_long_golden.py)")
     g = np.load(path)
     case = str(g["dataset"]) if "dataset" in g.files else "qm9"
     net, W, cfgs = _net(case, seed=int(g["weight_seed"]), scale=float(g["weight_scale"]), mode=mode)
-    ddpm = pkg.EquivariantVariationalDiffusion(net, cfgs["diffusion_cfg"], cfgs["dataloader_cfg"], pkg.dataset_info(case)).cuda()
+    ddpm = pkg.EquivariantVariationalDiffusion(net, cfgs["diffusion_cfg"], cfgs["dataloader_cfg"], pkg.dataset_info("geom" if case == "geom" else "qm9")).cuda()
     nn_ = torch.tensor(g["num_nodes"])
     N, F, T = int(nn_.sum()), _ocfg(case).num_node_scalar_features, int(g["T"])
+    ctx = torch.tensor(g["context"]).cuda() if "context" in g.files else None       # [B, 1] per molecule; mol_gen_sample expands it (:1317-1320)
     tape = O.TapeNoise(int(g["noise_seed"]))
     draws = [torch.cat((tape(N, 3), tape(N, F)), dim=-1).cuda() for _ in range(T + 2)]
     want = {int(s) for s in g["checkpoints"]}
@@ -196,7 +198,7 @@ def test_long_horizon_sampling_matches_reference_golden(mode, fixture, golden_di
         if s in want:
             got[s] = z.detach().cpu().clone()
 
-    out, _, _ = ddpm.mol_gen_sample(num_samples=len(nn_), num_nodes=nn_, device="cuda", noise_fn=lambda k: draws[k], step_callback=cb)
+    out, _, _ = ddpm.mol_gen_sample(num_samples=len(nn_), num_nodes=nn_, device="cuda", context=ctx, noise_fn=lambda k: draws[k], step_callback=cb)
     out = out.cpu()
     assert net.mfma_mode == mode and (ddpm.last_flags & pkg._native.FLAG_F16_RANGE) == 0        # no fp32 re-run behind the scenes
     assert set(got) == want

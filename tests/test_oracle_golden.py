@@ -296,10 +296,11 @@ def test_oracle_follows_long_horizon_golden_first_50_steps(golden_dir):
             assert (z.double() - r32).abs().max().item() <= bound, s
 
 
-@pytest.mark.parametrize("fixture,steps", [("long_geom8.npz", 3), ("long_config0_qm9.npz", 1)])
+@pytest.mark.parametrize("fixture,steps", [("long_geom8.npz", 3), ("long_config0_qm9.npz", 1), ("long_cond6_qm9.npz", 3)])
 def test_oracle_follows_the_round4_long_goldens_first_steps(fixture, steps, golden_dir):
     """The first steps of the reference's own 1000-step runs of 8 GEOM-Drugs-sized molecules (GEOM architecture) and of BASELINE.json configs[0]
-    (64 QM9 molecules x 19 atoms) -- tests/golden/make_long_golden.py geom8 / config0 -- on the same tape: the oracle lands on z32_999 (the whole
+    (64 QM9 molecules x 19 atoms), and of 6 molecules on the alpha-conditional model -- tests/golden/make_long_golden.py geom8 / config0 / cond6 -- on the
+    same tape (and the stored per-molecule context): the oracle lands on z32_999 (the whole
     runs are compared on the GPU, tests/test_gpu_parity.py::test_long_horizon_sampling_matches_reference_golden)."""
     path = os.path.join(golden_dir, fixture)
     if not os.path.exists(path):
@@ -316,9 +317,10 @@ def test_oracle_follows_the_round4_long_goldens_first_steps(fixture, steps, gold
     mask = torch.ones_like(bi).bool()
     gam = O.gamma_table(cfg)
     noise = O.TapeNoise(int(g["noise_seed"]))
+    ctx = torch.tensor(g["context"])[bi] if "context" in g.files else None
     z = O.sample_combined_noise(noise, bi, B, mask, cfg.num_node_scalar_features, torch.float32)
     for s in range(999, 999 - steps, -1):
-        z, _ = O.sample_p_zs_given_zt(W, cfg, gam, s / 1000, (s + 1) / 1000, z, bi, B, mask, None, noise)
+        z, _ = O.sample_p_zs_given_zt(W, cfg, gam, s / 1000, (s + 1) / 1000, z, bi, B, mask, ctx, noise)
         if s == 999:
             r32, r64 = torch.tensor(g["z32_999"]).double(), torch.tensor(g["z64_999"])
             bound = 4.0 * (r32 - r64).abs().max().item() + 1e-4 * r64.abs().max().item()
