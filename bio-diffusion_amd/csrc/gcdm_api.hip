@@ -79,9 +79,10 @@ struct gcdm_handle {
     int cog_fix = 1;                 // gcdm_sample_final re-projects drifting centres of gravity (off for chain frames, reference :1389)
     int layer_limit = -1;
     int edge_tile = 0;               // 64: one 8-wave workgroup per CU; 32: two 4-wave workgroups per CU; 0: automatic (env GCDM_EDGE_TILE)
-    // automatic choice, measured on MI355X: split-precision kernels -> 32 (QM9 +-0 ... +2 %, GEOM +2 %, 100-molecule
-    // evaluation batches +12 ... 25 %: less round quantisation), fp32 kernels -> 64.  Rows cut by tile boundaries are summed from per-tile
-    // partials in tile order (AggSrc), so every choice is bit-reproducible for any molecule size.
+    // automatic choice, measured on MI355X: 64 for both kernel families and every batch size since the persistent kernel with
+    // next-tile prefetch (round 3) -- round 4, 64 vs 32 edges per tile, QM9 64 / 100 / 200 molecules: 71 / 84 / 114 against 68 / 78 / 100 molecules/s,
+    // 1024 molecules +2 %, GEOM 32 molecules 45.5 against 38.3.  Rows cut by tile boundaries are summed from per-tile partials in tile order
+    // (AggSrc), so every choice is bit-reproducible for any molecule size.
     int tile() const { return edge_tile ? edge_tile : 64; }
     int cus = 256;                   // compute units of the device (persistent edge-message workgroups: one per CU)
     int persistent = 1;              // option "persistent" / env GCDM_PERSISTENT=0: one workgroup per tile (round 2 schedule; A/B runs)
