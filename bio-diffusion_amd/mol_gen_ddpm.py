@@ -10,7 +10,6 @@ molecule and hands them to an optional ``molecule_builder`` (the reference's ``b
 """
 from __future__ import annotations
 
-import io
 import logging
 import os
 import pickle

@@ -2,7 +2,6 @@
 and a NumPy emulation of the MFMA operand mapping that the weight packing relies on."""
 import ctypes
 import importlib
-import math
 import os
 import re
 
