@@ -10,6 +10,10 @@ are gathered with one all_gather outside the timed region.
 
     python bench.py --gpus 1 --steps 100 --warmup 5
     python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port P bench.py --gpus 8 ...
+    python bench.py --gpus 8 ...          (without WORLD_SIZE in the environment: launches the 8 ranks itself, same line)
+
+At N > 1 the line also carries ``other_configs["configs[4] geom xN"]``: GEOM-Drugs, 256 molecules per GPU sharded over the N ranks
+(BASELINE.json configs[4] at N = 8), windows bracketed by barriers, slowest rank counts, plus the time of the final all_gather.
 
 Prints ONE JSON line (rank 0).  ``value`` = molecules/s of a full 1000-step sample = molecules / (1001 network
 evaluations x measured s/step) over all ranks.  ``roofline`` is for the dominant kernel (fused edge-message kernel,
@@ -216,9 +220,12 @@ def load_kernel_stats(workload, x3, prefix):
     return None, None
 
 
-def quick_config(pkg, name, dev, rank, lanes=2, steps=40, warmup=25):
+def quick_config(pkg, name, dev, rank, lanes=2, steps=40, warmup=25, dist=None, world=1):
     """ms/step of another BASELINE.json config on this GPU (same code path as the headline: the batch as `lanes` slices, Philox noise);
-    a short run, reported as extra fields of the one JSON line (configs[2] = qm9cond, configs[3] = geom)."""
+    a short run, reported as extra fields of the one JSON line (configs[2] = qm9cond, configs[3] = geom).
+    With `dist` (N > 1 ranks): BASELINE.json configs[4] -- every rank runs the workload on its own molecules (seed + rank, no collective in
+    the loop), every timed window is bracketed by barriers and the SLOWEST rank's median counts; then the samples are finished (decode) and
+    gathered with the path's one collective (all_gather of the final samples), timed on its own."""
     import synth
     wl = WORKLOADS[name]
     case = "geom" if wl["dataset"] == "geom" else ("qm9cond" if wl["cond"] else "qm9")
@@ -252,17 +259,42 @@ def quick_config(pkg, name, dev, rank, lanes=2, steps=40, warmup=25):
     sl.wait(); torch.cuda.synchronize(dev)
     def run_steps(k):
         nonlocal s_idx
+        if dist is not None:                 # every rank enters the window together; it ends when the slowest rank is done
+            dist.barrier()
         for _ in range(k):
             sl.step(max(s_idx, 0), 1000); s_idx -= 1
         sl.wait(); torch.cuda.synchronize(dev)
+        if dist is not None:
+            dist.barrier()
 
     ms, wins = median_of_windows(run_steps, steps)
     flags = int(sl.flags.max().item())
+    extra = {}
+    if dist is not None:
+        gloo = dist.get_backend() == "gloo"
+        tt = torch.tensor([ms], dtype=torch.float64, device="cpu" if gloo else dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        ms = float(tt.item())
+        sl.final()
+        torch.cuda.synchronize(dev)
+        dist.barrier()
+        tg = time.perf_counter()
+        src = sl.out.cpu() if gloo else sl.out           # (gloo = the one-GPU test hook: host tensors)
+        bufs = [torch.empty_like(src) for _ in range(world)]
+        dist.all_gather(bufs, src)
+        torch.cuda.synchronize(dev)
+        gather_ms = (time.perf_counter() - tg) * 1e3
+        fl = torch.tensor([flags | int(sl.flags.max().item())], dtype=torch.int64, device="cpu" if gloo else dev)
+        dist.all_reduce(fl, op=dist.ReduceOp.MAX)
+        flags = int(fl.item())
+        extra = {"n_gpus": world, "parallelism": f"shard{world}", "molecules": world * B, "final_gather_ms": gather_ms,
+                 "gathered_rows": int(sum(b.shape[0] for b in bufs)), "outputs_finite": bool(all(torch.isfinite(b).all().item() for b in bufs)),
+                 "timing": "windows bracketed by barriers on every rank; ms_per_step = MAX over ranks of the median window"}
     sl.close()
     ddpm.release_lanes()
     net.release()
-    return {"workload": wl["name"], "ms_per_step": ms, "value": B / (ms * 1e-3 * NET_EVALS_PER_SAMPLE), "unit": "molecules/s", "steps": steps,
-            "windows_ms_per_step": [round(w, 4) for w in wins], "slices_of_the_batch": lanes, "flags": flags, "atoms": int(num_nodes.sum()), "edges": int((num_nodes.long() ** 2).sum())}
+    return {"workload": wl["name"], "ms_per_step": ms, "value": world * B / (ms * 1e-3 * NET_EVALS_PER_SAMPLE), "unit": "molecules/s", "steps": steps,
+            "windows_ms_per_step": [round(w, 4) for w in wins], "slices_of_the_batch": lanes, "flags": flags, "atoms": int(num_nodes.sum()), "edges": int((num_nodes.long() ** 2).sum()), **extra}
 
 
 def eval_driver_config(pkg, dev, rank, in_flight, steps=100):
@@ -327,8 +359,24 @@ def main():
                                                            "(the evaluation driver's concurrent_batches; for small batches)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N` (the shape of the driver's 1-GPU command): launch the N ranks ourselves -- one process per GPU through
+        # torch.distributed.run on the loopback address -- and hand their output through: rank 0 prints the ONE JSON line
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.call(cmd, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1")))
+
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
+    if os.environ.get("GCDM_BENCH_LAUNCH_ONLY") == "1":      # (test hook, tests/test_parallel_cpu.py: the self-launch above on a box without a GPU)
+        if rank == 0:
+            print(json.dumps({"launched_world": world, "gpus": args.gpus, "master_addr": os.environ.get("MASTER_ADDR")}))
+        return
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
     if args.gpus > 1 or world > 1:
@@ -513,6 +561,12 @@ def main():
         other_configs["geom_ragged"] = quick_config(pkg, "geom_ragged", dev, rank)
         other_configs["qm9_eval"] = eval_driver_config(pkg, dev, rank, 1)
         other_configs["qm9_eval_4_in_flight"] = eval_driver_config(pkg, dev, rank, 4)
+
+    # BASELINE.json configs[4] at N > 1: GEOM-Drugs, 256 molecules per GPU, sharded over the ranks (per-rank workload = configs[3])
+    sharded_geom = None
+    if world > 1 and dist is not None and not args.no_other_configs:
+        log("configs[4]: GEOM-Drugs 256 / GPU, sharded ...")
+        sharded_geom = quick_config(pkg, "geom", dev, rank, dist=dist, world=world)
 
     # Launch durations of the two kernel families of a layer -- the fused edge-message kernel (dominant) and the node kernel -- from HIP events the
     # library records on the launch stream.  These need WHOLE-BATCH launches on one handle (the slices' kernels of the timed loop overlap each
@@ -733,6 +787,8 @@ def main():
         res["roofline"]["pmc_collected_at_commit"] = pmc.get("collected_at_commit")
         if other_configs is not None:
             res["other_configs"] = other_configs
+        if sharded_geom is not None:
+            res["other_configs"] = {f"configs[4] geom x{world}": sharded_geom}
         if not args.no_cpu_baseline and world == 1:
             log("cpu baseline ...")
             res["cpu_baseline"] = cpu_baseline(wl["dataset"], wl["cond"], dims)

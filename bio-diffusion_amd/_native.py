@@ -64,8 +64,9 @@ def build(force: bool = False) -> str:
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     tmp = f"{LIB_PATH}.{os.getpid()}.tmp"          # concurrent builders (one per rank) never see a half-written library
     # packed-fp32 VALU ops (v_pk_fma_f32 & co.) are switched off: with them the 32-edge split-precision kernel is not bit-reproducible
-    # from run to run (first wrong values: the pre-phase FMAs the compiler had packed, fed by per-lane VMEM loads), and
-    # they buy nothing here -- the compiler needs as many v_mov to build the register pairs as it saves (measured: +-0 %).
+    # from run to run (first wrong values: the pre-phase FMAs the SLP vectoriser had packed, fed by per-lane VMEM loads), and
+    # they buy nothing here -- round 5 wrote the packable steps of the VALU phases on float2 by hand (csrc/gcdm_edge_x3.hip.h, "packed fp32"):
+    # 13 % fewer VALU instructions, +1.4 % tile cycles (+7.7 % with packed ops between the MFMAs); profiles/r05_packed_fp32_ab.md.
     cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops",
            "-o", tmp] + SOURCES
     try:

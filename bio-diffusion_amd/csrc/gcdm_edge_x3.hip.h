@@ -47,6 +47,77 @@ __device__ __forceinline__ float silu_scaled(float xs) { return xs; }
 __device__ __forceinline__ float silu_scaled(float xs) { return xs * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(xs)); }
 #endif
 
+// ---- packed fp32 (round 5: measured, NOT the default) -------------------------------------------------------------------------------
+// v_pk_{mul,add,fma}_f32 process an aligned register PAIR per instruction.  Every element-wise step of the VALU phases whose operands sit in
+// adjacent accumulator registers (channels 2i, 2i+1 of one edge) is written below on float2 values through pk_*<PK>: the accumulator merge, SiLU's
+// denominator and product, the prescale of every hi / lo' split, the residual add, the gate-partial fold, the attention scale.  With PK the
+// QM9 kernel issues 13 % fewer VALU instructions per tile (static census 3 887 -> 3 390) -- and runs SLOWER: tile 62 290 -> 63 170 cycles with the
+// packed forms in the VALU phases only, -> 67 070 with them between the MFMAs of the GEMM phases as well (a GEMM phase 9 620 -> 11 000 cycles);
+// GEOM 61 940 -> 60 960 / 63 900.  Same bits in every variant (forward and sampler hashes equal).  A packed fp32 instruction costs this kernel what
+// the two scalar ones cost, and beside MFMAs much more (profiles/r05_packed_fp32_ab.md; round 3 saw the same with the compiler's own packing).
+// So: PK = false, and the library keeps the rounds 1-4 build line (-packed-fp32-ops off; the assembler refuses v_pk_*_f32 without the feature).
+//     A/B:  GCDM_BUILD_BASE=-fno-slp-vectorize tools/build_variants.sh "pk:-DGCDM_X3_PK=1" "pkB:-DGCDM_X3_PK=1 -DGCDM_X3_PK_GEMM=0"
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+#if defined(GCDM_X3_PK) && GCDM_X3_PK
+constexpr bool X3_PK = true;
+#else
+constexpr bool X3_PK = false;
+#endif
+// ... and whether the pieces that are issued BETWEEN the MFMAs of a GEMM phase (the tail-skewed SiLU of N-tile 0, the hooked vector stages) use them too
+#ifdef GCDM_X3_PK_GEMM
+constexpr bool X3_PKG = X3_PK && (GCDM_X3_PK_GEMM != 0);
+#else
+constexpr bool X3_PKG = X3_PK;
+#endif
+template <bool PK = X3_PK> __device__ __forceinline__ f32x2 pk_mul(f32x2 a, f32x2 b) { if constexpr (PK) return a * b; else return (f32x2){a[0] * b[0], a[1] * b[1]}; }
+template <bool PK = X3_PK> __device__ __forceinline__ f32x2 pk_add(f32x2 a, f32x2 b) { if constexpr (PK) return a + b; else return (f32x2){a[0] + b[0], a[1] + b[1]}; }
+template <bool PK = X3_PK> __device__ __forceinline__ f32x2 pk_mul1(f32x2 a, float s) { if constexpr (PK) return a * (f32x2){s, s}; else return (f32x2){a[0] * s, a[1] * s}; }
+template <bool PK = X3_PK> __device__ __forceinline__ f32x2 pk_add1(f32x2 a, float s) { if constexpr (PK) return a + (f32x2){s, s}; else return (f32x2){a[0] + s, a[1] + s}; }
+template <bool PK = X3_PK> __device__ __forceinline__ f32x2 pk_fma1(f32x2 a, float s, f32x2 c) {
+    if constexpr (PK) return __builtin_elementwise_fma(a, (f32x2){s, s}, c);
+    else return (f32x2){__builtin_fmaf(a[0], s, c[0]), __builtin_fmaf(a[1], s, c[1])};
+}
+// SiLU (scaled units, see silu_scaled) of two adjacent channels: exp2 x2, packed add, rcp x2, packed multiply -- 6 issue slots instead of 8
+#ifdef GCDM_ABL_NOSILU
+template <bool PK = X3_PK> __device__ __forceinline__ f32x2 silu_scaled2(f32x2 xs) { return xs; }
+#else
+template <bool PK = X3_PK> __device__ __forceinline__ f32x2 silu_scaled2(f32x2 xs) {
+    const f32x2 e = {__builtin_amdgcn_exp2f(xs[0]), __builtin_amdgcn_exp2f(xs[1])};
+    const f32x2 d = pk_add1<PK>(e, 1.0f);
+    const f32x2 r = {__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
+    return pk_mul<PK>(xs, r);
+}
+#endif
+// merge of the two accumulators + SiLU over one 32 x 32 accumulator tile (16 registers per lane)
+template <bool PK = X3_PK> __device__ __forceinline__ void silu_merge16(f32x16& dst, const f32x16& am, const f32x16& al, float inv) {
+#pragma unroll
+    for (int r = 0; r < 16; r += 2) {
+        const f32x2 p = pk_fma1<PK>((f32x2){al[r], al[r + 1]}, inv, (f32x2){am[r], am[r + 1]});
+        const f32x2 s = silu_scaled2<PK>(p);
+        dst[r] = s[0]; dst[r + 1] = s[1];
+    }
+}
+// the node kernels' form (true units, fast_silu of gcdm_kernels.hip.h): merge, x * rcp(1 + exp(-x)) with the add and the product packed
+__device__ __forceinline__ void fast_silu_merge16(f32x16& dst, const f32x16& am, const f32x16& al, float inv) {
+#pragma unroll
+    for (int r = 0; r < 16; r += 2) {
+        const f32x2 p = pk_fma1((f32x2){al[r], al[r + 1]}, inv, (f32x2){am[r], am[r + 1]});
+        const f32x2 e = {__expf(-p[0]), __expf(-p[1])};
+        const f32x2 d = pk_add1(e, 1.0f);
+        const f32x2 q = {__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
+        const f32x2 s = pk_mul(p, q);
+        dst[r] = s[0]; dst[r + 1] = s[1];
+    }
+}
+// merge only (GCP2s without a scalar nonlinearity)
+__device__ __forceinline__ void merge16(f32x16& am, const f32x16& al, float inv) {
+#pragma unroll
+    for (int r = 0; r < 16; r += 2) {
+        const f32x2 p = pk_fma1((f32x2){al[r], al[r + 1]}, inv, (f32x2){am[r], am[r + 1]});
+        am[r] = p[0]; am[r + 1] = p[1];
+    }
+}
+
 // v_sqrt_f32 (1 ulp) instead of the ~20-instruction correctly rounded expansion: the argument is >= 1e-8, never denormal
 __device__ __forceinline__ float fast_sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
 
@@ -95,11 +166,12 @@ __device__ __forceinline__ void split16(float x, _Float16& hi, _Float16& lo) {
 // ones (-15 % / -20 % on the state-image phase in the micro-benchmark), every destination a full 32-bit write.  Bit-identical to split16:
 // all products are by powers of two, x - hi * 2^11 is exact in fp32, one rounding to f16 at the end of each half.
 typedef _Float16 h2 __attribute__((ext_vector_type(2)));
-typedef float f32x2 __attribute__((ext_vector_type(2)));
+template <bool PK = X3_PK>
 __device__ __forceinline__ void split16x2(float x0, float x1, h2& hi, h2& lo) {
     const float pre = X3_PRE, neg = -X3_SCALE;
     uint32_t hiu, lou;
-    const float t0 = x0 * pre, t1 = x1 * pre;
+    const f32x2 t = pk_mul1<PK>((f32x2){x0, x1}, pre);    // (round 5: one packed multiply)
+    const float t0 = t[0], t1 = t[1];
     float r0, r1;
     asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(hiu) : "v"(t0), "v"(t1));
     asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel_hi:[1,0,0]" : "=v"(r0) : "v"(hiu), "s"(neg), "v"(x0));
@@ -489,11 +561,16 @@ __device__ __forceinline__ void put_gate_partial(float* PG, const f32x16 (&gm)[N
     for (int n = 0; n < NT; ++n)
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-            v4f v;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) v[i] = gm[n][4 * t + i] + gl[n][4 * t + i] * X3_INV_SCALE;
+            const float inv = X3_INV_SCALE;
+            f32x2 v0 = pk_fma1((f32x2){gl[n][4 * t], gl[n][4 * t + 1]}, inv, (f32x2){gm[n][4 * t], gm[n][4 * t + 1]});
+            f32x2 v1 = pk_fma1((f32x2){gl[n][4 * t + 2], gl[n][4 * t + 3]}, inv, (f32x2){gm[n][4 * t + 2], gm[n][4 * t + 3]});
             v4f* p = (v4f*)(PG + pg_off<ET>(slot, 32 * n + l31, 2 * t + half));      // channels 8t + 4 half + {0..3}
-            *p = add ? *p + v : v;
+            if (add) {
+                const v4f o = *p;
+                v0 = pk_add((f32x2){o[0], o[1]}, v0);
+                v1 = pk_add((f32x2){o[2], o[3]}, v1);
+            }
+            *p = (v4f){v0[0], v0[1], v1[0], v1[1]};
         }
 }
 
@@ -578,11 +655,12 @@ __device__ __forceinline__ bool put16(char* XH, char* XL, int TP, int g8, int sl
 #define MFMA1632(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_f16((a), (b), (c), 0, 0, 0)
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+template <bool PK = X3_PK>
 __device__ __forceinline__ void split4(const float (&x)[4], h4& hi, h4& lo, float& amax) {
 #pragma unroll
     for (int s = 0; s < 4; s += 2) {
         h2 a, b;
-        split16x2(x[s], x[s + 1], a, b);
+        split16x2<PK>(x[s], x[s + 1], a, b);
         hi[s] = a[0]; hi[s + 1] = a[1];
         lo[s] = b[0]; lo[s + 1] = b[1];
         X3_TRACK(amax, x[s], x[s + 1]);
@@ -614,7 +692,11 @@ struct VecStage {
     __device__ __forceinline__ v4f gate_sum(int m) const {
         v4f g = *(const v4f*)(bg + 16 * m + 4 * vq);
 #pragma unroll
-        for (int s = 0; s < 4; ++s) g += *(const v4f*)(PG + pg_off<ET>(s, ve, 4 * m + vq));
+        for (int s = 0; s < 4; ++s) {
+            const v4f v = *(const v4f*)(PG + pg_off<ET>(s, ve, 4 * m + vq));
+            if constexpr (X3_PKG) g += v;
+            else { g[0] += v[0]; g[1] += v[1]; g[2] += v[2]; g[3] += v[3]; }
+        }
         return g;
     }
     static __device__ __forceinline__ v4f sig4(v4f g) {
@@ -691,16 +773,16 @@ struct VecStage {
     }
     __device__ __forceinline__ void split_vh(int b) {
         const float v0[4] = {vraw[0], vraw[1], vraw[2], vraw[3]}, v1[4] = {vraw[4], vraw[5], vraw[6], vraw[7]};
-        split4(v0, sh0, sl0, amax);
-        split4(v1, sh1, sl1, amax);
+        split4<X3_PKG>(v0, sh0, sl0, amax);
+        split4<X3_PKG>(v1, sh1, sl1, amax);
         bh[b] = cat44(sh0, sh1);
         bl[b] = cat44(sl0, sl1);
         x3_settle(bh[b], bl[b]);
     }
     __device__ __forceinline__ void split_vv(int x) {                                             // B images of vector_down: own groups q | 4 + q
         const float b0[4] = {va[x][0], va[x][1], va[x][2], va[x][3]}, b1[4] = {vb[x][0], vb[x][1], vb[x][2], vb[x][3]};
-        split4(b0, sh0, sl0, amax);
-        split4(b1, sh1, sl1, amax);
+        split4<X3_PKG>(b0, sh0, sl0, amax);
+        split4<X3_PKG>(b1, sh1, sl1, amax);
     }
     __device__ __forceinline__ void pre_x(int x) {
         h8 xh = cat44(sh0, sh1), xl = cat44(sl0, sl1);
@@ -715,7 +797,7 @@ struct VecStage {
     __device__ __forceinline__ void vhb_x(int x, h8& img) {                                       // [hi(3) 0 | lo'(3) 0] of hidden vectors 3q .. 3q+2
         const float v[4] = {o[x][0], o[x][1], o[x][2], 0.f};
         h4 vh, vl;
-        split4(v, vh, vl, amax);
+        split4<X3_PKG>(v, vh, vl, amax);
         img = cat44(vh, vl);
         x3_settle(img);
     }
@@ -738,8 +820,8 @@ struct VecStage {
         } else if constexpr (I == T0 + 5) {       // extended-K group 32 + q of this edge
             const float c0[4] = {ev[0], ev[1], ev[2], ev[3]}, c1[4] = {ev[4], ev[5], 0.f, vq == 3 ? 1.0f : 0.f};
             h4 h0_, l0_, h1_, l1_;
-            split4(c0, h0_, l0_, amax);
-            split4(c1, h1_, l1_, amax);
+            split4<X3_PKG>(c0, h0_, l0_, amax);
+            split4<X3_PKG>(c1, h1_, l1_, amax);
             *(h8*)(XH + ((32 + vq) * ETP + ve) * 16) = cat44(h0_, h1_);
             *(h8*)(XL + ((32 + vq) * ETP + ve) * 16) = cat44(l0_, l1_);
         } else if constexpr (I == T0 + 6) { vhb_x(0, bh[0]); }
@@ -1344,14 +1426,16 @@ __global__ __launch_bounds__(ET * 8) __attribute__((amdgpu_waves_per_eu(2, 2))) 
 #ifdef GCDM_ABL_NOPQ
                     for (int t = 0; t < 4; ++t) am[m][n][4 * q + t] = 0.f;
 #else
-                    for (int t = 0; t < 4; ++t) am[m][n][4 * q + t] = in.pqi[m][n][q][t] + in.pqj[m][n][q][t];
+                    for (int t = 0; t < 4; t += 2) {
+                        const f32x2 s2 = pk_add((f32x2){in.pqi[m][n][q][t], in.pqi[m][n][q][t + 1]}, (f32x2){in.pqj[m][n][q][t], in.pqj[m][n][q][t + 1]});
+                        am[m][n][4 * q + t] = s2[0]; am[m][n][4 * q + t + 1] = s2[1];
+                    }
 #endif
         STAMP(3);
         constexpr int SILU0_N0 = (NT == 2 && MT == 1) ? 1 : 0;       // N-tile 0's SiLU rides in the GEMM's tail (x3_tail_skew)
         if constexpr (SILU0_N0) {
             tile_gemm_x3z<MT, NT, PD, KB0C, false, true>(am, al2, ring, wp, o0H, o0L, xh8, xl8, ETP, lane, [&]() {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) st[0][0][r] = silu_scaled(am[0][0][r] + al2[0][0][r] * X3_INV_SCALE);
+                silu_merge16<X3_PKG>(st[0][0], am[0][0], al2[0][0], X3_INV_SCALE);
             });
         } else {
             tile_gemm_x3z<MT, NT, PD, KB0C, false, true>(am, al2, ring, wp, o0H, o0L, xh8, xl8, ETP, lane);
@@ -1363,9 +1447,7 @@ __global__ __launch_bounds__(ET * 8) __attribute__((amdgpu_waves_per_eu(2, 2))) 
 #pragma unroll
         for (int m = 0; m < MT; ++m)
 #pragma unroll
-            for (int n = SILU0_N0; n < NT; ++n)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) st[m][n][r] = silu_scaled(am[m][n][r] + al2[m][n][r] * X3_INV_SCALE);
+            for (int n = SILU0_N0; n < NT; ++n) silu_merge16(st[m][n], am[m][n], al2[m][n], X3_INV_SCALE);
         STAMP(5);
 #ifndef GCDM_ABL_NOGATE
         gate_partial_x3p<MT, NT, true>(gm, gl, st, gw0);
@@ -1398,9 +1480,7 @@ __global__ __launch_bounds__(ET * 8) __attribute__((amdgpu_waves_per_eu(2, 2))) 
         if (k == GCDM_STAMP_K) STAMP(10);
         [[maybe_unused]] auto silu_n0 = [&]() {             // SiLU of N-tile 0, issued between the last MFMAs of N-tile 1 (tile_gemm_x3s, tail skew)
 #pragma unroll
-            for (int m = 0; m < MT; ++m)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) am[m][0][r] = silu_scaled(am[m][0][r] + al2[m][0][r] * X3_INV_SCALE);
+            for (int m = 0; m < MT; ++m) silu_merge16<X3_PKG>(am[m][0], am[m][0], al2[m][0], X3_INV_SCALE);
         };
         if (vhalf == (k & 1)) {
             VecStage<ET, H0, k == 0, VE == 8> vs;
@@ -1430,9 +1510,7 @@ __global__ __launch_bounds__(ET * 8) __attribute__((amdgpu_waves_per_eu(2, 2))) 
 #pragma unroll
         for (int m = 0; m < MT; ++m)
 #pragma unroll
-            for (int n = SILU_N0; n < NT; ++n)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) am[m][n][r] = silu_scaled(am[m][n][r] + al2[m][n][r] * X3_INV_SCALE);
+            for (int n = SILU_N0; n < NT; ++n) silu_merge16(am[m][n], am[m][n], al2[m][n], X3_INV_SCALE);
         if (k == GCDM_STAMP_K) STAMP(13);
 #ifndef GCDM_ABL_NOGATE
         gate_partial_x3p<MT, NT, true>(gm, gl, am, gwk);
@@ -1468,7 +1546,10 @@ __global__ __launch_bounds__(ET * 8) __attribute__((amdgpu_waves_per_eu(2, 2))) 
 #pragma unroll
             for (int n = 0; n < NT; ++n)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) st[m][n][r] += am[m][n][r];       // residual add in fp32 (gcpnet.py:701)
+                for (int r = 0; r < 16; r += 2) {                              // residual add in fp32 (gcpnet.py:701), two channels per instruction
+                    const f32x2 s2 = pk_add((f32x2){st[m][n][r], st[m][n][r + 1]}, (f32x2){am[m][n][r], am[m][n][r + 1]});
+                    st[m][n][r] = s2[0]; st[m][n][r + 1] = s2[1];
+                }
         if (k == 2) load_const(std::integral_constant<int, 2>{}, a, me, start_ + min(it_ + stride_, cnt_ - 1), in);
         if (k < 2) {
 #ifndef GCDM_ABL_NOSTORE
@@ -1525,7 +1606,10 @@ __global__ __launch_bounds__(ET * 8) __attribute__((amdgpu_waves_per_eu(2, 2))) 
 #pragma unroll
                 for (int n = 0; n < NT; ++n)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) st[m][n][r] *= att[n];
+                    for (int r = 0; r < 16; r += 2) {
+                        const f32x2 s2 = pk_mul1((f32x2){st[m][n][r], st[m][n][r + 1]}, att[n]);
+                        st[m][n][r] = s2[0]; st[m][n][r + 1] = s2[1];
+                    }
             static_for<GCH / 2, GCH>([&](auto gc) { load_gather_part(gc, a, me, ix, in); });
             __builtin_amdgcn_sched_barrier(0);
             store_state<MT, NT, false>(XS4, 0, st, ETP, mt0, lane, 0);

@@ -346,8 +346,7 @@ __global__ __launch_bounds__(NX_THREADS) void k_node_x3(NodeX3Args ax) {
         __syncthreads();
         acc_bias(w.b);
         gemm(integral_constant<int, 0>{}, ax.emb.wH, ax.emb.wL, ax.emb.KB, 0);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) am[0][0][r] += al[0][0][r] * X3_INV_SCALE;     // nonlinearities (None, None): h = p
+        merge16(am[0][0], al[0][0], X3_INV_SCALE);     // nonlinearities (None, None): h = p
         hst = am[0][0];
         fold_gate(ax.emb.wgH, ax.emb.wgL, am);
         __syncthreads();
@@ -448,8 +447,7 @@ __global__ __launch_bounds__(NX_THREADS) void k_node_x3(NodeX3Args ax) {
             acc_bias(w.b);
             gemm(integral_constant<int, 34>{}, ax.ff.wH, ax.ff.wL, ax.ff.KB, 0);        // K' = 512 + 16 + 16
             NSTAMP(6);
-#pragma unroll
-            for (int r = 0; r < 16; ++r) am[0][0][r] = fast_silu(am[0][0][r] + al[0][0][r] * X3_INV_SCALE);
+            fast_silu_merge16(am[0][0], am[0][0], al[0][0], X3_INV_SCALE);
             __syncthreads();                                      // every wave is done reading agg.s (8-groups 0..31)
             over |= store_block_x3(XH, XL, 4 * wave, am[0][0], NTP, lane);   // hidden activations of Linear-SiLU-Linear
             __syncthreads();
@@ -459,8 +457,7 @@ __global__ __launch_bounds__(NX_THREADS) void k_node_x3(NodeX3Args ax) {
             vm_pos.load(ax.pos.vmH, ax.pos.vmL, lane);
             gemm(integral_constant<int, 16>{}, ax.ff.w2H, ax.ff.w2L, 16, 0);
             NSTAMP(8);
-#pragma unroll
-            for (int r = 0; r < 16; ++r) am[0][0][r] += al[0][0][r] * X3_INV_SCALE;   // nonlinearities (None, None)
+            merge16(am[0][0], al[0][0], X3_INV_SCALE);   // nonlinearities (None, None)
             fold_gate_w(gw, am);
             __syncthreads();
             NSTAMP(9);
@@ -491,8 +488,7 @@ __global__ __launch_bounds__(NX_THREADS) void k_node_x3(NodeX3Args ax) {
             const GateW gw = load_gate(ax.pos.wgH, ax.pos.wgL);
             gemm(integral_constant<int, 18>{}, ax.pos.wH, ax.pos.wL, ax.pos.KB, HB8);    // K' = 256 + 8 + 16 -> 288
             NSTAMP(13);
-#pragma unroll
-            for (int r = 0; r < 16; ++r) am[0][0][r] = fast_silu(am[0][0][r] + al[0][0][r] * X3_INV_SCALE);
+            fast_silu_merge16(am[0][0], am[0][0], al[0][0], X3_INV_SCALE);
             fold_gate_w(gw, am);
             __syncthreads();
             vec_finish_w<NT_, 8, 1, NX_THREADS>(PG, fw_pos, 1, VH, e, part, [&](int c, float ox, float oy, float oz) {

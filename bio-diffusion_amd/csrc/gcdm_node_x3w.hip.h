@@ -306,8 +306,7 @@ __global__ __launch_bounds__(512) void k_node_x3w(NodeX3Args ax) {
         NSTAMP(6);
 #pragma unroll
         for (int n = 0; n < 2; ++n)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) am[0][n][r] = fast_silu(am[0][n][r] + al[0][n][r] * X3_INV_SCALE);
+            fast_silu_merge16(am[0][n], am[0][n], al[0][n], X3_INV_SCALE);
         __syncthreads();                                                                 // every wave is done reading the h images
         over |= store_state_x3<1, 2>(XH, XL, 0, am, TP, wave, lane);                     // hidden activations of Linear-SiLU-Linear
         __syncthreads();
@@ -319,8 +318,7 @@ __global__ __launch_bounds__(512) void k_node_x3w(NodeX3Args ax) {
         NSTAMP(8);
 #pragma unroll
         for (int n = 0; n < 2; ++n)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) am[0][n][r] += al[0][n][r] * X3_INV_SCALE;       // nonlinearities (None, None)
+            merge16(am[0][n], al[0][n], X3_INV_SCALE);       // nonlinearities (None, None)
         fold_gate_w(gw, am);
         __syncthreads();
         NSTAMP(9);
@@ -361,8 +359,7 @@ __global__ __launch_bounds__(512) void k_node_x3w(NodeX3Args ax) {
         NSTAMP(13);
 #pragma unroll
         for (int n = 0; n < 2; ++n)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) am[0][n][r] = fast_silu(am[0][n][r] + al[0][n][r] * X3_INV_SCALE);
+            fast_silu_merge16(am[0][n], am[0][n], al[0][n], X3_INV_SCALE);
         fold_gate_w(gw, am);
         __syncthreads();
         nw_vec_finish<8, 1>(VV, VH, [&](int i, int, int h) { return fw_pos.w[i][h >> 2][h & 3]; }, [&](int i, int) { return fw_pos.bg[i]; }, 1, e, part,

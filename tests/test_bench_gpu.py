@@ -62,3 +62,42 @@ def test_one_rank_under_torchrun_prints_the_n1_line():
     assert set(a) == set(b) and set(a["config"]) == set(b["config"]) and set(a["roofline"]) == set(b["roofline"])
     assert a["metric"] == b["metric"] and a["unit"] == b["unit"] and a["config"]["workload"] == b["config"]["workload"]
     assert abs(a["ms_per_step"] / b["ms_per_step"] - 1) < 0.25                 # same work, same box (clock noise only)
+
+
+def test_plain_command_with_gpus_2_launches_its_own_ranks_and_measures_configs4():
+    """`python bench.py --gpus 2` with no WORLD_SIZE in the environment -- the shape of the driver's 1-GPU command -- must start its two ranks itself
+    (torch.distributed.run on 127.0.0.1) and still print ONE JSON line; at N > 1 that line carries the BASELINE.json configs[4] leg (GEOM-Drugs,
+    256 molecules per GPU, sharded) next to the QM9 weak-scaling headline."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(HSA_ENABLE_IPC_MODE_LEGACY="0", GCDM_BENCH_SINGLE_GPU_TEST="1")
+    args = [a for a in QUICK if a != "--no-other-configs"]
+    p = subprocess.run([sys.executable, "bench.py", "--gpus", "2"] + args, cwd=ROOT, env=env, capture_output=True, text=True, timeout=400)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    r = json.loads(lines[0])
+    _check_line(r, 2, 128)
+    leg = r["other_configs"]["configs[4] geom x2"]
+    assert leg["n_gpus"] == 2 and leg["parallelism"] == "shard2" and leg["molecules"] == 512 and leg["gathered_rows"] == 2 * 256 * 44
+    assert leg["final_gather_ms"] > 0.0 and leg["outputs_finite"] is True and leg["flags"] == 0
+    assert abs(leg["value"] / (512 / (1001 * leg["ms_per_step"] * 1e-3)) - 1) < 1e-9
+
+
+def test_rccl_communicator_and_all_gather_with_world_size_one():
+    """The "nccl" backend (= RCCL on ROCm) itself: communicator creation, barrier and the all_gather of the final samples, with world size 1 on
+    this box's GPU -- so that the first RCCL call of this code base is not made on the driver's 8-GPU node (the two-rank tests above share
+    one GPU and therefore have to use gloo)."""
+    code = (
+        "import os, torch, torch.distributed as dist\n"
+        "torch.cuda.set_device(0)\n"
+        "dist.init_process_group('nccl', rank=0, world_size=1)\n"
+        "x = torch.arange(19 * 9, dtype=torch.float32, device='cuda').view(19, 9)\n"
+        "bufs = [torch.empty_like(x)]\n"
+        "dist.barrier(); dist.all_gather(bufs, x)\n"
+        "t = torch.tensor([3.5], dtype=torch.float64, device='cuda'); dist.all_reduce(t, op=dist.ReduceOp.MAX)\n"
+        "torch.cuda.synchronize()\n"
+        "assert torch.equal(bufs[0], x) and float(t.item()) == 3.5 and dist.get_backend() == 'nccl'\n"
+        "dist.destroy_process_group(); print('RCCL_OK')\n")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
+    p = subprocess.run([sys.executable, "-c", code], cwd=ROOT, env=env, capture_output=True, text=True, timeout=280)
+    assert p.returncode == 0 and "RCCL_OK" in p.stdout, p.stderr[-3000:]

@@ -123,3 +123,20 @@ def test_sample_sharded_two_ranks_with_context():
     want = torch.cat(want).numpy()
     for r in range(2):
         assert np.array_equal(res[r][1], want) and res[r][2].tolist() == nn_all.tolist()
+
+
+def test_bench_plain_command_launches_its_own_ranks():
+    """`python bench.py --gpus 2` without WORLD_SIZE (the driver's 1-GPU command shape with N > 1) re-executes itself through torch.distributed.run on
+    127.0.0.1 and prints ONE line from rank 0 (GCDM_BENCH_LAUNCH_ONLY: the ranks stop before they touch a GPU -- the rest of the multi-rank branch is
+    covered on the GPU box by tests/test_bench_gpu.py)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    env["GCDM_BENCH_LAUNCH_ONLY"] = "1"
+    p = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--steps", "3"], cwd=root, env=env, capture_output=True, text=True, timeout=280)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout
+    assert json.loads(lines[0]) == {"launched_world": 2, "gpus": 2, "master_addr": "127.0.0.1"}

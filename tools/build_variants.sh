@@ -9,7 +9,8 @@ cd "$(dirname "$0")/.."
 mkdir -p build/ab
 for spec in "$@"; do
     name="${spec%%:*}"; flags="${spec#*:}"
-    /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC -Xclang -target-feature -Xclang -packed-fp32-ops $flags \
+    # (GCDM_BUILD_BASE=-fno-slp-vectorize replaces the packed-fp32 switch for the -DGCDM_X3_PK=1 variants: the assembler needs the feature for v_pk_*_f32)
+    /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC ${GCDM_BUILD_BASE:--Xclang -target-feature -Xclang -packed-fp32-ops} $flags \
         -o "build/ab/libgcdm_${name}.so" bio-diffusion_amd/csrc/gcdm_api.hip 2>&1 | grep -v "packed-fp32-ops" || true
     echo "built build/ab/libgcdm_${name}.so  [$flags]"
 done
