@@ -114,6 +114,7 @@ struct gcdm_handle {
         uint64_t seed = 0; int num_steps = 0;
     } sg;
     hipStream_t cap_stream = nullptr;  // capture happens here (the caller's stream may be the null stream, which cannot capture)
+    hipEvent_t sg_done = nullptr; bool sg_inflight = false;   // recorded behind every graph launch: an exec (and the row table it reads) is retired only after it
     StepRow* d_rows = nullptr; int rows_steps = 0;
     int* d_cursor = nullptr; int cursor_expected = -1;
     int64_t graph_launches = 0;        // option "graph_launches" (read-only): steps served by the graph since the handle was created
@@ -127,8 +128,15 @@ int fail(gcdm_handle* h, const std::string& msg) {
 }
 
 // Anything a captured step has baked in changed (plan, weights, gamma table, an option): drop the instantiated graph
+// (the last launch of the exec may still be in flight -- the sampler changes options right behind its last step, a restart switches the matrix mode
+//  with ~25 launches queued: HIP does not promise to defer the destruction of an exec that is executing, so wait for the event recorded behind it)
+void wait_step_graph_idle(gcdm_handle* h) {
+    if (h->sg_inflight && h->sg_done) (void)hipEventSynchronize(h->sg_done);
+    h->sg_inflight = false;
+}
 void drop_step_graph(gcdm_handle* h) {
     if (!h) return;
+    if (h->sg.exec || h->sg.graph) wait_step_graph_idle(h);
     if (h->sg.exec) (void)hipGraphExecDestroy(h->sg.exec);
     if (h->sg.graph) (void)hipGraphDestroy(h->sg.graph);
     h->sg = gcdm_handle::StepGraph{};
@@ -543,6 +551,7 @@ int gcdm_destroy(gcdm_handle* h) {
     if (h->d_rows) (void)hipFree(h->d_rows);
     if (h->d_cursor) (void)hipFree(h->d_cursor);
     if (h->cap_stream) (void)hipStreamDestroy(h->cap_stream);
+    if (h->sg_done) (void)hipEventDestroy(h->sg_done);
     delete h;
     return 0;
 }
@@ -697,14 +706,13 @@ static int finalize_pass(gcdm_handle* h, int k_shift) {
             o.wg0 = pool.add(pack_mfma(Wg));
             o.bg0 = pool.add(padded(bg, 32));
             o.wup0 = pool.add(*wu.v);
-            // split-precision images: K' = [e'(Se) | n (H0 -> 8-groups) | q (9 -> 16)] padded to a multiple of 16
-            const int N8 = Se / 8, H0G8 = (H0 + 7) / 8, Q8 = N8 + H0G8;
-            const int Kx = round_up(8 * (Q8 + 2), 16);
+            // split-precision images: K' = [e'(Se) | n (H0) | q (9)] compact (round 5), padded to a multiple of 16 (x3_msg0_kb / x3_msg0_qpos)
+            const int Kx = 16 * x3_msg0_kb(Se, H0), qpos = x3_msg0_qpos(Se, H0);      // (gcdm_edge_x3.hip.h: the kernel's own layout functions)
             Dense W0x(S, Kx);
             for (int m = 0; m < S; ++m) {
                 for (int k = 0; k < Se; ++k) W0x.at(m, k) = ws.at(m, S + k);
-                for (int k = 0; k < H0; ++k) W0x.at(m, 8 * N8 + k) = ws.at(m, 2 * S + Se + k);
-                for (int k = 0; k < 9; ++k) W0x.at(m, 8 * Q8 + k) = ws.at(m, 2 * S + Se + H0 + k);
+                for (int k = 0; k < H0; ++k) W0x.at(m, Se + k) = ws.at(m, 2 * S + Se + k);
+                for (int k = 0; k < 9; ++k) W0x.at(m, qpos + k) = ws.at(m, 2 * S + Se + H0 + k);
             }
             for (auto& v : W0x.a) v *= X3_C;                    // true-unit inputs -> scaled pre-activation
             std::vector<float> xh, xl;
@@ -1085,7 +1093,7 @@ int gcdm_forward_sc(gcdm_handle* h, const float* xh, const float* xh_sc, const f
             xa.wpool = h->wpool; xa.wpool_bytes = (uint32_t)h->wpool_bytes;
             xa.wspool = h->ws; xa.wspool_bytes = (uint32_t)(h->ws_floats * sizeof(float));
             xa.flags_dev = h->d_flags;
-            if (d.KB != 18 || d.KB0 != (h->Se == 64 ? 7 : 4)) return fail(h, "internal: k-block counts differ from the kernel's compile-time constants");
+            if (d.KB != 18 || d.KB0 != x3_msg0_kb(h->Se, h->H0)) return fail(h, "internal: k-block counts differ from the kernel's compile-time constants");
             // persistent workgroups: as many as fit the chip at once (one per CU with 64-edge tiles, two with 32), a multiple of 8 so that every
             // XCD gets the same number; fewer tiles than that -> one tile per workgroup, as before
             int wgs = h->cus * (ET == 64 ? 1 : 2) / 8 * 8;
@@ -1243,14 +1251,14 @@ static int step_via_graph(gcdm_handle* h, float* z, const float* context, int32_
     if (h->rows_steps != num_steps) {              // the table of this step count (s = i / num_steps, t = (i + 1) / num_steps, as gcdm_sample_step_to)
         std::vector<StepRow> rows((size_t)num_steps);
         for (int i = 0; i < num_steps; ++i) rows[i] = step_row(h, (float)i / (float)num_steps, (float)(i + 1) / (float)num_steps, (uint32_t)i);
-        if (h->d_rows) { (void)hipStreamSynchronize(st); (void)hipFree(h->d_rows); h->d_rows = nullptr; }     // (a graph still reading the old table is behind st)
+        if (h->d_rows) { wait_step_graph_idle(h); (void)hipFree(h->d_rows); h->d_rows = nullptr; }     // (a graph still reading the old table: whatever stream it was launched on)
         if ((e = hipMalloc(&h->d_rows, rows.size() * sizeof(StepRow))) != hipSuccess) return give_up("hipMalloc", e);
         if ((e = hipMemcpy(h->d_rows, rows.data(), rows.size() * sizeof(StepRow), hipMemcpyHostToDevice)) != hipSuccess) return give_up("hipMemcpy", e);
-        if (h->sg.exec) { (void)hipGraphExecDestroy(h->sg.exec); (void)hipGraphDestroy(h->sg.graph); h->sg = gcdm_handle::StepGraph{}; }
+        if (h->sg.exec) { wait_step_graph_idle(h); (void)hipGraphExecDestroy(h->sg.exec); (void)hipGraphDestroy(h->sg.graph); h->sg = gcdm_handle::StepGraph{}; }
         h->rows_steps = num_steps;
     }
     if (!h->sg.exec || h->sg.z != z || h->sg.ctx != context || h->sg.flags != flags || h->sg.seed != seed || h->sg.num_steps != num_steps) {
-        if (h->sg.exec) { (void)hipGraphExecDestroy(h->sg.exec); (void)hipGraphDestroy(h->sg.graph); h->sg = gcdm_handle::StepGraph{}; }
+        if (h->sg.exec) { wait_step_graph_idle(h); (void)hipGraphExecDestroy(h->sg.exec); (void)hipGraphDestroy(h->sg.graph); h->sg = gcdm_handle::StepGraph{}; }
         if ((e = hipStreamBeginCapture(h->cap_stream, hipStreamCaptureModeThreadLocal)) != hipSuccess) return give_up("hipStreamBeginCapture", e);
         h->capturing = true;
         const int rc = transition(h, z, z, nullptr, context, 0.f, 1.f / (float)num_steps, nullptr, seed, 0u, flags, (void*)h->cap_stream);
@@ -1260,6 +1268,13 @@ static int step_via_graph(gcdm_handle* h, float* z, const float* context, int32_
         e = hipStreamEndCapture(h->cap_stream, &g);
         if (rc != 0 || e != hipSuccess || !g) {
             if (g) (void)hipGraphDestroy(g);
+            if (rc != 0 && e == hipSuccess) {
+                // the step itself was refused (an argument / state check of transition(): e.g. a conditional model called without a context) while the
+                // capture as such went through: that is the CALLER's error -- report transition()'s own diagnostic (h->err), exactly what the direct path
+                // returns for the same call, and leave the graph enabled for the next valid call
+                (void)hipGetLastError();
+                return -1;
+            }
             return give_up("capture of one step", e);
         }
         hipGraphExec_t ex = nullptr;
@@ -1269,6 +1284,9 @@ static int step_via_graph(gcdm_handle* h, float* z, const float* context, int32_
     }
     if (h->cursor_expected != s_index) hipLaunchKernelGGL(k_cursor_set, dim3(1), dim3(1), 0, st, h->d_cursor, (int)s_index);
     if ((e = hipGraphLaunch(h->sg.exec, st)) != hipSuccess) return give_up("hipGraphLaunch", e);
+    if (!h->sg_done && hipEventCreateWithFlags(&h->sg_done, hipEventDisableTiming) != hipSuccess) h->sg_done = nullptr;
+    if (h->sg_done) h->sg_inflight = hipEventRecord(h->sg_done, st) == hipSuccess;
+    if (!h->sg_inflight) (void)hipStreamSynchronize(st);          // (no event: the conservative form)
     h->cursor_expected = s_index - 1;
     h->graph_launches += 1;
     return 1;
@@ -1389,15 +1407,17 @@ int gcdm_unnormalize_z(gcdm_handle* h, const float* z, float* out, void* stream_
 int gcdm_set_option(gcdm_handle* h, const char* name, int32_t value) {
     if (!h || !name) return fail(h, "gcdm_set_option: bad argument");
     const std::string k(name);
-    drop_step_graph(h);                     // every option below is baked into a captured step
-    if (k == "step_graph") { h->step_graph = value ? 1 : 0; h->step_graph_failed = false; return 0; }
+    // every option below except these two is baked into a captured step (cog_fix acts in gcdm_sample_final only; the sampler sets it right behind its
+    // last step); an option set to the value it already has changes nothing either
+    if (k == "step_graph") { h->step_graph = value ? 1 : 0; h->step_graph_failed = false; if (!value) drop_step_graph(h); return 0; }
+    if (k == "cog_fix") { h->cog_fix = value ? 1 : 0; return 0; }
+    if (gcdm_get_option(h, name) != value || k == "mfma_mode") drop_step_graph(h);
     if (k == "mfma_mode") {                 // 0: fp32 MFMA, 1: split-precision f16 x3 (fp32-equivalent, 5.3x the matrix rate)
         if (value != 0 && value != 1) return fail(h, "gcdm_set_option(mfma_mode): 0 or 1");
         if (value == 1 && !h->x3_weights_ok) return fail(h, "gcdm_set_option(mfma_mode): a weight of this model is >= 2047 in magnitude (or not finite), outside the split-precision images at every exponent split; only mode 0 (fp32 MFMA) is available");
         h->mfma_x3 = value;
         return 0;
     }
-    if (k == "cog_fix") { h->cog_fix = value ? 1 : 0; return 0; }
     if (k == "fix_noise") { h->fix_noise = value ? 1 : 0; return 0; }
     if (k == "flat_prev") { h->flat_prev = value ? 1 : 0; return 0; }
     if (k == "flat_next") { h->flat_next = value ? 1 : 0; return 0; }
@@ -1441,7 +1461,7 @@ int gcdm_profile_enable(gcdm_handle* h, int32_t enable) {
         h->ev.resize(3 * (size_t)h->L);
         for (auto& e : h->ev) HIP_OK(h, hipEventCreate(&e));
     }
-    if (enable >= 2 && !GCDM_HAVE_STAMPS)
+    if (enable == 3 && !GCDM_HAVE_STAMPS)        // (enable == 2 on a build without the phase stamps: only entry 20, the end-of-tile stamp of the split-precision edge kernel, is written)
         return fail(h, "gcdm_profile_enable: in-kernel phase stamps need a library built with -DGCDM_STAMPS (tools/build_variants.sh stamps:-DGCDM_STAMPS)");
     drop_step_graph(h);
     h->profile = enable != 0;

@@ -290,6 +290,17 @@ __device__ __forceinline__ void x3_prefetch_b(X3Ring<MT, PD>& ring, const WPool&
 // NOTE: the prefetches run PD k-blocks (A) / one k-block (B) past the end of the contraction without clamping: the packed weight
 // arrays carry X3_TAIL_BLOCKS zero blocks of padding behind the last M-tile, and the LDS reads stay inside the XH8|XL8|VV allocation.
 #define X3_TAIL_BLOCKS 4
+// K' of msg0's per-edge part (kernel and host packing, gcdm_api.hip): [e' (Se) | norms of the H0 hidden vectors | 9 frame scalars | 0 ...] in units of
+// 16-deep k-blocks.  Round 5: the three pieces are COMPACT -- 64 + 20 + 9 = 93 slots = 6 k-blocks at QM9, 16 + 18 + 9 = 43 = 3 at GEOM; rounds 1-4 started
+// the norms and the frame scalars on 8-slot groups of their own (7 / 4 k-blocks; -DGCDM_X3_MSG0_PADDED brings that layout back for an A/B).  The contraction
+// order of msg0 changes with the layout: not the same bits as round 4, same error model.
+#ifdef GCDM_X3_MSG0_PADDED
+__host__ __device__ constexpr int x3_msg0_qpos(int Se, int H0) { return 8 * (Se / 8 + (H0 + 7) / 8); }
+__host__ __device__ constexpr int x3_msg0_kb(int Se, int H0) { return (x3_msg0_qpos(Se, H0) + 16 + 15) / 16; }
+#else
+__host__ __device__ constexpr int x3_msg0_qpos(int Se, int H0) { return Se + H0; }
+__host__ __device__ constexpr int x3_msg0_kb(int Se, int H0) { return (Se + H0 + 9 + 15) / 16; }
+#endif
 constexpr int X3_PD = 2;         // k-blocks of weight prefetch distance in the edge kernel (register ring of PD + 1 sets)
 #ifndef GCDM_STAMP_K
 #define GCDM_STAMP_K 0              // which residual GCP2 (0..2) carries the per-phase stamps 10..17 of a -DGCDM_STAMPS build
@@ -1052,9 +1063,8 @@ __global__ __launch_bounds__(ET * 8) __attribute__((amdgpu_waves_per_eu(2, 2))) 
     constexpr int H0 = (2 * GCDM_V + VE) / 4;
     constexpr int SEG = SE / 4;                          // float4 groups of e' in global memory
     constexpr int N8 = SE / 8;                           // first 8-group of the norm rows in msg0
-    constexpr int H0G8 = (H0 + 7) / 8;
-    constexpr int Q8 = N8 + H0G8;
-    constexpr int KB0C = (8 * (Q8 + 2) + 15) / 16;       // k-blocks of the msg0 per-edge part (host: gcdm_api.hip, same formula); msg1..3: 18
+    constexpr int QPOS = x3_msg0_qpos(SE, H0);           // first slot of the 9 frame scalars
+    constexpr int KB0C = x3_msg0_kb(SE, H0);             // k-blocks of the msg0 per-edge part (host: gcdm_api.hip, same functions); msg1..3: 18
     // who am I: recomputed from an opaque copy of the thread index at the top of every tile, so that the compiler does not hoist the dozens of
     // lane-dependent LDS / buffer offsets of the tile body out of the persistent loop and keep them in registers across the GEMM phases
     struct Who {
@@ -1378,18 +1388,15 @@ __global__ __launch_bounds__(ET * 8) __attribute__((amdgpu_waves_per_eu(2, 2))) 
 #pragma unroll
                 for (int r = 0; r < 3; ++r) {
                     const int idx = 3 * k + r;
-                    over |= put16(XH, XL, ETP, Q8 + (idx >> 3), idx & 7, e, in.fr[3 * r] * vx + in.fr[3 * r + 1] * vy + in.fr[3 * r + 2] * vz);
+                    over |= put16(XH, XL, ETP, (QPOS + idx) >> 3, (QPOS + idx) & 7, e, in.fr[3 * r] * vx + in.fr[3 * r + 1] * vy + in.fr[3 * r + 2] * vz);
                 }
             }
         }
         static_for<(NH0 < 3 ? 4 + NH0 : 7), GCH>([&](auto cc) { load_pq_part(cc, a, me, ix, in); });
         if (part == PARTS - 1) {
-            for (int hh = H0; hh < 8 * H0G8; ++hh) put16(XH, XL, ETP, N8 + (hh >> 3), hh & 7, e, 0.f);
-            for (int idx = 9; idx < 16; ++idx) put16(XH, XL, ETP, Q8 + (idx >> 3), idx & 7, e, 0.f);
-            for (int g = Q8 + 2; g < 2 * KB0C; ++g) {
-                *(v4f*)(XH + (g * ETP + e) * 16) = (v4f){0.f, 0.f, 0.f, 0.f};
-                *(v4f*)(XL + (g * ETP + e) * 16) = (v4f){0.f, 0.f, 0.f, 0.f};
-            }
+            // the slots no row is written to: between the norms and the frame scalars (padded layout only), and behind the last frame scalar
+            for (int pos = SE + H0; pos < QPOS; ++pos) put16(XH, XL, ETP, pos >> 3, pos & 7, e, 0.f);
+            for (int pos = QPOS + 9; pos < 16 * KB0C; ++pos) put16(XH, XL, ETP, pos >> 3, pos & 7, e, 0.f);
         }
     }
 #endif
@@ -1665,7 +1672,7 @@ __global__ __launch_bounds__(ET * 8) __attribute__((amdgpu_waves_per_eu(2, 2))) 
         }
     }
 #endif
-    STAMP(20);
+    STAMP_END(20);
     it_ += stride_;
     if (it_ >= cnt_) break;
     // (no barrier here: the one inside the next tile's pre-phase says that every wave is done with this tile's LDS)

@@ -595,6 +595,12 @@ struct EdgeMsgArgs {
 // In-kernel phase time stamps are compiled in only with -DGCDM_STAMPS (tools/build_variants.sh; gcdm_profile_enable(h, 2 | 3) fails
 // without it): even switched off at run time each stamp costs the wave an exec-mask save, a branch and a restore -- 20 of them are
 // ~2 % of the edge kernel's issue slots, and they pin the instruction schedule around them.
+// STAMP_END: the END-OF-TILE stamp alone is part of every build (one uniform branch per tile; the -DGCDM_STAMPS builds pin the instruction schedule at 20 places
+// and differ from the shipped kernel by +-1.5 % tile cycles from build to build, profiles/r05_edge_kernel_cycles.md -- the shipped kernel is measured by this one)
+#define STAMP_END(i)                                                                                    \
+    do {                                                                                                \
+        if (a.prof && lane == 0) a.prof[((size_t)prof_tile * 8 + wave) * 24 + (i)] = (float)(__builtin_amdgcn_s_memtime() - t_start); \
+    } while (0)
 #ifdef GCDM_STAMPS
 #define STAMP(i)                                                                                        \
     do {                                                                                                \
