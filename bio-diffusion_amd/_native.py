@@ -8,7 +8,10 @@ import subprocess
 from typing import Optional
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libgcdm_hip.so")
+# GCDM_HIP_LIB: another build of the same sources (kernel variants for A/B and hazard runs: tools/build_variants.sh, tests/test_hazards_gpu.py); the
+# default is the in-tree library __graft_entry__.build() produces
+DEFAULT_LIB_PATH = os.path.join(_HERE, "libgcdm_hip.so")
+LIB_PATH = os.environ.get("GCDM_HIP_LIB") or DEFAULT_LIB_PATH
 SOURCES = [os.path.join(_HERE, "csrc", "gcdm_api.hip")]
 HEADERS = ([os.path.join(_HERE, "csrc", f) for f in sorted(os.listdir(os.path.join(_HERE, "csrc"))) if f.endswith(".h") and f != "gcdm_ops.hip.h"]
            + [os.path.join(os.path.dirname(_HERE), "include", "gcdm_hip.h")])
@@ -59,10 +62,10 @@ _lib: Optional[C.CDLL] = None
 def build(force: bool = False) -> str:
     """hipcc --offload-arch=gfx950 (cross-compiles without a GPU).  Rebuilds when a source is newer than the .so."""
     deps = SOURCES + HEADERS
-    if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in deps):
-        return LIB_PATH
+    if not force and os.path.exists(DEFAULT_LIB_PATH) and all(os.path.getmtime(DEFAULT_LIB_PATH) >= os.path.getmtime(d) for d in deps):
+        return DEFAULT_LIB_PATH
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    tmp = f"{LIB_PATH}.{os.getpid()}.tmp"          # concurrent builders (one per rank) never see a half-written library
+    tmp = f"{DEFAULT_LIB_PATH}.{os.getpid()}.tmp"          # concurrent builders (one per rank) never see a half-written library
     # packed-fp32 VALU ops (v_pk_fma_f32 & co.) are switched off: with them the 32-edge split-precision kernel is not bit-reproducible
     # from run to run (first wrong values: the pre-phase FMAs the SLP vectoriser had packed, fed by per-lane VMEM loads; DESIGN.md 3.4), and
     # they buy nothing here -- round 5 wrote the packable steps of the VALU phases on float2 by hand (csrc/gcdm_edge_x3.hip.h, "packed fp32"):
@@ -71,11 +74,11 @@ def build(force: bool = False) -> str:
            "-o", tmp] + SOURCES
     try:
         subprocess.run(cmd, check=True)
-        os.replace(tmp, LIB_PATH)
+        os.replace(tmp, DEFAULT_LIB_PATH)
     finally:
         if os.path.exists(tmp):
             os.remove(tmp)
-    return LIB_PATH
+    return DEFAULT_LIB_PATH
 
 
 def build_ops(force: bool = False) -> str:

@@ -190,8 +190,16 @@ __device__ __forceinline__ void split16x2(float x0, float x1, h2& hi, h2& lo) {
 // one k-block with the MFMAs of the previous one; the exact instruction pair was not isolated (tests/gpu_ragged_diag.py: 16 s_nops
 // around the MFMAs without a data dependence do not help, the compiler-generated split and this fence both do).  The fence is a
 // data dependence: every split of an operand is complete, plus two wait states, before the first MFMA that reads it.
+// Round 5: since round 3 the splits above end in v_cvt_pk_f16_f32 -- FULL 32-bit writes -- so the partial-write precondition of the fault is gone from every
+// MFMA operand; the fence stays as belt and braces (same bits, same time), and tests/test_hazards_gpu.py builds the library WITHOUT it
+// (-DGCDM_X3_NO_SETTLE) and runs the configuration that exposed the fault, so that what a new compiler does with the un-fenced code is on record.
+#ifdef GCDM_X3_NO_SETTLE
+__device__ __forceinline__ void x3_settle(h8&, h8&) {}
+__device__ __forceinline__ void x3_settle(h8&) {}
+#else
 __device__ __forceinline__ void x3_settle(h8& a, h8& b) { asm("s_nop 1" : "+v"(a), "+v"(b)); }
 __device__ __forceinline__ void x3_settle(h8& a) { asm("s_nop 1" : "+v"(a)); }
+#endif
 
 // ---- tile GEMM on split operands: am += Whi.Xhi ; al += Whi.Xlo' + Wlo'.Xhi ------------------------------------------------
 // A-operand ring of one GEMM (PD+1 statically indexed register sets of hi / lo' weights).  `x3_prefetch` issues the loads of the

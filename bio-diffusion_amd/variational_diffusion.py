@@ -956,6 +956,26 @@ class EquivariantVariationalDiffusion(nn.Module):
 
     def _inpaint_modules(self, molecule, node_mask_fixed, num_resamplings, jump_length, return_frames, num_timesteps, context, generate_x_only,
                          noise_fn, seed):
+        """_inpaint_modules_once with the range recovery of _mol_gen_sample_modules: an activation beyond the f16 range of the split-precision kernels
+        (F16RangeError of the deferred guard; the handle is then in fp32 MFMA) re-runs the loop from the start on the same noise (the draws are
+        indexed / seeded inside the loop), the handle returns to its default mode, and ``last_flags`` reports FLAG_F16_RANGE."""
+        dyn = self.dynamics_network
+        try:
+            return self._inpaint_modules_once(molecule, node_mask_fixed, num_resamplings, jump_length, return_frames, num_timesteps, context, generate_x_only,
+                                              noise_fn, seed)
+        except F16RangeError:
+            log.warning("An activation left the f16 range of the split-precision kernels; re-running the inpainting loop with fp32 MFMA.")
+            try:
+                out = self._inpaint_modules_once(molecule, node_mask_fixed, num_resamplings, jump_length, return_frames, num_timesteps, context, generate_x_only,
+                                                 noise_fn, seed)
+            finally:
+                if getattr(dyn, "_handle", None) is not None:
+                    dyn.set_mfma_mode(1)
+            self.last_flags |= _native.FLAG_F16_RANGE         # reported: this result was computed with fp32 MFMA
+            return out
+
+    def _inpaint_modules_once(self, molecule, node_mask_fixed, num_resamplings, jump_length, return_frames, num_timesteps, context, generate_x_only,
+                              noise_fn, seed):
         """inpaint (:1582-1789, the two repairs of the fused method's docstring) step by step through the reference-signature methods of this class:
         torch algebra on the device around one network evaluation per step.  Serves ``generate_x_only`` (position-only diffusion: the molecule is
         its positions, z = z_x, [N, 3] out -- the dynamics network must be built without node features, as for mol_gen_sample) and configurations
@@ -1047,7 +1067,9 @@ class EquivariantVariationalDiffusion(nn.Module):
             out[0] = x
         else:
             out[0] = torch.cat([x, h["categorical"].to(x.dtype)] + ([h["integer"].to(x.dtype)] if self.include_charges else []), dim=-1)
-        self.last_flags = 0
+        # the device check word of the network evaluations of this loop (NaN in vel, ...; the range bit was handled by the deferred guard above)
+        rf = getattr(self.dynamics_network, "read_flags", None)
+        self.last_flags = (int(rf()) & ~_native.FLAG_F16_RANGE) if rf is not None and getattr(self.dynamics_network, "_handle", None) is not None else 0
         return out.squeeze(0)
 
     # ---- several independent batches in flight (evaluation driver) -------------------------------------------------------------

@@ -183,9 +183,10 @@ int gcdm_debug_set_layer_limit(gcdm_handle* h, int32_t num_layers_to_run);
  * block on operands split as x = hi + 2^-11 lo' (fp32-equivalent accuracy; raises GCDM_FLAG_F16_RANGE if an
  * activation exceeds the range of its image -- 1.2e8 at the default exponent split -- in which case the caller must re-run with
  * mode 0); 0 (env GCDM_MFMA=f32) uses fp32 MFMA throughout.  gcdm_finalize_weights picks the exponent split per checkpoint: the
- * packed images hold 2^(11-k) W in f16 with the smallest k <= 6 that fits the largest weight (k = 0 while |W| < 21.3; every
- * further doubling of |W| costs one k and halves the activation range: k = 6 admits |W| < 1.36e3, activations < 1.9e6).  Only a
- * model with a larger (|W| >= 2047 at the latest) or non-finite matrix weight runs in mode 0 whatever was requested
+ * packed images hold 2^(11-k) W in f16 with the smallest k <= 6 that fits the largest magnitude that actually goes into an image
+ * (matrices and the constants the host folds into them; no head room: k = 0 while that maximum is < 31.98; every further doubling
+ * costs one k and halves the activation range: k = 6 admits < 2047, activations < 1.9e6).  Only a model with a larger (>= 2047)
+ * or non-finite packed weight runs in mode 0 whatever was requested
  * (gcdm_get_option reports the effective mode) and setting mode 1 on it fails.
  * "edge_tile": edges per workgroup of the edge-message kernels: 64 (one 8-wave workgroup per CU), 32 (two 4-wave workgroups per CU) or
  * 0 = automatic (default; env GCDM_EDGE_TILE): 64 -- with the operand requests of the next k-blocks issued between the MFMAs of the

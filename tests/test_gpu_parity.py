@@ -168,6 +168,10 @@ def test_edge_list_and_geometry_match_reference_golden(golden_dir):
         net.debug_set_layer_limit(-1)
 
 
+# (fixture, matrix mode) -> (atom-type, charge) near-tie differences observed with the kernels of this tree; everything not listed: (0, 0)
+NEAR_TIES = {("long_ragged16_qm9.npz", 0): (0, 1)}
+
+
 @pytest.mark.parametrize("fixture", ["long_full_qm9.npz", "long_ragged16_qm9.npz", "long_geom8.npz", "long_config0_qm9.npz", "long_cond6_qm9.npz"])
 @pytest.mark.parametrize("mode", MODES)
 def test_long_horizon_sampling_matches_reference_golden(mode, fixture, golden_dir):
@@ -214,7 +218,7 @@ def test_long_horizon_sampling_matches_reference_golden(mode, fixture, golden_di
     assert (out[:, :3].double() - f32[:, :3]).abs().max().item() <= bound
     # discrete outputs: equal to the reference's on every atom its own fp32 and fp64 runs decide alike -- except rounding near-ties: the
     # untrained weights drive the charge channel to O(5e3), where the allowed 1e-4 * max|z| deviation of the latent is a fraction of the
-    # rounding unit; such atoms (at most 1 % of the decided ones, charge off by at most 1) are counted, not hidden
+    # rounding unit; such atoms (charge off by at most 1) are counted, not hidden, and their number is pinned (NEAR_TIES)
     nt = _ocfg(case).num_atom_types
     dec_t = f32[:, 3:3 + nt].argmax(1) == f64[:, 3:3 + nt].argmax(1)
     bad_t = int((out[:, 3:3 + nt].argmax(1)[dec_t] != f32[:, 3:3 + nt].argmax(1)[dec_t]).sum())
@@ -224,8 +228,10 @@ def test_long_horizon_sampling_matches_reference_golden(mode, fixture, golden_di
     else:                                              # GEOM: no charge column
         dec_q, dq = torch.zeros(0, dtype=torch.bool), torch.zeros(0, dtype=torch.float64)
     bad_q = int((dq != 0).sum())
-    allowed = 0 if fixture == "long_full_qm9.npz" else max(1, int(0.01 * len(f32)))
-    assert bad_t <= allowed and bad_q <= allowed and (dq.max().item() if len(dq) else 0.0) <= 1.0, (bad_t, bad_q, dq.max().item())
+    # pinned to what the kernels of this tree produce (round 5, GPUTEST log: every fixture 0 / 0 in both modes, except ONE charge near-tie of the ragged
+    # fixture in the fp32-MFMA mode): a regression from 0 to a handful of differing atoms fails here instead of hiding below a 1 % allowance
+    allowed_t, allowed_q = NEAR_TIES.get((fixture, mode), (0, 0))
+    assert bad_t <= allowed_t and bad_q <= allowed_q and (dq.max().item() if len(dq) else 0.0) <= 1.0, (bad_t, bad_q, dq.max().item() if len(dq) else 0.0)
     print(f"long horizon {fixture}: {bad_t} type / {bad_q} charge near-tie differences on {int(dec_t.sum())} / {int(dec_q.sum())} decided atoms")
     print(f"long horizon ({'f16x3' if mode else 'f32'}): worst err / bound over the checkpoints = {worst:.3f}")
 
@@ -1174,6 +1180,40 @@ def test_full_size_properties(case, B, n, mode):
         assert (sub[n:2 * n] - out[b * n:(b + 1) * n]).abs().max().item() <= TOL * scale
         ref = O.dynamics_forward(W, _ocfg(case), xh[lo:hi], t[lo:hi], bi[lo:hi] - (b - 1), None, cs)
         assert (sub - ref).abs().max().item() <= TOL * scale
+
+
+_FULLSIZE_OUT = {}
+
+
+@pytest.mark.parametrize("mode", MODES)
+@pytest.mark.parametrize("case", ["qm9", "qm9cond", "geom"])
+def test_full_size_every_row_matches_reference_golden(case, mode, golden_dir):
+    """BASELINE.json configs[1] / [2] / [3] at FULL size (QM9 1024 x 19, alpha-conditional QM9 1024 x 19, GEOM-Drugs 256 x 44): EVERY row of the forward -- all
+    19 456 / 19 456 / 11 264 nodes, i.e. every tile of every persistent workgroup, every XCD range boundary -- against the REFERENCE's own forward of the same
+    batch (tests/golden/fullsize_<case>.npz: the reference run in fp64 in the build container, make_fullsize_golden.py; weights / inputs are synth seeds 51 / 77, as
+    in test_full_size_properties).  Bar: 1e-4 * max(1, |out|) (north_star); both matrix modes; and the two modes -- two independent kernel families -- against
+    each other on the full batch."""
+    g = np.load(os.path.join(golden_dir, f"fullsize_{case}.npz"))
+    B, n = int(g["B"]), int(g["n"])
+    d = _dims(case)
+    net, W, _ = _net(case, seed=int(g["weight_seed"]), scale=float(g["weight_scale"]), mode=mode)
+    xh, t, bi, nn_, ctx = synth.make_inputs([n] * B, synth.dims_feat(d), seed=int(g["input_seed"]), t_value=float(g["t_value"]), n_ctx=d["n_ctx"])
+    assert abs(float(xh.double().sum().item()) - float(g["xh_checksum"])) <= 1e-6 * max(1.0, abs(float(g["xh_checksum"])))      # the inputs the fixture was made from
+    out = _fwd(net, xh, t, bi, ctx)
+    ref = torch.tensor(g["out64"])
+    assert out.shape == ref.shape == (B * n, 3 + synth.dims_feat(d))
+    bar = TOL * max(1.0, ref.abs().max().item())
+    err = (out - ref).abs()
+    worst_row = int(err.max(dim=1).values.argmax())
+    print(f"full size {case} ({'f16x3' if mode else 'f32'}): max |hip - ref64| over {out.shape[0]} rows = {err.max().item():.3e} (row {worst_row}, molecule {worst_row // n}); "
+          f"reference's own |fp32 - fp64| = {float(g['ref32_vs_ref64_maxabs']):.3e}; bar {bar:.1e}")
+    assert torch.isfinite(out).all() and err.max().item() <= bar
+    # fp32-class, not merely inside the bar: within 20 x the reference's own fp32-vs-fp64 distance on this batch
+    assert err.max().item() <= 20.0 * float(g["ref32_vs_ref64_maxabs"]) + 1e-6
+    _FULLSIZE_OUT[(case, mode)] = out
+    other = _FULLSIZE_OUT.get((case, 1 - mode))
+    if other is not None:
+        assert (out - other).abs().max().item() <= bar
 
 
 @pytest.mark.parametrize("dataset,B,n", [("qm9", 1024, 19), ("geom", 256, 44)])

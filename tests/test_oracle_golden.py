@@ -184,7 +184,7 @@ def test_mol_gen_optimize_small(golden_dir):
     assert fr.shape == ref.shape == (5, int(g["num_nodes"].sum()), 8)
     assert (fr - ref).abs().max().item() <= 1e-4 * max(1.0, ref.abs().max().item())
     assert torch.equal(fr[0, :, 3:], ref[0, :, 3:])                                 # one-hot of the decode
-    assert (ref[0] - g["a_out"]).abs().max().item() > 1e-6 or True                   # (frame 0 skips the CoG re-projection of the frame-less run)
+    # (frame 0 of a chain is the decoded sample WITHOUT the CoG re-projection the frame-less run a_out gets, reference :1389: the two may differ)
 
 
 def test_repaint_schedule_matches_reference(golden_dir):

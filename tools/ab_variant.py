@@ -73,4 +73,16 @@ if os.environ.get("GCDM_AB_STAMPS", "1") != "0" and lib.gcdm_profile_enable(h, 2
     ph = dyn.debug_read("phase").view(-1, 8, 24)[:, :nw].mean(dim=(0, 1))
     lib.gcdm_profile_enable(h, 0)
     cyc = " tile_cycles=%d phases=[%s]" % (ph[20], " ".join("%d:%d" % (i, ph[i]) for i in (1, 2, 4, 6, 7, 8, 9, 12, 14, 15, 16, 17, 18, 19, 20)))
-print(f"AB {tag} {case} edge_tile={lib.gcdm_get_option(h, b'edge_tile')} fwd={h_fwd} z3={h_z} ms_per_step={ev[0].elapsed_time(ev[1]) / K:.4f} flags={int(flags.item())}{rel}{cyc}")
+# launch durations of the two kernel families (HIP events recorded by the library on the launch stream; clock dependent: compare alternating runs on one box)
+kms = ""
+if lib.gcdm_profile_enable(h, 1) == 0:
+    te = tn = 0.0
+    ne = 0
+    for i in range(5):
+        lib.gcdm_sample_step(h, zp, None, 940 - i, 1000, None, sd, fp, st)
+        ms_, nl_ = C.c_double(), C.c_int32()
+        lib.gcdm_profile_edge_kernel_ms(h, C.byref(ms_), C.byref(nl_)); te += ms_.value; ne += nl_.value
+        lib.gcdm_profile_node_kernel_ms(h, C.byref(ms_), C.byref(nl_)); tn += ms_.value
+    lib.gcdm_profile_enable(h, 0)
+    kms = f" edge_ms={te / max(ne, 1):.4f} node_ms={tn / max(ne, 1):.4f}"
+print(f"AB {tag} {case} edge_tile={lib.gcdm_get_option(h, b'edge_tile')} fwd={h_fwd} z3={h_z} ms_per_step={ev[0].elapsed_time(ev[1]) / K:.4f} flags={int(flags.item())}{rel}{kms}{cyc}")
