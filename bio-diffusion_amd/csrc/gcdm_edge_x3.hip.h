@@ -30,6 +30,8 @@
 #undef GCDM_ABL_NOB
 #undef GCDM_ABL_MFMA1
 #undef GCDM_ABL_NOGATHER
+#undef GCDM_ABL_NOCONST
+#undef GCDM_ABL_FINW
 #undef GCDM_ABL_NOP1
 #undef GCDM_ABL_NOBETA
 #undef GCDM_ABL_NOP1W
@@ -707,7 +709,9 @@ struct VecStage {
     float ev[6];
     h4 sh0, sl0, sh1, sl1;
     float amax = 0.f;
+    bool preloaded = false;          // w1 / w2 were requested by the caller (finish_only of the last GCP2: ahead of the next tile's HBM prefetches)
 
+    __device__ __forceinline__ void load_fin() { w1[0] = fA[lane]; w1[1] = fA[64 + lane]; w2[0] = fB[lane]; w2[1] = fB[64 + lane]; }
     __device__ __forceinline__ v4f gate_sum(int m) const {
         v4f g = *(const v4f*)(bg + 16 * m + 4 * vq);
 #pragma unroll
@@ -858,7 +862,7 @@ struct VecStage {
     __device__ __forceinline__ void run() {
         if constexpr (FIRST) {        // vector_up of msg0 (hidden vectors: fp32 rows VH[h*3 + x][e] written by P1) ...
             if constexpr (I == 0) {
-                w1[0] = fA[lane]; w1[1] = fA[64 + lane]; w2[0] = fB[lane]; w2[1] = fB[64 + lane];
+                if (!preloaded) load_fin();
                 g0 = gate_sum(0);
             } else if constexpr (I == 1) {
                 g0 = sig4(g0);
@@ -873,7 +877,7 @@ struct VecStage {
             else pre_stage<I, 6>();   // ... then vector_down of the first residual GCP2
         } else if constexpr (PIPE) {
             if constexpr (I == 0) {
-                w1[0] = fA[lane]; w1[1] = fA[64 + lane]; w2[0] = fB[lane]; w2[1] = fB[64 + lane];
+                if (!preloaded) load_fin();
                 g0 = gate_sum(0);
             } else if constexpr (I == 1) {
                 g0 = sig4(g0);
@@ -891,7 +895,7 @@ struct VecStage {
             else pre_stage<I, 6>();              // (stages 10 .. 14: norms, extended-K group, hidden-vector images: as before)
         } else {
             if constexpr (I == 0) {
-                w1[0] = fA[lane]; w1[1] = fA[64 + lane]; w2[0] = fB[lane]; w2[1] = fB[64 + lane];
+                if (!preloaded) load_fin();
                 g0 = gate_sum(0);
             } else if constexpr (I == 1) {
                 g0 = sig4(g0);
@@ -1086,11 +1090,13 @@ __global__ __launch_bounds__(ET * 8) __attribute__((amdgpu_waves_per_eu(2, 2))) 
         w.e = (ET == 64) ? w.lane : (tid_ & (ET - 1));
         w.part = (ET == 64) ? w.wave : (tid_ / ET);
         w.mt0 = (8 / (ET / 8)) * w.wave;
-        // the frame rows of an edge are needed by the thread that stages them in LDS (the last part) and by the threads whose rows of the pre-phase are
-        // the three frame vectors (H0 <= part + PARTS i < H0 + 3): 4 of the 8 threads per edge; the others skip the nine loads
+        // Round 5: the frame rows and the unit vector of an edge are loaded ONCE per workgroup, by the thread that stages them in LDS (the last part); the
+        // threads whose rows of the pre-phase are the three frame vectors, and every thread's u, read them back from LDS behind the pre-phase barrier.
+        // Rounds 1-4 had 4 of the 8 waves load the same nine frame rows and all 8 the same three u rows: 60 wave-level loads per tile instead of 12, each
+        // one or two cache-line misses to HBM (non-temporal stream) in flight together with the tile's other 32 -- and with the weight stream of the
+        // GEMM phases queued behind them: removing EITHER the FR or the AL loads alone returned 1.3-1.7 k of the tile's 61.2 k cycles, removing all
+        // constants no more than that (profiles/r05_ab_log.txt, runs 11-13): the cost was the number of misses in flight, not the bytes.
         w.need_fr = w.part == PARTS - 1;
-#pragma unroll
-        for (int i = 0; i < (H0 + 3 + PARTS - 1) / PARTS; ++i) w.need_fr |= (w.part + PARTS * i >= H0) && (w.part + PARTS * i < H0 + 3);
         return w;
     };
     const Who w0 = who_am_i(threadIdx.x);
@@ -1147,35 +1153,60 @@ __global__ __launch_bounds__(ET * 8) __attribute__((amdgpu_waves_per_eu(2, 2))) 
     };
     auto load_const = [&](auto pc, const EdgeMsgArgs& a, const Who& w, int tile, TileIn& in) {       // independent of the edge list; three bursts (P = 0, 1, 2; P < 0: all)
         constexpr int P = decltype(pc)::value;
+#ifdef GCDM_ABL_NOCONST      // (timing ablation, round 5: the tile WITHOUT [some of] its 368 B per edge of streamed constants -- the ceiling of what recomputing them per layer could return)
+        // GCDM_ABL_NOCONST = bit mask of the streams replaced by constants: 1 FR, 2 EP4, 4 AL (alpha), 8 U
+        constexpr int ABL = GCDM_ABL_NOCONST;
+#else
+        constexpr int ABL = 0;
+#endif
+        if constexpr ((ABL & 1) != 0 && (P < 0 || P == 0)) { for (int r = 0; r < 9; ++r) in.fr[r] = 0.01f * (r + 1); }
+        if constexpr ((ABL & 2) != 0 && (P < 0 || P == 1)) { for (int i = 0; i < EPN1; ++i) in.epv[i] = (v4f){0.1f, -0.2f, 0.3f, 0.05f}; }
+        if constexpr ((ABL & 4) != 0 && (P < 0 || P == 1)) { for (int j = 0; j < 8; ++j) in.av[j] = 0.02f * j; }
+        if constexpr ((ABL & 4) != 0 && (P < 0 || P == 2)) { for (int c = 0; c < (BETA_MFMA ? 1 : VE); ++c) in.al[c] = 0.03f; }
+        if constexpr ((ABL & 8) != 0 && (P < 0 || P == 2)) { in.u0 = 0.6f; in.u1 = 0.0f; in.u2 = 0.8f; }
         const int e0 = tile * ET, eid = min(e0 + w.e, E - 1);
         const uint32_t ve4 = (uint32_t)eid * 4u, ve16 = (uint32_t)eid * 16u;
-        if constexpr (P < 0 || P == 0) {
+#ifndef GCDM_X3_AL_AUX
+#define GCDM_X3_AL_AUX SAUX
+#endif
+#ifndef GCDM_X3_AV_BURST
+#define GCDM_X3_AV_BURST 1
+#endif
+        if constexpr ((ABL & 4) == 0 && (P < 0 || P == GCDM_X3_AV_BURST) && BETA_MFMA && GCDM_X3_AV_BURST == 0) {
+            if (w.wave >= ET / 8 - ET / 32) {
+                const uint32_t eg4 = (uint32_t)min(e0 + 32 * (w.wave - (ET / 8 - ET / 32)) + (w.lane & 31), E - 1) * 4u + (uint32_t)(8 * (w.lane >> 5)) * rowE, o = ws.off(a.AL);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) in.av[j] = ws.template ld1s<GCDM_X3_AL_AUX>(eg4, o + (uint32_t)j * rowE);
+            }
+        }
+        if constexpr ((ABL & 1) == 0 && (P < 0 || P == 0)) {
             const uint32_t o = ws.off(a.FR);
 #pragma unroll
             for (int r = 0; r < 9; ++r) in.fr[r] = w.need_fr ? ws.template ld1s<SAUX>(ve4, o + r * rowE) : 0.f;
         }
-        if constexpr (P < 0 || P == 1) {
+        if constexpr ((ABL & 2) == 0 && (P < 0 || P == 1)) {
             const uint32_t o = ws.off(a.EP4);
 #pragma unroll
             for (int i = 0; i < EPN1; ++i)
                 in.epv[i] = ws.template ld4s<SAUX>(ve16 + (uint32_t)min(w.part + PARTS * i, SE / 4 - 1) * (rowE * 4u), o);          // the group index depends on the lane's part
         }
-        if constexpr ((P < 0 || P == 2) && !BETA_MFMA) {
+        if constexpr ((ABL & 4) == 0 && (P < 0 || P == 2) && !BETA_MFMA) {
             const uint32_t o = ws.off(a.AL);
 #pragma unroll
             for (int c = 0; c < VE; ++c) in.al[c] = ws.template ld1s<SAUX>(ve4, o + c * rowE);
         }
-        if constexpr ((P < 0 || P == 1) && BETA_MFMA) {
+        if constexpr ((ABL & 4) == 0 && (P < 0 || P == 1) && BETA_MFMA && GCDM_X3_AV_BURST != 0) {
             if (w.wave >= ET / 8 - ET / 32) {         // the LAST waves contract beta: they are the first to leave the previous tile's segment sums
                 // (the half of K this lane holds rides in the per-lane offset: a lane-dependent scalar offset would cost a waterfall loop per load)
                 const uint32_t eg4 = (uint32_t)min(e0 + 32 * (w.wave - (ET / 8 - ET / 32)) + (w.lane & 31), E - 1) * 4u + (uint32_t)(8 * (w.lane >> 5)) * rowE, o = ws.off(a.AL);
 #pragma unroll
-                for (int j = 0; j < 8; ++j) in.av[j] = ws.template ld1s<SAUX>(eg4, o + (uint32_t)j * rowE);
+                for (int j = 0; j < 8; ++j) in.av[j] = ws.template ld1s<GCDM_X3_AL_AUX>(eg4, o + (uint32_t)j * rowE);
             }
         }
-        if constexpr (P < 0 || P == 2) {
+        if constexpr ((ABL & 8) == 0 && (P < 0 || P == 2)) {
             const uint32_t oU = ws.off(a.U);
-            in.u0 = ws.template ld1s<SAUX>(ve4, oU); in.u1 = ws.template ld1s<SAUX>(ve4, oU + rowE); in.u2 = ws.template ld1s<SAUX>(ve4, oU + 2 * rowE);
+            if (w.need_fr) { in.u0 = ws.template ld1s<SAUX>(ve4, oU); in.u1 = ws.template ld1s<SAUX>(ve4, oU + rowE); in.u2 = ws.template ld1s<SAUX>(ve4, oU + 2 * rowE); }
+            else { in.u0 = 0.f; in.u1 = 0.f; in.u2 = 0.f; }
         }
     };
     // node rows (need the index words), in GCH chunks: the 16 PQ4 rows (16 B per lane each: 16 clk of the L1 path per wave instruction) and the
@@ -1240,7 +1271,7 @@ __global__ __launch_bounds__(ET * 8) __attribute__((amdgpu_waves_per_eu(2, 2))) 
     [[maybe_unused]] const uint64_t t_start = a.prof ? __builtin_amdgcn_s_memtime() : 0;
     bool over = false;
     x3_prefetch_b<MT, PD>(ring, wp, o0H, o0L, KB0C);   // flies during P1
-    const float u0 = in.u0, u1 = in.u1, u2 = in.u2;
+    float* US = (float*)(smem + Geo::OFF_US);            // [3][ETP]: the edges' unit vectors (staged by the last part, read by everyone behind the barrier)
 
     // ---- P1: msg0 pre-phase ---------------------------------------------------------------------------------------------
 #ifndef GCDM_ABL_NOP1
@@ -1287,6 +1318,7 @@ __global__ __launch_bounds__(ET * 8) __attribute__((amdgpu_waves_per_eu(2, 2))) 
         if (part == PARTS - 1) {
 #pragma unroll
             for (int r = 0; r < 9; ++r) FR[r * ETP + e] = in.fr[r];
+            US[e] = in.u0; US[ETP + e] = in.u1; US[2 * ETP + e] = in.u2;
         }
         load_pq_part(std::integral_constant<int, 1>{}, a, me, ix, in);
         load_pq_part(std::integral_constant<int, 2>{}, a, me, ix, in);
@@ -1341,9 +1373,12 @@ __global__ __launch_bounds__(ET * 8) __attribute__((amdgpu_waves_per_eu(2, 2))) 
             if (a.BL) beta2[i] = BETA2[e * 33 + hh];
         }
         }
+        const float u0 = US[e], u1 = US[ETP + e], u2 = US[2 * ETP + e];
         if (wave == 0) {
             const bool own = lane < ET;
-            const int prev = __shfl_up(ni, 1);
+            // (ds_bpermute on the tile's own lane index: __shfl_up computes the lane id with v_mbcnt, which the compiler hoists out of the persistent loop and --
+            //  at 256 VGPRs -- SPILLS; each scratch reload is then the youngest load in flight and waits for every prefetched row of the next tile, round 5)
+            const int prev = __builtin_amdgcn_ds_bpermute(((lane + 63) & 63) << 2, ni);      // lane 0's value is not used (e == 0)
             const bool start = own && (e < nvalid) && (e == 0 || prev != ni);
             const unsigned long long mask = __ballot(start);
             const int sid = __popcll(mask & ((2ull << lane) - 1ull)) - 1;
@@ -1396,7 +1431,8 @@ __global__ __launch_bounds__(ET * 8) __attribute__((amdgpu_waves_per_eu(2, 2))) 
 #pragma unroll
                 for (int r = 0; r < 3; ++r) {
                     const int idx = 3 * k + r;
-                    over |= put16(XH, XL, ETP, (QPOS + idx) >> 3, (QPOS + idx) & 7, e, in.fr[3 * r] * vx + in.fr[3 * r + 1] * vy + in.fr[3 * r + 2] * vz);
+                    const float f0 = FR[(3 * r) * ETP + e], f1 = FR[(3 * r + 1) * ETP + e], f2 = FR[(3 * r + 2) * ETP + e];
+                    over |= put16(XH, XL, ETP, (QPOS + idx) >> 3, (QPOS + idx) & 7, e, f0 * vx + f1 * vy + f2 * vz);
                 }
             }
         }
@@ -1532,6 +1568,15 @@ __global__ __launch_bounds__(ET * 8) __attribute__((amdgpu_waves_per_eu(2, 2))) 
         // the next tile (clamped to the workgroup's last one: no branch): its index words and per-edge constants are requested behind the last
         // gate contraction (its operands are dead) and arrive under the fold of the gate partials and the state image; the gathers that need the index words are dealt out
         // over the attention phase (load_gather_part) and arrive under the aggregation
+        // the vector_up operands of the last GCP2's vector part (finish_only below) are requested ahead of the next tile's index words and constants: loads
+        // return in order, so behind those HBM streams they would wait for them (-DGCDM_X3_FIN_LATE: requested at the point of use, rounds 1-4)
+        [[maybe_unused]] h8 fin_w1[2], fin_w2[2];
+#ifndef GCDM_X3_FIN_LATE
+        if (k == 2 && vhalf == 1) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) { fin_w1[j] = wp.ld(wp.off(ax.vf1[2] + 64 * j)); fin_w2[j] = wp.ld(wp.off(ax.vf2[2] + 64 * j)); }
+        }
+#endif
         if (k == 2) {
             const int nxt = start_ + min(it_ + stride_, cnt_ - 1);
             ix = load_idx(a, me, nxt);
@@ -1592,7 +1637,7 @@ __global__ __launch_bounds__(ET * 8) __attribute__((amdgpu_waves_per_eu(2, 2))) 
             }
 #pragma unroll
             for (int n = 0; n < NT; ++n) {
-                pd[n] += __shfl_xor(pd[n], 32);
+                pd[n] += __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute((lane ^ 32) << 2, __builtin_bit_cast(int, pd[n])));
                 if (half == 0) ATT_P[(32 * n + l31) * NW + wave] = pd[n];
             }
             __syncthreads();
@@ -1601,6 +1646,13 @@ __global__ __launch_bounds__(ET * 8) __attribute__((amdgpu_waves_per_eu(2, 2))) 
                 vs.PG = PG; vs.bg = a.mk[2].bg; vs.FR = FR; vs.VH = VH; vs.VHB = VHB; vs.VV4 = VV4; vs.XH = XH; vs.XL = XL;
                 vs.fA = ax.vf1[2]; vs.fB = ax.vf2[2]; vs.pH = nullptr; vs.pL = nullptr;
                 vs.ve = ve; vs.vq = vq; vs.lane = lane;
+#ifndef GCDM_X3_FIN_LATE
+                vs.w1[0] = fin_w1[0]; vs.w1[1] = fin_w1[1]; vs.w2[0] = fin_w2[0]; vs.w2[1] = fin_w2[1]; vs.preloaded = true;
+#endif
+#ifdef GCDM_ABL_FINW        // (timing ablation, round 5: the last vector part WITHOUT its four operand loads, which are issued behind the next tile's HBM prefetches and return in order)
+                { const h8 c_ = {(_Float16)0.01f, (_Float16)0.02f, (_Float16)0.03f, (_Float16)0.01f, (_Float16)0.02f, (_Float16)0.03f, (_Float16)0.01f, (_Float16)0.02f};
+                  vs.w1[0] = c_; vs.w1[1] = c_; vs.w2[0] = c_; vs.w2[1] = c_; vs.preloaded = true; }
+#endif
                 vs.finish_only();
             }
             float att[NT];

@@ -629,7 +629,9 @@ struct EdgeGeo {
     static constexpr int OFF_VHB = (OFF_META + (T + T + (T + 2) + T + 4) * 4 + 15) & ~15;   // split-precision kernel: hidden-vector images [3][3][T] x 16 B
     static constexpr int LDS_BYTES = OFF_VHB + 3 * 3 * T * 16;
     static constexpr int OFF_WAX = LDS_BYTES;                      // split-precision kernel (persistent): attention weights, staged once per workgroup
-    static constexpr int LDS_BYTES_X3 = OFF_WAX + GCDM_S * 4;
+    static constexpr int OFF_US = OFF_WAX + GCDM_S * 4;            // split-precision kernel: unit vectors u of the tile's edges [3][TP], staged by one wave (round 5)
+    static constexpr int LDS_BYTES_X3 = OFF_US + 3 * TP * 4;
+    static_assert(T != 64 || LDS_BYTES_X3 <= 160 * 1024, "64-edge tile: one workgroup per CU, 160 KB of LDS");
 };
 
 template <int SE, int VE, int ET>
