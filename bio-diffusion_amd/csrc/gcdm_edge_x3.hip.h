@@ -315,8 +315,14 @@ constexpr int X3_PD = 2;         // k-blocks of weight prefetch distance in the 
 #ifndef GCDM_STAMP_K
 #define GCDM_STAMP_K 0              // which residual GCP2 (0..2) carries the per-phase stamps 10..17 of a -DGCDM_STAMPS build
 #endif
-constexpr int X3_TAIL_PER_MFMA = 14;  // tail skew: instructions of N-tile 0's SiLU issued behind each of N-tile 1's last MFMAs (8: +0.3 %)
-constexpr int X3_VEC_PER_MFMA = 6;   // instructions of a vector stage issued behind each MFMA of the hosting k-block (0 / 3 / 4 / 10: +-0.3 %)
+#ifndef GCDM_X3_TAIL_PER_MFMA
+#define GCDM_X3_TAIL_PER_MFMA 8      // round 5, shipped-style builds (end-of-tile stamp): 4 / 6 / 8 / 10 / 12 / 14 / 20 -> 59 360 / 59 550 / 59 460 / 59 470 / 59 670 / 59 820 / 59 530 cycles (QM9), same order at GEOM
+#endif
+#ifndef GCDM_X3_VEC_PER_MFMA
+#define GCDM_X3_VEC_PER_MFMA 6
+#endif
+constexpr int X3_TAIL_PER_MFMA = GCDM_X3_TAIL_PER_MFMA;  // tail skew: instructions of N-tile 0's SiLU issued behind each of N-tile 1's last MFMAs
+constexpr int X3_VEC_PER_MFMA = GCDM_X3_VEC_PER_MFMA;   // instructions of a vector stage issued behind each MFMA of the hosting k-block (0 / 3 / 4 / 10: +-0.3 %)
 
 template <int MT, int PD>
 __device__ __forceinline__ void x3_prefetch(X3Ring<MT, PD>& ring, const h8* __restrict__ wH, const h8* __restrict__ wL, int KB, int lane) {
@@ -1118,7 +1124,11 @@ __global__ __launch_bounds__(ET * 8) __attribute__((amdgpu_waves_per_eu(2, 2))) 
     // edge (node) index, array base and row stride are scalars -- no 64-bit VALU address arithmetic per load
     const BufView ws = make_view(ax0.wspool, ax0.wspool_bytes);
     const BufView wv = make_view(ax0.wpool, ax0.wpool_bytes);
+#ifdef GCDM_X3_SAUX
+    constexpr int SAUX = GCDM_X3_SAUX;
+#else
     constexpr int SAUX = SE == 64 ? 2 : 0;               // cache policy of the streamed per-edge constants (BufView::ld1s)
+#endif
     constexpr int EPN = (SE / 4) / PARTS;                // e' float4 groups per thread (QM9 2, GEOM: parts 0..3 one each)
     constexpr int EPN1 = EPN > 0 ? EPN : 1;
     const uint32_t rowE = (uint32_t)E * 4u, rowN = (uint32_t)N * 4u;
