@@ -1573,6 +1573,7 @@ __global__ __launch_bounds__(ET * 8) __attribute__((amdgpu_waves_per_eu(2, 2))) 
 #pragma unroll
             for (int n = SILU_N0; n < NT; ++n) silu_merge16(am[m][n], am[m][n], al2[m][n], X3_INV_SCALE);
         if (k == GCDM_STAMP_K) STAMP(13);
+        [[maybe_unused]] h8 fin_w1[2], fin_w2[2];
 #ifndef GCDM_ABL_NOGATE
         gate_partial_x3p<MT, NT, true>(gm, gl, am, gwk);
         // the next tile (clamped to the workgroup's last one: no branch): its index words and per-edge constants are requested behind the last
@@ -1580,7 +1581,6 @@ __global__ __launch_bounds__(ET * 8) __attribute__((amdgpu_waves_per_eu(2, 2))) 
         // over the attention phase (load_gather_part) and arrive under the aggregation
         // the vector_up operands of the last GCP2's vector part (finish_only below) are requested ahead of the next tile's index words and constants: loads
         // return in order, so behind those HBM streams they would wait for them (-DGCDM_X3_FIN_LATE: requested at the point of use, rounds 1-4)
-        [[maybe_unused]] h8 fin_w1[2], fin_w2[2];
 #ifndef GCDM_X3_FIN_LATE
         if (k == 2 && vhalf == 1) {
 #pragma unroll
