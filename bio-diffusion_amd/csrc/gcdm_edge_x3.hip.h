@@ -1056,8 +1056,11 @@ struct EdgeMsgX3Args {
 #define GCDM_FLAG_F16_RANGE_BIT 8u
 
 // ET = 64: 8 waves, wave w owns M-tile w x both N-tiles (every weight byte is loaded once per CU and tile).
-// ET = 32: 4 waves, wave w owns M-tiles 2w, 2w+1 x one N-tile; half the LDS, so two workgroups share a CU and run out of phase
-//          (one in its GEMM while the other is in a VALU phase) at the price of streaming the weights twice per 64 edges.
+// ET = 32: 4 waves, wave w owns M-tiles 2w, 2w+1 x one N-tile; half the LDS.  Designed for two workgroups per CU running out of phase (one in its GEMM
+//          while the other is in a VALU phase) at the price of streaming the weights twice per 64 edges -- but since the attention weights (round 3) and the
+//          unit vectors (round 5) are staged in LDS its footprint is 83 260 B, 1.3 KB more than half of the CU's 160 KB: the launch's 2 x CUs workgroups run
+//          in two rounds of ONE per CU (QM9: 0.89 ms per launch against 0.72 ms with 64-edge tiles).  Kept as an option (edge_tile = 32) for A/B runs and
+//          for the determinism tests, which cover both tile sizes; not a production configuration.
 template <int SE, int VE, int ET>
 __global__ __launch_bounds__(ET * 8) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_edge_msg_x3(EdgeMsgX3Args ax0) {
     constexpr int NW = ET / 8, MT = 8 / NW, NT = ET / 32;     // waves, M-tiles and N-tiles per wave

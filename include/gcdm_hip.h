@@ -188,7 +188,8 @@ int gcdm_debug_set_layer_limit(gcdm_handle* h, int32_t num_layers_to_run);
  * costs one k and halves the activation range: k = 6 admits < 2047, activations < 1.9e6).  Only a model with a larger (>= 2047)
  * or non-finite packed weight runs in mode 0 whatever was requested
  * (gcdm_get_option reports the effective mode) and setting mode 1 on it fails.
- * "edge_tile": edges per workgroup of the edge-message kernels: 64 (one 8-wave workgroup per CU), 32 (two 4-wave workgroups per CU) or
+ * "edge_tile": edges per workgroup of the edge-message kernels: 64 (one 8-wave workgroup per CU), 32 (4-wave workgroups of 83 KB of LDS: one per CU at a time
+ * since round 3, i.e. slower -- an A/B and test option) or
  * 0 = automatic (default; env GCDM_EDGE_TILE): 64 -- with the operand requests of the next k-blocks issued between the MFMAs of the
  * current one the 64-edge tile (every weight byte read once per 64 edges) is the faster one for both edge widths, DESIGN.md 3.4.
  * "persistent": 1 (default; env GCDM_PERSISTENT) / 0 -- the split-precision edge-message kernel as one workgroup per CU (two at 32-edge tiles) that walks
