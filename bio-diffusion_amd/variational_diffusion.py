@@ -19,6 +19,7 @@ Two ways to take a step:
 from __future__ import annotations
 
 import ctypes as C
+import os
 import logging
 from random import random as _random
 from typing import Any, Callable, Dict, List, Optional, Tuple, Union
@@ -85,8 +86,11 @@ def slice_cuts(num_nodes: torch.Tensor, K: int) -> List[int]:
         raise ValueError(f"cannot cut {Bm} molecules into {K} non-empty slices")
     work_cum = (nn_ ** 2).cumsum(0)
     cuts = [0]
+    fr = os.environ.get("GCDM_SLICE_FRACTIONS")              # experiment hook: cumulative work fractions of the cuts, e.g. "0.4873" for K = 2
+    fr = [float(v) for v in fr.split(",")] if fr else None
     for k in range(1, K):
-        c = int(torch.searchsorted(work_cum, work_cum[-1] * k // K).item()) + 1
+        target = int(work_cum[-1] * fr[k - 1]) if fr and len(fr) == K - 1 else work_cum[-1] * k // K
+        c = int(torch.searchsorted(work_cum, target).item()) + 1
         cuts.append(min(max(c, cuts[-1] + 1), Bm - (K - k)))
     cuts.append(Bm)
     return cuts
