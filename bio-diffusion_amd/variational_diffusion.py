@@ -86,11 +86,10 @@ def slice_cuts(num_nodes: torch.Tensor, K: int) -> List[int]:
         raise ValueError(f"cannot cut {Bm} molecules into {K} non-empty slices")
     work_cum = (nn_ ** 2).cumsum(0)
     cuts = [0]
-    fr = os.environ.get("GCDM_SLICE_FRACTIONS")              # experiment hook: cumulative work fractions of the cuts, e.g. "0.4873" for K = 2
-    fr = [float(v) for v in fr.split(",")] if fr else None
+    # (round 5 measured unequal cuts -- the first slice's tile count a multiple of the persistent workgroup count, 0.4873 / 0.5127 / 0.45 / 0.531 of the work:
+    #  6.93 / 6.92 / 6.95 / 6.85 ms per step against 6.88 for the equal cut, profiles/r05_slices.txt: the dispatcher already fills one slice's tails with the other)
     for k in range(1, K):
-        target = int(work_cum[-1] * fr[k - 1]) if fr and len(fr) == K - 1 else work_cum[-1] * k // K
-        c = int(torch.searchsorted(work_cum, target).item()) + 1
+        c = int(torch.searchsorted(work_cum, work_cum[-1] * k // K).item()) + 1
         cuts.append(min(max(c, cuts[-1] + 1), Bm - (K - k)))
     cuts.append(Bm)
     return cuts
