@@ -598,6 +598,22 @@ def test_committed_pmc_summaries_belong_to_the_kernels_in_the_tree():
         assert bench.csrc_sha16(tmp) != base
 
 
+def test_persistent_edge_kernels_do_not_touch_scratch():
+    """Static check (no GPU): no instantiation of the persistent split-precision edge kernel may spill.  One spilled register cost 2.4 % of every tile in
+    rounds 3-4: a scratch reload is the youngest load in flight and waits behind every prefetch of the next tile."""
+    import shutil
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import isa_census
+    fake = ("_Z13k_edge_msg_x3ILi64ELi16ELi64EEv13EdgeMsgX3Args:                                  ; @_Z13k_edge_msg_x3ILi64ELi16ELi64EEv13EdgeMsgX3Args\n"
+            "\tscratch_load_dword v1, off, off\n\ts_endpgm\n\t.end_amdhsa_kernel\n")
+    assert isa_census.scratch_users(fake) == ["_Z13k_edge_msg_x3ILi64ELi16ELi64EEv13EdgeMsgX3Args"]
+    assert isa_census.scratch_users(fake.replace("scratch_load_dword v1, off, off", "v_mov_b32_e32 v1, v2")) == []
+    if shutil.which(os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")) is None:
+        pytest.skip("hipcc not available")
+    assert isa_census.scratch_users() == []
+
+
 def test_no_mfma_directly_behind_a_partial_write_of_its_source():
     """Static check of the compiled gfx950 kernels (no GPU): an MFMA issued with no wait state behind a v_fma_mix{lo,hi}_f16 write of one
     of its source registers reads the old register on gfx950 (tools/mfma_partial_write_hazard.hip); the compiler is expected to separate the

@@ -31,7 +31,18 @@ CLASSES = [
 ]
 
 
+_ASM_CACHE = {}
+
+
 def compile_to_asm():
+    key = tuple(os.path.getmtime(os.path.join(os.path.dirname(SRC), f)) for f in sorted(os.listdir(os.path.dirname(SRC))))
+    if key not in _ASM_CACHE:
+        _ASM_CACHE.clear()
+        _ASM_CACHE[key] = _compile_to_asm()
+    return _ASM_CACHE[key]
+
+
+def _compile_to_asm():
     with tempfile.TemporaryDirectory() as d:
         out = os.path.join(d, "k.s")
         subprocess.run([os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")] + FLAGS + ["-o", out, SRC], check=True, stderr=subprocess.DEVNULL)
@@ -61,6 +72,14 @@ def _kernels(text):
                 continue
             ins.append(t)
         yield m.group(1), ins
+
+
+def scratch_users(text=None, pattern="k_edge_msg_x3"):
+    """Kernels (mangled names containing `pattern`) whose ISA touches scratch memory.  Round 5: ONE spilled VGPR of k_edge_msg_x3<64,16,64> -- a lane id the
+    compiler had hoisted out of the persistent loop -- cost 2.4 % of every tile: its scratch reload is the youngest load in flight and, loads returning in
+    order, waits for every prefetched row of the next tile.  The persistent kernels must stay spill-free."""
+    text = compile_to_asm() if text is None else text
+    return [name for name, ins in _kernels(text) if pattern in name and any(i.startswith("scratch_") or "offen" in i and i.startswith("buffer_") and "s[0:3]" in i for i in ins)]
 
 
 def lint_partial_writes(text=None, min_states=1, embed_rule=True):
