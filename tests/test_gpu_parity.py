@@ -551,6 +551,43 @@ def test_captured_step_equals_direct_launches(case, num_nodes, mode):
     assert lib.gcdm_get_option(h, b"graph_launches") == before and torch.isfinite(z).all()
 
 
+def test_step_refused_during_capture_keeps_the_callers_error_and_the_graph():
+    """A call that fails the step's own argument checks WHILE the step is being captured (a context-conditioned model called without a context) must return
+    that diagnostic -- what the direct path returns for the same call -- and must not switch the step graph off for the handle: the next valid call is
+    captured and served by the graph (rounds 3-4 reported "capture of one step: no error" and latched the graph off)."""
+    case = "qm9cond"
+    d = _dims(case)
+    net, W, cfgs = _net(case, seed=23, scale=0.25, mode=1)
+    ddpm = pkg.EquivariantVariationalDiffusion(net, cfgs["diffusion_cfg"], cfgs["dataloader_cfg"], pkg.dataset_info("qm9")).cuda()
+    dev = torch.device("cuda")
+    dyn, lib, h = ddpm._native(dev)
+    nn_ = torch.tensor([5, 19, 3, 11])
+    bi = O.num_nodes_to_batch_index(nn_)
+    N, D = len(bi), 3 + _ocfg(case).num_node_scalar_features
+    dyn.plan(nn_)
+    g = torch.Generator().manual_seed(5)
+    z = (0.3 * torch.randn((N, D), generator=g)).to(dev)
+    ctx = torch.randn((len(nn_), 1), generator=g)[bi].to(dev).contiguous()
+    stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    fl = torch.zeros(1, dtype=torch.int32, device=dev)
+    args = lambda cp, s: (h, C.c_void_p(z.data_ptr()), cp, s, 1000, None, C.c_uint64(7), C.c_void_p(fl.data_ptr()), stream)
+    assert lib.gcdm_set_option(h, b"step_graph", 1) == 0
+    before = lib.gcdm_get_option(h, b"graph_launches")
+    assert lib.gcdm_sample_step(*args(None, 999)) != 0                      # refused: no context
+    assert b"context required" in lib.gcdm_last_error(h), lib.gcdm_last_error(h)
+    assert lib.gcdm_get_option(h, b"step_graph") == 1                        # ... and the graph is still enabled
+    for s in (999, 998, 997):
+        assert lib.gcdm_sample_step(*args(C.c_void_p(ctx.data_ptr()), s)) == 0, lib.gcdm_last_error(h)
+    torch.cuda.synchronize()
+    assert lib.gcdm_get_option(h, b"graph_launches") - before == 3 and torch.isfinite(z).all()
+    # cog_fix and an option set to the value it already has do not invalidate the captured step (no re-capture: the launches keep counting, same exec)
+    assert lib.gcdm_set_option(h, b"cog_fix", 0) == 0 and lib.gcdm_set_option(h, b"cog_fix", 1) == 0
+    assert lib.gcdm_set_option(h, b"mfma_mode", 1) == 0
+    assert lib.gcdm_sample_step(*args(C.c_void_p(ctx.data_ptr()), 996)) == 0
+    torch.cuda.synchronize()
+    assert lib.gcdm_get_option(h, b"graph_launches") - before == 4
+
+
 @pytest.mark.parametrize("bias", [1.0e4, 1.0e5])
 def test_split_precision_envelope_at_large_activations(bias):
     """The worst clean point of the round-4 envelope sweep (tests/gpu_envelope.py): with no LayerNorm in the production configuration
