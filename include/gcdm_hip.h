@@ -216,8 +216,10 @@ int gcdm_get_option(const gcdm_handle* h, const char* name);
  * kernel, one launch per interaction layer) with HIP events on `stream`; gcdm_profile_edge_kernel_ms() synchronises on
  * them and returns the summed duration and the launch count of the LAST forward.  enable = 2 adds in-kernel phase time
  * stamps of that kernel (gcdm_debug_read "phase": [tiles][8 waves][24] shader-clock offsets), enable = 3 the same for the
- * per-layer node kernel ("phase_node": [node tiles][8][24]); both are diagnostics that exist only in a library built with
- * -DGCDM_STAMPS (the stamps cost issue slots even when switched off): enable >= 2 fails on the default build. */
+ * per-layer node kernel ("phase_node": [node tiles][8][24]).  The per-phase stamps are diagnostics of a library built with
+ * -DGCDM_STAMPS (they cost issue slots and pin the schedule: a stamped build's tile is not the shipped kernel's); the default build
+ * carries ONE of them, the end-of-tile stamp of the split-precision edge kernel (entry 20 of "phase"; round 5) -- the shipped kernel's
+ * own cycles per tile, which is what compares builds and boxes (tools/ab_variant.py).  enable = 3 fails on the default build. */
 int gcdm_profile_enable(gcdm_handle* h, int32_t enable);
 int gcdm_profile_edge_kernel_ms(gcdm_handle* h, double* total_ms, int32_t* launches);
 /* The same for the per-layer node kernel (feed-forward + position update + the next layer's node-level halves; launched right behind
