@@ -594,6 +594,19 @@ def main():
 
     mode_ms = {m: (mode_wall[m][0], *kernel_launch_ms(m)) for m in sorted(mode_wall, reverse=True)}
     lib.gcdm_set_option(h, b"mfma_mode", x3_mode)
+    # the shipped edge kernel's own cycles per tile (end-of-tile stamp, part of every build; split-precision mode): the figure that compares builds and boxes --
+    # the boxes of the pool run this loop at 2.00-2.15 GHz, so milliseconds differ by +-4 % for identical kernels, cycles by +-0.1 %
+    tile_cycles = tiles = None
+    if x3_mode == 1:
+        for _ in range(3):                       # (back in the split-precision mode: its weights are cold in the L2 after the fp32-mode steps)
+            lib.gcdm_sample_step(h, zp, cptr, max(s_idx, 0), T, None, seed, fp, stream); s_idx -= 1
+    if x3_mode == 1 and lib.gcdm_profile_enable(h, 2) == 0:
+        lib.gcdm_sample_step(h, zp, cptr, max(s_idx, 0), T, None, seed, fp, stream); s_idx -= 1
+        torch.cuda.synchronize(dev)
+        et = int(lib.gcdm_get_option(h, b"edge_tile"))
+        ph = dyn.debug_read("phase").view(-1, 8, 24)[:, :(4 if et == 32 else 8), 20]
+        tiles, tile_cycles = int(ph.shape[0]), float(ph.mean().item())
+        lib.gcdm_profile_enable(h, 0)
     edge_ms, node_ms = mode_ms[x3_mode][1], mode_ms[x3_mode][2]
     fallback_ms = mode_ms[0][0] if 0 in mode_ms and x3_mode == 1 else None
 
@@ -737,6 +750,7 @@ def main():
             "roofline": {"bound": "mfma", "kernel": "k_edge_msg_x3" if x3 else "k_edge_msg", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
                          "frac": achieved / peak, "traffic": pmc.get("hbm_bytes_per_launch"), "avg_launch_ms": edge_ms,
                          "algorithmic_flop_per_launch": alg_edge_layer, "launches_per_step": d["L"], "edges_per_workgroup": int(lib.gcdm_get_option(h, b"edge_tile")),
+                         "tile_cycles": tile_cycles, "tiles_per_launch": tiles,
                          "mfma": ("f16 x3 split (x = hi + 2^-11 lo', fp32 accumulate, fp32-equivalent accuracy); peak = 2500/3" if x3
                                   else "fp32 32x32x2"),
                          "mfma_busy_frac_pmc": pmc.get("mfma_busy_frac"), "pmc_source": pmc.get("source"),

@@ -40,6 +40,8 @@ def _check_line(r, n_gpus, B):
     want = n_gpus * B / (1001 * r["ms_per_step"] * 1e-3)
     assert abs(r["value"] / want - 1) < 1e-9
     assert 0.0 < r["roofline"]["frac"] < 1.0 and r["roofline"]["avg_launch_ms"] > 0 and r["roofline"]["node_kernel"]["avg_launch_ms"] > 0
+    # the shipped kernel's own cycles per tile (end-of-tile stamp): the box-independent figure of the line
+    assert 3.0e4 < r["roofline"]["tile_cycles"] < 1.0e5 and r["roofline"]["tiles_per_launch"] == -(-B * 19 * 19 // 64)
 
 
 def test_two_ranks_run_the_multi_rank_branch():
