@@ -1711,8 +1711,17 @@ __global__ __launch_bounds__(ET * 8) __attribute__((amdgpu_waves_per_eu(2, 2))) 
         // channel): 88 per segment, so the 4-5 row segments of a QM9 tile are ONE trip of the 512 threads (round 2: 160 units, the vector
         // components one float each -> 1.4 trips, the second one on three waves only)
         constexpr int UNITS = GCDM_SG + 3 * (GCDM_V / 4);
+        // work-item order (round 5): all scalar units of all segments first (GCDM_SG = 64 per segment: every wave of that part runs ONE path on one segment),
+        // then the vector units -- rounds 2-4 numbered the items segment by segment (88 per segment), so that most waves held both kinds and ran both paths
+        // one after the other.  Same sums in the same order per item: same bits.
+        const int nscal = nseg * GCDM_SG;
         for (int wk = tid; wk < nseg * UNITS; wk += EK_THREADS) {
+#ifdef GCDM_X3_AGG_BY_SEGMENT
             const int sg = wk / UNITS, un = wk - sg * UNITS;
+#else
+            const int rv = wk - nscal;
+            const int sg = wk < nscal ? wk / GCDM_SG : rv / (UNITS - GCDM_SG), un = wk < nscal ? wk - sg * GCDM_SG : GCDM_SG + rv - sg * (UNITS - GCDM_SG);
+#endif
             const int2 rec = m_rec[sg];
             const int node = rec.x, sb = rec.y & 255, en = (rec.y >> 8) & 255;
             const bool whole = (rec.y >> 16) != 0;
