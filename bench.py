@@ -45,6 +45,7 @@ for p in (ROOT, os.path.join(ROOT, "tests")):
 PEAK_FP32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md, dense fp32 matrix peak
 PEAK_F16_MFMA_TFLOPS = 2500.0   # same guide, dense f16/bf16 matrix peak (the 5 PF marketing figure is 2:1 sparse)
 NET_EVALS_PER_SAMPLE = 1001     # 1000 denoise steps + the t=0 decode
+NOMINAL_SCLK_MHZ = 2400.0       # the engine clock the guide's matrix peaks are quoted at
 
 WORKLOADS = {
     "qm9": dict(dataset="qm9", cond=(), B=1024, n=19, name="QM9 unconditional, 1024 molecules x 19 atoms / GPU, 1000-step DDPM"),
@@ -335,6 +336,146 @@ def eval_driver_config(pkg, dev, rank, in_flight, steps=100):
             "unit": "molecules/s", "steps": steps, "windows_ms_per_step": [round(w, 4) for w in wins]}
 
 
+class ClockSampler:
+    """Engine clock (sclk, MHz) and socket power (W) of ONE GPU, sampled by a side thread while a timed window runs, so that a reader of the JSON
+    line can tell a kernel gain from a faster box (the pool's boxes sustain 2.00-2.15 GHz under this loop: +-4 % in milliseconds for identical
+    kernels).  Sources, first one that answers: the amdsmi Python binding (in-process), the amdgpu hwmon files of the device's PCI address
+    (freq1_input / power1_input), `rocm-smi --showclocks --showpower --json` (a subprocess per sample: coarse).  Never raises: a box where none
+    works reports source = None and empty statistics."""
+
+    def __init__(self, dev_index=0, period_s=0.01):
+        import threading
+        self.period = period_s
+        self.samples = []            # (t, sclk_mhz, power_w)
+        self._stop = threading.Event()
+        self._thread = None
+        self.source = None
+        self._read = None
+        try:
+            prop = torch.cuda.get_device_properties(dev_index)
+            bdf = "%04x:%02x:%02x.0" % (getattr(prop, "pci_domain_id", 0), prop.pci_bus_id, prop.pci_device_id)
+        except Exception:
+            bdf = None
+        self.bdf = bdf
+        for probe in (self._probe_amdsmi, self._probe_hwmon, self._probe_rocm_smi):
+            try:
+                rd = probe(dev_index)
+                if rd is not None and rd()[0]:
+                    self._read = rd
+                    break
+            except Exception:
+                continue
+        if self._read is None:
+            self.source = None
+
+    def _probe_amdsmi(self, dev_index):
+        import amdsmi
+        amdsmi.amdsmi_init()
+        hs = amdsmi.amdsmi_get_processor_handles()
+        h = None
+        if self.bdf:
+            for c in hs:
+                try:
+                    if amdsmi.amdsmi_get_gpu_device_bdf(c).lower() == self.bdf:
+                        h = c
+                except Exception:
+                    pass
+        if h is None:
+            h = hs[dev_index]
+
+        def rd():
+            ck = amdsmi.amdsmi_get_clock_info(h, amdsmi.AmdSmiClkType.GFX)
+            pw = amdsmi.amdsmi_get_power_info(h)
+            w = pw.get("current_socket_power", pw.get("average_socket_power"))
+            if not isinstance(w, (int, float)) or w <= 0:
+                w = pw.get("average_socket_power")
+            return float(ck.get("clk", ck.get("cur_clk", 0)) or 0), float(w) if isinstance(w, (int, float)) else None
+        self.source = "amdsmi"
+        return rd
+
+    def _probe_hwmon(self, dev_index):
+        import glob
+        if not self.bdf:
+            return None
+        hw = glob.glob(f"/sys/bus/pci/devices/{self.bdf}/hwmon/hwmon*")
+        if not hw:
+            return None
+        fq, pw = os.path.join(hw[0], "freq1_input"), os.path.join(hw[0], "power1_input")
+        if not os.path.exists(pw):
+            pw = os.path.join(hw[0], "power1_average")
+
+        def rd():
+            with open(fq) as f:
+                mhz = int(f.read()) / 1e6
+            try:
+                with open(pw) as f:
+                    w = int(f.read()) / 1e6
+            except Exception:
+                w = None
+            return mhz, w
+        self.source = "hwmon:" + self.bdf
+        return rd
+
+    def _probe_rocm_smi(self, dev_index):
+        import subprocess
+
+        def rd():
+            o = subprocess.run(["/opt/rocm/bin/rocm-smi", "--showclocks", "--showpower", "--json"], capture_output=True, text=True, timeout=10).stdout
+            d = json.loads(o)
+            c = d[sorted(d)[dev_index]]
+            mhz = w = None
+            for k, v in c.items():
+                if k.startswith("sclk clock speed"):
+                    mhz = float(str(v).strip("()Mhz "))
+                if "Socket Graphics Package Power" in k or k.startswith("Average Graphics Package Power"):
+                    w = float(v)
+            return mhz, w
+        self.source = "rocm-smi"
+        self.period = max(self.period, 0.5)
+        return rd
+
+    def start(self):
+        import threading
+        if self._read is None or self._thread is not None:
+            return self
+        self._stop.clear()
+
+        def loop():
+            while not self._stop.is_set():
+                try:
+                    mhz, w = self._read()
+                    self.samples.append((time.perf_counter(), mhz, w))
+                except Exception:
+                    pass
+                self._stop.wait(self.period)
+        self._thread = threading.Thread(target=loop, daemon=True)
+        self._thread.start()
+        return self
+
+    def stop(self):
+        if self._thread is not None:
+            self._stop.set()
+            self._thread.join(timeout=15)
+            self._thread = None
+
+    def stats(self, t0=None, t1=None):
+        """mean / min / max of the samples taken in [t0, t1] (perf_counter times; None = all)."""
+        sel = [(m, w) for (t, m, w) in self.samples if (t0 is None or t >= t0) and (t1 is None or t <= t1) and m]
+        nearest = False
+        if not sel and self.samples and t0 is not None and t1 is not None:
+            # a window shorter than the sampling period: the sample nearest to it (the clock moves on a ~100 ms scale), if one lies within 0.25 s
+            mid = 0.5 * (t0 + t1)
+            t, m, w = min(self.samples, key=lambda x: abs(x[0] - mid))
+            if m and abs(t - mid) <= 0.25 + 0.5 * (t1 - t0):
+                sel, nearest = [(m, w)], True
+        if not sel:
+            return {"source": self.source, "samples": 0, "sclk_mhz": None, "power_w": None}
+        ms = [m for m, _ in sel]
+        ws = [w for _, w in sel if w]
+        return {"source": self.source, "samples": 0 if nearest else len(sel), "nearest_sample_used": nearest, "sclk_mhz": sum(ms) / len(ms), "sclk_mhz_min": min(ms), "sclk_mhz_max": max(ms),
+                "power_w": (sum(ws) / len(ws)) if ws else None, "power_w_max": max(ws) if ws else None}
+
+
 def log(msg):
     if os.environ.get("RANK", "0") == "0":
         print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
@@ -463,6 +604,8 @@ def main():
                 native.check(ln.lib, ln.h, st, "gcdm_sample_step")
 
     log(f"plan: N={N} E={E} cpu_count={os.cpu_count()}")
+    clocks = ClockSampler(local_rank).start()          # sclk / socket power of THIS rank's GPU through every window below (roofline.sclk_mhz & co.)
+    log(f"clock sampler: {clocks.source}")
     native.check(lib, h, lib.gcdm_sample_init(h, zp, None, seed, stream), "gcdm_sample_init")
     if sliced is not None:
         sliced.init()
@@ -487,7 +630,15 @@ def main():
         sliced.wait()
     barrier()
     elapsed = time.perf_counter() - t0
+    clk_timed = clocks.stats(t0, t0 + elapsed)
+    per_rank = None
     if dist is not None:
+        # the line reports the SLOWEST rank (contract); the per-rank figures say whether a scaling loss is a slow box or the code
+        mine = {"rank": rank, "ms_per_step": elapsed / args.steps * 1e3, "sclk_mhz": clk_timed.get("sclk_mhz"), "power_w": clk_timed.get("power_w")}
+        gathered = [None] * world
+        dist.all_gather_object(gathered, mine)
+        per_rank = {"ms_per_step": [round(g["ms_per_step"], 4) for g in gathered], "sclk_mhz": [g["sclk_mhz"] for g in gathered],
+                    "power_w": [g["power_w"] for g in gathered]}
         tt = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if dist.get_backend() == "gloo" else dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
@@ -515,7 +666,9 @@ def main():
     mode_steps = 20
     mode_wall = {}
     run_steps(3)
+    t_mw = time.perf_counter()
     mode_wall[x3_mode] = median_of_windows(run_steps, mode_steps)
+    clk_windows = clocks.stats(t_mw, time.perf_counter())
     if x3_mode == 1 and not args.no_fp32_timing:
         set_mode(0)
         run_steps(3)                # settle clocks / caches
@@ -543,7 +696,8 @@ def main():
                                        context=None if ctx is None else ctx[torch.cumsum(num_nodes.long(), 0).to(dev) - 1])
         torch.cuda.synchronize(dev)
         fs = time.perf_counter() - tfs
-        full_sample = {"seconds": fs, "value": B / fs, "unit": "molecules/s", "flags": int(ddpm.last_flags), "finite": bool(torch.isfinite(xs).all().item()),
+        clk_full = clocks.stats(tfs, tfs + fs)
+        full_sample = {"seconds": fs, "sclk_mhz": clk_full.get("sclk_mhz"), "power_w": clk_full.get("power_w"), "clock_samples": clk_full.get("samples"), "value": B / fs, "unit": "molecules/s", "flags": int(ddpm.last_flags), "finite": bool(torch.isfinite(xs).all().item()),
                        "vs_extrapolated": (B / fs) / (B / (ms_per_step * 1e-3 * NET_EVALS_PER_SAMPLE)),
                        "what": "one complete mol_gen_sample call (1000 denoise steps + decode, host clock, same slices and matrix mode as the timed loop)"}
 
@@ -592,7 +746,13 @@ def main():
         lib.gcdm_profile_enable(h, 0)
         return tot / max(cnt, 1), totn / max(cnt, 1)
 
-    mode_ms = {m: (mode_wall[m][0], *kernel_launch_ms(m)) for m in sorted(mode_wall, reverse=True)}
+    mode_ms = {}
+    clk_kernel = {}
+    for m in sorted(mode_wall, reverse=True):
+        t_m = time.perf_counter()
+        mode_ms[m] = (mode_wall[m][0], *kernel_launch_ms(m))
+        torch.cuda.synchronize(dev)
+        clk_kernel[m] = clocks.stats(t_m, time.perf_counter())
     lib.gcdm_set_option(h, b"mfma_mode", x3_mode)
     # the shipped edge kernel's own cycles per tile (end-of-tile stamp, part of every build; split-precision mode): the figure that compares builds and boxes --
     # the boxes of the pool run this loop at 2.00-2.15 GHz, so milliseconds differ by +-4 % for identical kernels, cycles by +-0.1 %
@@ -608,6 +768,7 @@ def main():
         tiles, tile_cycles = int(ph.shape[0]), float(ph.mean().item())
         lib.gcdm_profile_enable(h, 0)
     edge_ms, node_ms = mode_ms[x3_mode][1], mode_ms[x3_mode][2]
+    clocks.stop()
     fallback_ms = mode_ms[0][0] if 0 in mode_ms and x3_mode == 1 else None
 
     # plug point 1: what the reference's UNCHANGED mol_gen_sample loop costs after the one-line registry swap -- per step one
@@ -751,6 +912,17 @@ def main():
                          "frac": achieved / peak, "traffic": pmc.get("hbm_bytes_per_launch"), "avg_launch_ms": edge_ms,
                          "algorithmic_flop_per_launch": alg_edge_layer, "launches_per_step": d["L"], "edges_per_workgroup": int(lib.gcdm_get_option(h, b"edge_tile")),
                          "tile_cycles": tile_cycles, "tiles_per_launch": tiles,
+                         # the clock the numbers of this line ran at (ClockSampler: sclk / socket power of this GPU, sampled every 20 ms):
+                         #   sclk_mhz / power_w                 during the driver-contract window (ms_per_step); when that window is shorter than a few samples
+                         #                                      (the default 20 steps are 0.14 s) read clock.mode_windows / full_sample.sclk_mhz beside it
+                         #   frac_at_measured_clock             achieved / (peak x sclk / 2400 MHz) with the sclk of the whole-batch launches avg_launch_ms was measured on
+                         #   sclk_mhz_from_cycles               the same clock from the kernel itself: ceil(tiles / CUs) x tile_cycles / avg_launch_ms
+                         "sclk_mhz": clk_timed.get("sclk_mhz") or clk_windows.get("sclk_mhz"), "power_w": clk_timed.get("power_w") or clk_windows.get("power_w"),
+                         "clock": {"source": clocks.source, "nominal_mhz": NOMINAL_SCLK_MHZ, "timed_window": clk_timed, "mode_windows": clk_windows,
+                                   "kernel_timing": clk_kernel.get(x3_mode)},
+                         "frac_at_measured_clock": (achieved / (peak * clk_kernel[x3_mode]["sclk_mhz"] / NOMINAL_SCLK_MHZ)
+                                                    if clk_kernel.get(x3_mode, {}).get("sclk_mhz") else None),
+                         "sclk_mhz_from_cycles": ((-(-tiles // cus_)) * tile_cycles / (edge_ms * 1e3)) if (tile_cycles and tiles and edge_ms) else None,
                          "mfma": ("f16 x3 split (x = hi + 2^-11 lo', fp32 accumulate, fp32-equivalent accuracy); peak = 2500/3" if x3
                                   else "fp32 32x32x2"),
                          "mfma_busy_frac_pmc": pmc.get("mfma_busy_frac"), "pmc_source": pmc.get("source"),
@@ -797,6 +969,8 @@ def main():
         res["training_step"] = {"ms_per_batch": train_ms, "batch": 64, "value": None if train_ms is None else 64 / (train_ms * 1e-3), "unit": "molecules/s",
                                 "what": "forward in training mode + loss + backward of one 64-molecule batch on the module path (libgcdm_ops.so operators with "
                                         "autograd; parity with the reference's autograd: tests/test_modules_gpu.py); outside the sampling path"}
+        if per_rank is not None:
+            res["per_rank"] = per_rank
         res["roofline"]["pmc_stale"] = pmc.get("stale")
         res["roofline"]["pmc_collected_at_commit"] = pmc.get("collected_at_commit")
         if other_configs is not None:

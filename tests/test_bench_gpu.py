@@ -42,6 +42,19 @@ def _check_line(r, n_gpus, B):
     assert 0.0 < r["roofline"]["frac"] < 1.0 and r["roofline"]["avg_launch_ms"] > 0 and r["roofline"]["node_kernel"]["avg_launch_ms"] > 0
     # the shipped kernel's own cycles per tile (end-of-tile stamp): the box-independent figure of the line
     assert 3.0e4 < r["roofline"]["tile_cycles"] < 1.0e5 and r["roofline"]["tiles_per_launch"] == -(-B * 19 * 19 // 64)
+    # the clock the line ran at (round 6): sclk / socket power sampled while the windows ran, the roofline fraction at THAT clock, and the clock the
+    # kernel's own cycle stamps imply -- what separates 3 % of kernel from 4 % of box
+    rf = r["roofline"]
+    for key in ("sclk_mhz", "power_w", "frac_at_measured_clock", "sclk_mhz_from_cycles", "clock"):
+        assert key in rf, key
+    assert rf["clock"]["source"] is not None, "no clock source answered on this box (amdsmi / hwmon / rocm-smi)"
+    assert 400.0 < rf["sclk_mhz"] <= 2500.0 and 100.0 < rf["power_w"] < 2000.0
+    assert 400.0 < rf["sclk_mhz_from_cycles"] <= 2600.0
+    assert rf["frac"] <= rf["frac_at_measured_clock"] < 1.0          # the box never runs above the nominal 2.4 GHz the peak is quoted at
+    if n_gpus > 1:
+        pr = r["per_rank"]
+        assert len(pr["ms_per_step"]) == n_gpus == len(pr["sclk_mhz"]) == len(pr["power_w"])
+        assert abs(max(pr["ms_per_step"]) / r["ms_per_step"] - 1) < 1e-3          # the line reports the slowest rank
 
 
 def test_two_ranks_run_the_multi_rank_branch():

@@ -1253,6 +1253,102 @@ def test_full_size_every_row_matches_reference_golden(case, mode, golden_dir):
         assert (out - other).abs().max().item() <= bar
 
 
+@pytest.mark.parametrize("mode", MODES)
+@pytest.mark.parametrize("case", ["qm9", "qm9cond", "geom"])
+def test_full_size_every_row_through_the_two_slice_handles_matches_reference_golden(case, mode, golden_dir):
+    """The configuration bench.py TIMES is not one handle: `mol_gen_sample(lanes=2)` / `_SlicedBatch` cut the flat batch into two slices of molecules, each planned on
+    its own handle with the seam options (flat_prev / flat_next / node_base) set, and every step evaluates the network once per slice.  Here the same full-size inputs
+    as test_full_size_every_row_matches_reference_golden go through exactly those two handles (`_SlicedBatch` builds them; one gcdm_forward per slice on its own
+    stream, rows addressed as the sampler addresses them) and EVERY row -- the seam rows 9 727 / 9 728 (C2, C3) and 5 631 / 5 632 (C4) included -- is held to the
+    reference's own fp64 forward of the flat batch.  (gcpnet.py:1069-1232: the orientations of a node read its flat-batch neighbours.)"""
+    g = np.load(os.path.join(golden_dir, f"fullsize_{case}.npz"))
+    B, n = int(g["B"]), int(g["n"])
+    d = _dims(case)
+    net, W, cfgs = _net(case, seed=int(g["weight_seed"]), scale=float(g["weight_scale"]), mode=mode)
+    xh, t, bi, nn_, ctx = synth.make_inputs([n] * B, synth.dims_feat(d), seed=int(g["input_seed"]), t_value=float(g["t_value"]), n_ctx=d["n_ctx"])
+    ds = "geom" if case == "geom" else "qm9"
+    ddpm = pkg.EquivariantVariationalDiffusion(net, cfgs["diffusion_cfg"], cfgs["dataloader_cfg"], pkg.dataset_info(ds)).cuda()
+    dev = torch.device("cuda")
+    ctx_mol = None if ctx is None else ctx.view(B, n, -1)[:, 0].contiguous()            # per molecule, as mol_gen_sample takes it
+    sb = ddpm._SlicedBatch(ddpm, torch.full((B,), n, dtype=torch.int32), dev, ctx_mol, 11, 2)
+    assert len(sb.sl) == 2 and sb.sl[1]["n0"] == (B // 2) * n
+    xd, td = xh.to(dev).contiguous(), t.reshape(-1).to(dev).contiguous()
+    od = torch.full_like(xd, float("nan"))
+    start = torch.cuda.Event()
+    start.record(torch.cuda.current_stream())
+    for k, w in enumerate(sb.sl):
+        ln, n0 = w["lane"], w["n0"]
+        assert ln.lib.gcdm_get_option(ln.h, b"flat_prev") == int(k > 0) and ln.lib.gcdm_get_option(ln.h, b"flat_next") == int(k < 1)
+        assert ln.lib.gcdm_get_option(ln.h, b"node_base") == n0 and ln.lib.gcdm_get_option(ln.h, b"mfma_mode") == mode
+        ln.stream.wait_event(start)
+        st = ln.lib.gcdm_forward(ln.h, sb._row(xd, n0), C.c_void_p(td.data_ptr() + 4 * n0), sb._cptr(n0), sb._row(od, n0), None, w["stream"])
+        assert st == 0, ln.lib.gcdm_last_error(ln.h)
+    torch.cuda.synchronize()
+    sb.close()
+    out = od.cpu()
+    ref = torch.tensor(g["out64"])
+    bar = TOL * max(1.0, ref.abs().max().item())
+    err = (out - ref).abs()
+    seam = sb.sl[1]["n0"]
+    print(f"full size {case} ({'f16x3' if mode else 'f32'}) through 2 slice handles: max |hip - ref64| = {err.max().item():.3e}; seam rows {seam - 1}, {seam}: "
+          f"{err[seam - 1].max().item():.3e}, {err[seam].max().item():.3e}; bar {bar:.1e}")
+    assert torch.isfinite(out).all() and err.max().item() <= bar
+    assert err.max().item() <= 20.0 * float(g["ref32_vs_ref64_maxabs"]) + 1e-6
+    one = _FULLSIZE_OUT.get((case, mode))
+    if one is not None:                                  # and against the one-handle forward of the same build (only the edge-tile boundaries move)
+        assert (out - one).abs().max().item() <= bar
+    ddpm.release_lanes()
+
+
+@pytest.mark.parametrize("case,B,n", [("qm9", 1024, 19), ("geom", 256, 44)])
+def test_full_size_captured_step_and_sliced_steps_equal_direct_single_handle(case, B, n):
+    """At the benchmark sizes (round 5 checked these at <= 40 molecules): (a) gcdm_sample_step served by the handle's captured hipGraph is BITWISE the direct-launch
+    step (device cursor table, every kernel of a step, 4 steps with on-device Philox noise); (b) the same 4 steps taken by the two slice handles of `_SlicedBatch`
+    (double-buffered latent, seam options, global Philox index) give the single-handle latent up to the edge-tile boundaries (1e-4 bar) -- the stepper bench.py times.
+    (variational_diffusion.py:1204-1278)"""
+    d = _dims(case)
+    net, W, cfgs = _net(case, seed=51, scale=0.25, mode=1)
+    ds = "geom" if case == "geom" else "qm9"
+    ddpm = pkg.EquivariantVariationalDiffusion(net, cfgs["diffusion_cfg"], cfgs["dataloader_cfg"], pkg.dataset_info(ds)).cuda()
+    dev = torch.device("cuda")
+    dyn, lib, h = ddpm._native(dev)
+    nn_ = torch.full((B,), n, dtype=torch.int32)
+    dyn.plan(nn_)
+    N, D = B * n, 3 + _ocfg(case).num_node_scalar_features
+    stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    fl = torch.zeros(1, dtype=torch.int32, device=dev)
+    seed = C.c_uint64(77)
+    steps = (999, 998, 997, 996)
+
+    def run(graph):
+        assert lib.gcdm_set_option(h, b"step_graph", graph) == 0
+        z = torch.empty((N, D), device=dev)
+        assert lib.gcdm_sample_init(h, C.c_void_p(z.data_ptr()), None, seed, stream) == 0
+        before = lib.gcdm_get_option(h, b"graph_launches")
+        for s in steps:
+            assert lib.gcdm_sample_step(h, C.c_void_p(z.data_ptr()), None, s, 1000, None, seed, C.c_void_p(fl.data_ptr()), stream) == 0, lib.gcdm_last_error(h)
+        torch.cuda.synchronize()
+        return z, lib.gcdm_get_option(h, b"graph_launches") - before
+
+    direct, n0 = run(0)
+    graphed, n1 = run(1)
+    assert n0 == 0 and n1 == len(steps)
+    assert torch.isfinite(direct).all() and torch.equal(direct, graphed) and int(fl.item()) == 0
+    sb = ddpm._SlicedBatch(ddpm, nn_, dev, None, 77, 2)
+    sb.init()
+    for s in steps:
+        sb.step(s, 1000)
+    sb.wait()
+    torch.cuda.synchronize()
+    zs = sb.bufs[sb.cur]
+    scale = max(1.0, direct.abs().max().item())
+    err = (zs - direct).abs().max().item()
+    print(f"{case} {B} x {n}: captured == direct bitwise over {len(steps)} steps; 2 slices vs one handle: max |dz| = {err:.3e} (bar {TOL * scale:.1e})")
+    assert err <= TOL * scale and int(sb.flags.max().item()) == 0
+    sb.close()
+    ddpm.release_lanes()
+
+
 @pytest.mark.parametrize("dataset,B,n", [("qm9", 1024, 19), ("geom", 256, 44)])
 def test_full_sample_at_benchmark_size(dataset, B, n):
     """BASELINE.json configs[1] / configs[3] END TO END: one complete 1000-step sample + decode (Philox noise, the default f16x3 matrix mode, the

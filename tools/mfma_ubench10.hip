@@ -49,7 +49,7 @@ struct WPool {                         // weight stream through buffer loads, sc
 };
 
 // tile GEMM: MT M-tiles x NT N-tiles, weights streamed with a ring of PD + 1 register sets, B operands one block ahead (the kernel's tile_gemm_x3s)
-template <int MT, int NT, int PER = 0, class Hook = void (*)(int)>
+template <int MT, int NT, int PER = 0, class Hook = void (*)(int), int MIDBAR = 0>
 __device__ __forceinline__ void gemm(f32x16 (&am)[MT][NT], f32x16 (&al)[MT][NT], const WPool& wp, uint32_t wH, uint32_t wL, const h8* xh, const h8* xl, int lane,
                                      Hook hook = [](int) {}) {
     constexpr int R = PD + 1;
@@ -64,6 +64,7 @@ __device__ __forceinline__ void gemm(f32x16 (&am)[MT][NT], f32x16 (&al)[MT][NT],
     for (int n = 0; n < NT; ++n) { bh[0][n] = xh[boff + 32 * n]; bl[0][n] = xl[boff + 32 * n]; }
 #pragma unroll
     for (int k = 0; k < KB; ++k) {
+        if (MIDBAR > 0 && k == MIDBAR) __syncthreads();          // schedule M: the workgroup barrier between the two halves of a GEMM
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
             ah[(k + PD) % R][m] = wp.ld(wH + (m * KB + (k + PD < KB ? k + PD : KB - 1)) * 1024);
@@ -295,6 +296,46 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             __syncthreads();
             finish<2>(p, st, wp, GW, YH, YL, PG, wave, lane, pre, neg, inv);
             __syncthreads();
+        } else if (VAR == 11 || VAR == 12) {
+            // M (round 6): M-TILE de-phasing of the two waves of a SIMD.  Every wave keeps the kernel's tile (its M-tile x both N-tiles: nothing is streamed twice), but
+            // waves 4-7 (the SIMD partners of waves 0-3) run half a GEMM behind: per GCP2 four slots separated by barriers,
+            //     waves 0-3:  GEMM k-blocks 0-7 | GEMM 8-17 | finish N-tile 0 | finish N-tile 1 |
+            //     waves 4-7:  finish N-tile 1'  | GEMM 0-7  | GEMM 8-17       | finish N-tile 0 |
+            // so that in two of the four slots one wave of every SIMD is in its GEMM while the other is in a VALU phase.  Data flow of the real layer chain: waves 0-3 contract
+            // first over the channels of M-tiles 0-3 (their own finish, complete one slot earlier), then over those of M-tiles 4-7 (complete when the first half ends).
+            // VAR 12: the same with `s_setprio 1` on whichever wave is in a VALU phase (the GEMM wave needs one issue slot in eight).
+            f32x16 am[1][2], al[1][2];
+            const bool lead = wave < 4;
+            auto fin_half = [&](int hf) {
+                f32x16 ph[1] = {p[hf]}, sh[1] = {st[hf]};
+                if (VAR == 12) __builtin_amdgcn_s_setprio(1);
+                finish<1>(ph, sh, wp, GW, YH, YL, PG, wave * 2 + hf, lane, pre, neg, inv);
+                if (VAR == 12) __builtin_amdgcn_s_setprio(0);
+                st[hf] = sh[0];
+            };
+            if (lead) {
+                gemm<1, 2, 0, void (*)(int), 8>(am, al, wp, wH + (uint32_t)wave * KB * 1024, wL + (uint32_t)wave * KB * 1024, xh, xl, lane);     // slots 0, 1 (barrier inside)
+#pragma unroll
+                for (int b = 0; b < 2; ++b)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) p[b][r] = am[0][b][r] + al[0][b][r] * inv;
+                __syncthreads();
+                fin_half(0);                            // slot 2
+                __syncthreads();
+                fin_half(1);                            // slot 3
+                __syncthreads();
+            } else {
+                fin_half(1);                            // slot 0: the previous GCP2's second half
+                __syncthreads();
+                gemm<1, 2, 0, void (*)(int), 8>(am, al, wp, wH + (uint32_t)wave * KB * 1024, wL + (uint32_t)wave * KB * 1024, xh, xl, lane);     // slots 1, 2
+#pragma unroll
+                for (int b = 0; b < 2; ++b)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) p[b][r] = am[0][b][r] + al[0][b][r] * inv;
+                __syncthreads();
+                fin_half(0);                            // slot 3
+                __syncthreads();
+            }
         } else if (VAR >= 5) {                          // F: the S loop with synthetic fillers of ONE kind (which kinds hide under the wave's own MFMAs?)
             FmaStage fm; TransStage tr; SplitStage sp;
             for (int i = 0; i < 12; ++i) { fm.x[i] = 0.001f * (lane + i); tr.x[i] = 0.01f * (lane + i); }
@@ -897,6 +938,15 @@ void run(const char* name, int blocks) {
 }
 
 int main(int argc, char** argv) {
+    if (argc > 1 && argv[1][0] == 'M') {       // round 6: M-tile de-phasing of the two waves of a SIMD (8 waves, the kernel's own tile per wave)
+        for (int rep = 0; rep < 2; ++rep) {
+            run<0>("L lockstep (8 waves GEMM, then finish)", 256);
+            run<11>("M de-phased by M-tile (waves 4-7 half a GEMM behind)", 256);
+            run<12>("M + s_setprio 1 in the VALU slots", 256);
+        }
+        run<11>("M, one workgroup", 1);
+        return 0;
+    }
     if (argc > 1 && argv[1][0] == 'Q') {       // round 6: schedule Q (quarter-sequential, weights held in registers)
         run<0>("L lockstep (8 waves GEMM, then finish)", 256);
         run_q<0, 0>("Q      quarter order alone, no finish work (GEMM floor)", 256);
