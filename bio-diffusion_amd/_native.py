@@ -22,6 +22,7 @@ OPS_HEADERS = [os.path.join(_HERE, "csrc", "gcdm_ops.hip.h"), os.path.join(os.pa
 ABI_VERSION = 2
 
 FLAG_NAN_VEL, FLAG_MEAN_NOT_ZERO, FLAG_COG_DRIFT, FLAG_F16_RANGE = 1, 2, 4, 8
+FLAG_TAIL = 16          # fused layer launch: placement check / bounded wait failed (raised together with FLAG_F16_RANGE: the fp32 re-run repairs the result)
 
 
 class GcdmConfig(C.Structure):

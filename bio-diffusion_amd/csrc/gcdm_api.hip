@@ -4,6 +4,10 @@
 #include "gcdm_edge_x3.hip.h"
 #include "gcdm_node_x3.hip.h"
 #include "gcdm_node_x3w.hip.h"
+#include "gcdm_layer_x3.hip.h"
+#ifndef GCDM_FUSE_TILE_DEFAULT
+#define GCDM_FUSE_TILE_DEFAULT 32
+#endif
 #include "gcdm_embed_x3.hip.h"
 #include "gcdm_stability.hip.h"
 #include "../../include/gcdm_hip.h"
@@ -71,6 +75,16 @@ struct gcdm_handle {
     size_t ws_floats = 0;
     float *X0 = nullptr, *XC = nullptr, *FBAR = nullptr, *CHI0 = nullptr, *HIN4 = nullptr, *H4 = nullptr, *CHI = nullptr, *PQ4 = nullptr,
           *VDI = nullptr, *VDJ = nullptr, *AGG = nullptr, *PART = nullptr, *VEL = nullptr, *EPS = nullptr, *TBUF = nullptr, *EP4 = nullptr, *AL = nullptr, *U = nullptr, *FR = nullptr, *PROF = nullptr, *ZK = nullptr, *ZU = nullptr, *ZROW = nullptr;
+    float *PQ4b = nullptr, *VDIb = nullptr, *VDJb = nullptr;   // second set of the node-level msg0 halves: layer l gathers set l & 1, its node tiles write set (l + 1) & 1 (round 6:
+                                                               // with the node tiles as a tail role of the edge workgroups both happen in ONE launch)
+    // Fused layer launch (gcdm_layer_x3.hip.h): tables of the node-tile queue for 32- and 64-node tiles ([0] / [1]); null when the plan does not qualify
+    int* d_tail_tab[2] = {nullptr, nullptr};       // qstart[9] | rel_node_end[8] | need[node tiles]
+    int* d_tail_ctr = nullptr;                     // ready[node tiles of 32] | qcur[17]  (zeroed at plan time, self-resetting)
+    int tail_tiles32 = 0;
+    int fuse_node = 1;               // option "fuse_node" / env GCDM_FUSE_NODE: 1 = the layer's node tiles run as a tail role of the persistent edge workgroups (one launch
+                                     // per layer) where the plan qualifies; 0 = two launches per layer (rounds 1-5)
+    int fuse_tile = 0;               // option "fuse_tile": nodes per node tile of the tail role (32 / 64; 0 = automatic)
+    int fuse_active = 0;             // option "fuse_active" (read-only): the last forward used the fused launch
     uint32_t* d_flags = nullptr;
     float* d_gmean = nullptr;
     int flat_prev = 0, flat_next = 0;   // the plan is a slice of a larger flat batch (options "flat_prev" / "flat_next"; include/gcdm_hip.h)
@@ -480,6 +494,9 @@ void free_plan(gcdm_handle* h) {
     if (h->d_rowstart) (void)hipFree(h->d_rowstart);
     if (h->d_mask) (void)hipFree(h->d_mask);
     h->d_mask = nullptr;
+    for (int i = 0; i < 2; ++i) { if (h->d_tail_tab[i]) (void)hipFree(h->d_tail_tab[i]); h->d_tail_tab[i] = nullptr; }
+    if (h->d_tail_ctr) (void)hipFree(h->d_tail_ctr);
+    h->d_tail_ctr = nullptr;
     if (h->ws) (void)hipFree(h->ws);
     h->d_noff = h->d_erow = h->d_ecol = h->d_ncnt = h->d_rowstart = nullptr;
     h->ws = nullptr;
@@ -529,6 +546,8 @@ int gcdm_create(const GcdmConfig* cfg, gcdm_handle** out) {
     if (const char* pe = getenv("GCDM_PERSISTENT")) h->persistent = atoi(pe) ? 1 : 0;
     if (const char* nt = getenv("GCDM_NODE_TILE")) h->node_tile = atoi(nt) == 32 ? 32 : atoi(nt) == 64 ? 64 : 0;
     if (const char* sg = getenv("GCDM_STEP_GRAPH")) h->step_graph = atoi(sg) ? 1 : 0;
+    if (const char* fz = getenv("GCDM_FUSE_NODE")) h->fuse_node = atoi(fz) ? 1 : 0;
+    if (const char* fz = getenv("GCDM_FUSE_TILE")) { const int v = atoi(fz); if (v == 32) h->fuse_tile = v; }
     DeviceGuard guard(cfg->device);
     {
         int n = 0;
@@ -826,6 +845,7 @@ static int finalize_pass(gcdm_handle* h, int k_shift) {
             set_lds_attr(h, k_edge_msg<64, 16, 32>, EdgeGeo<32>::LDS_BYTES) || set_lds_attr(h, k_edge_msg<16, 8, 32>, EdgeGeo<32>::LDS_BYTES) ||
             set_lds_attr(h, k_edge_msg_x3<64, 16, 64>, EdgeGeo<64>::LDS_BYTES_X3) || set_lds_attr(h, k_edge_msg_x3<16, 8, 64>, EdgeGeo<64>::LDS_BYTES_X3) ||
             set_lds_attr(h, k_edge_msg_x3<64, 16, 32>, EdgeGeo<32>::LDS_BYTES_X3) || set_lds_attr(h, k_edge_msg_x3<16, 8, 32>, EdgeGeo<32>::LDS_BYTES_X3) ||
+            set_lds_attr(h, k_edge_msg_x3<64, 16, 64, NodeTailRole<32>>, NodeTailRole<32>::LDS_BYTES) || set_lds_attr(h, k_edge_msg_x3<16, 8, 64, NodeTailRole<32>>, NodeTailRole<32>::LDS_BYTES) ||
             set_lds_attr(h, k_node_x3<true>, NK_LDS_BYTES) || set_lds_attr(h, k_node_x3<false>, NK_LDS_BYTES) || set_lds_attr(h, k_node_x3w, NW_LDS_BYTES) ||
             set_lds_attr(h, k_node<true>, NK_LDS_BYTES) || set_lds_attr(h, k_node<false>, NK_LDS_BYTES) ||
             set_lds_attr(h, k_node_x3<true, 4>, NK_LDS_BYTES) || set_lds_attr(h, k_node<true, 4>, NK_LDS_BYTES))
@@ -931,7 +951,8 @@ int gcdm_plan_batch_masked(gcdm_handle* h, int32_t B, const int32_t* nn, const u
                  oAGG = take(GCDM_AGGW * n), oPART = take(((e + 31) / 32) * 2 * GCDM_AGGW), oVEL = take(3 * n), oEPS = take((size_t)h->D * n), oT = take(n), oEP = take((size_t)h->Se * e),
                  oAL = take((size_t)h->Ve * e), oU = take(3 * e), oFR = take(9 * e), oPROF = take(((e + 31) / 32) * 192),
                  oX0SC = take(h->sc ? 3 * n : 0), oBL = take(h->sc ? (size_t)h->Ve * e : 0), oUSC = take(h->sc ? 3 * e : 0),
-                 oZK = take((size_t)h->D * n), oZU = take((size_t)h->D * n), oZROW = take(GCDM_AGGW);
+                 oZK = take((size_t)h->D * n), oZU = take((size_t)h->D * n), oZROW = take(GCDM_AGGW),
+                 oPQb = take(512 * n), oVDIb = take((size_t)(h->H0 + 3) * 3 * n), oVDJb = take((size_t)(h->H0 + 3) * 3 * n);
     h->ws_floats = off;
     if (off * sizeof(float) >= ((size_t)1 << 32)) return fail(h, "gcdm_plan_batch: workspace exceeds 4 GB (buffer-addressed); split the batch");
     HIP_OK(h, hipMalloc(&h->ws, off * sizeof(float)));
@@ -941,8 +962,49 @@ int gcdm_plan_batch_masked(gcdm_handle* h, int32_t B, const int32_t* nn, const u
     h->PQ4 = w + oPQ; h->VDI = w + oVDI; h->VDJ = w + oVDJ; h->AGG = w + oAGG; h->PART = w + oPART; h->VEL = w + oVEL; h->EPS = w + oEPS; h->TBUF = w + oT; h->EP4 = w + oEP;
     h->AL = w + oAL; h->U = w + oU; h->FR = w + oFR; h->PROF = w + oPROF;
     h->ZK = w + oZK; h->ZU = w + oZU; h->ZROW = w + oZROW;     // ZROW is never written: the workspace starts zeroed
+    h->PQ4b = w + oPQb; h->VDIb = w + oVDIb; h->VDJb = w + oVDJb;
     h->X0SC = h->sc ? w + oX0SC : nullptr; h->BL = h->sc ? w + oBL : nullptr; h->USC = h->sc ? w + oUSC : nullptr;
     h->B = B; h->N = N; h->E = E; h->max_n = max_n;
+    // ---- node-tile queues of the fused layer launch (gcdm_layer_x3.hip.h): 64-edge tiles, XCD x owns the x-th contiguous eighth of the tile list (the partition of
+    // k_edge_msg_x3's persistent loop); node tile t (T nodes) waits for the edge tiles first_tile(t) .. last_tile(t) of its rows and is owned by the XCD whose range
+    // contains first_tile(t).  Built for T = 32 and T = 64; a plan qualifies when nothing is masked, the launch is persistent and no node tile spans three XCDs.
+    h->tail_tiles32 = 0;
+    const int wgs_ = h->cus / 8 * 8;
+    if (!node_mask && E > (int64_t)64 * wgs_ && wgs_ >= 8) {
+        const int G = (int)((E + 63) / 64), base = G >> 3, rem = G & 7;
+        int xs[9];
+        for (int x = 0; x <= 8; ++x) xs[x] = x * base + std::min(x, rem);
+        auto xcd_of_tile = [&](int g) { int x = 0; while (x < 7 && g >= xs[x + 1]) ++x; return x; };
+        for (int which = 0; which < 1; ++which) {          // (T = 32; the builder is generic in T)
+            const int T = which ? 64 : 32, NTt = (N + T - 1) / T;
+            std::vector<int> tab(64 + (size_t)NTt, 0);
+            std::vector<std::vector<std::pair<int, int>>> owned(8);          // per XCD: (edge tile the node item stands behind, node tile)
+            bool ok = true;
+            for (int t = 0; t < NTt && ok; ++t) {
+                const int nf = t * T, nl = std::min(nf + T, N) - 1;
+                const int ft = rowstart[nf] >> 6, lt = (rowstart[nl] + ncnt[nl] - 1) >> 6;
+                const int owner = xcd_of_tile(ft), xl = xcd_of_tile(lt);
+                if (xl > owner + 1 || lt - ft + 1 > 0xffff) ok = false;
+                tab[64 + t] = (lt - ft + 1) | ((xl != owner ? 1 : 0) << 16);
+                owned[owner].push_back({lt, t});
+            }
+            for (int x = 0; x < 8 && ok; ++x) {
+                tab[8 * x] = owned[x].empty() ? 0 : owned[x][0].second;
+                tab[8 * x + 1] = (int)owned[x].size();
+                tab[8 * x + 2] = xs[x + 1] - xs[x] + (int)owned[x].size();
+                if (x >= 1) {                                                // rows of XCD x's first tiles that belong to the boundary node tile owned by XCD x - 1
+                    const int tb = erow[(size_t)xs[x] * 64] / T;
+                    if ((rowstart[tb * T] >> 6) < xs[x]) tab[8 * x + 3] = std::min((tb + 1) * T, N);
+                }
+            }
+            if (!ok) continue;
+            HIP_OK(h, hipMalloc(&h->d_tail_tab[which], tab.size() * sizeof(int)));
+            HIP_OK(h, hipMemcpy(h->d_tail_tab[which], tab.data(), tab.size() * sizeof(int), hipMemcpyHostToDevice));
+        }
+        h->tail_tiles32 = (N + 31) / 32;
+        HIP_OK(h, hipMalloc(&h->d_tail_ctr, ((size_t)h->tail_tiles32 + TAIL_CTR_WORDS) * sizeof(int)));
+        HIP_OK(h, hipMemset(h->d_tail_ctr, 0, ((size_t)h->tail_tiles32 + TAIL_CTR_WORDS) * sizeof(int)));
+    }
     return 0;
 }
 
@@ -1004,6 +1066,7 @@ int gcdm_forward_sc(gcdm_handle* h, const float* xh, const float* xh_sc, const f
     const int N = h->N, B = h->B;
     const int E = (int)h->E;
     HIP_OK(h, hipMemsetAsync(h->d_flags, 0, sizeof(uint32_t), st));
+    h->fuse_active = 0;
     PrepArgs pa{xh, t, context, h->d_noff, N, h->F, h->C, h->FinG, h->X0, h->XC, h->FBAR, h->CHI0, (v4f*)h->HIN4, h->flat_prev, h->flat_next,
                 h->sc, xh_sc, h->X0SC, h->d_mask};
     hipLaunchKernelGGL(k_prep, dim3(B), dim3(64), 3 * h->max_n * sizeof(float), st, pa);
@@ -1027,7 +1090,7 @@ int gcdm_forward_sc(gcdm_handle* h, const float* xh, const float* xh_sc, const f
     na.N = N; na.F = h->F; na.C = h->C; na.FinG = h->FinG; na.Dout = h->D; na.pos_weight = h->cfg.node_positions_weight;
     na.HIN4 = (const v4f*)h->HIN4; na.CHI0 = h->CHI0; na.emb = h->emb;
     na.agg = AggSrc{h->AGG, h->PART, h->d_rowstart, h->d_ncnt, 0, h->ZROW}; na.H4 = (v4f*)h->H4; na.CHI = h->CHI; na.XC = h->XC; na.X0 = h->X0; na.FBAR = h->FBAR;
-    na.PQ4 = (v4f*)h->PQ4; na.VDI = h->VDI; na.VDJ = h->VDJ; na.H0 = h->H0;
+    na.PQ4 = (v4f*)h->PQ4; na.VDI = h->VDI; na.VDJ = h->VDJ; na.H0 = h->H0;          // (the embedding writes set 0: layer 0 gathers set 0)
     na.proj = h->proj; na.OUT = out; na.VEL = h->VEL; na.flags_dev = h->d_flags; na.mask = h->d_mask;
     auto set_next = [&](int l) {
         if (l < h->L) {
@@ -1041,18 +1104,22 @@ int gcdm_forward_sc(gcdm_handle* h, const float* xh, const float* xh_sc, const f
     NodeX3Args nx{};
     nx.x3c = h->x3c();
     bool node_kb_ok = true;
+    auto prep_node_x3 = [&](int next_layer, const LayerDev* cur) {          // fills nx from na for the split-precision node kernels
+        nx.base = na;
+        nx.emb = h->embx; nx.proj = h->projx;
+        if (cur) { nx.ff = cur->ffx; nx.pos = cur->posx; }
+        if ((cur && (nx.ff.KB != 34 || nx.pos.KB != 18)) || nx.proj.KB != 19) {     // compile-time k-block counts of k_node_x3
+            (void)fail(h, "internal: node k-block counts differ from the kernel's compile-time constants");
+            node_kb_ok = false;
+            return false;
+        }
+        nx.prof = (h->profile_node && cur && next_layer < h->L) ? h->PROF : nullptr;
+        if (next_layer < h->L) { nx.wpqH = h->layers[next_layer].wpqH; nx.wpqL = h->layers[next_layer].wpqL; nx.vdH = h->layers[next_layer].vdH; nx.vdL = h->layers[next_layer].vdL; nx.bpqx = h->layers[next_layer].bpqx; }
+        return true;
+    };
     auto launch_node = [&](bool embed, int next_layer, const LayerDev* cur) {
         if (h->use_x3()) {
-            nx.base = na;
-            nx.emb = h->embx; nx.proj = h->projx;
-            if (cur) { nx.ff = cur->ffx; nx.pos = cur->posx; }
-            if ((cur && (nx.ff.KB != 34 || nx.pos.KB != 18)) || nx.proj.KB != 19) {     // compile-time k-block counts of k_node_x3
-                (void)fail(h, "internal: node k-block counts differ from the kernel's compile-time constants");
-                node_kb_ok = false;
-                return;
-            }
-            nx.prof = (h->profile_node && cur && next_layer < h->L) ? h->PROF : nullptr;
-            if (next_layer < h->L) { nx.wpqH = h->layers[next_layer].wpqH; nx.wpqL = h->layers[next_layer].wpqL; nx.vdH = h->layers[next_layer].vdH; nx.vdL = h->layers[next_layer].vdL; nx.bpqx = h->layers[next_layer].bpqx; }
+            if (!prep_node_x3(next_layer, cur)) return;
             if (embed && h->sc) hipLaunchKernelGGL((k_node_x3<true, 4>), dim3(ngrid), dim3(NX_THREADS), NK_LDS_BYTES, st, nx);
             else if (embed) hipLaunchKernelGGL(k_node_x3<true>, dim3(ngrid), dim3(NX_THREADS), NK_LDS_BYTES, st, nx);
             else if (node_tile_for(h, N) == 64) hipLaunchKernelGGL(k_node_x3w, dim3((N + NW_T - 1) / NW_T), dim3(512), NW_LDS_BYTES, st, nx);
@@ -1074,7 +1141,10 @@ int gcdm_forward_sc(gcdm_handle* h, const float* xh, const float* xh_sc, const f
         EdgeMsgArgs ma{};
         ma.EP4 = (const v4f*)h->EP4; ma.AL = h->AL; ma.U = h->U; ma.FR = h->FR; ma.EROW = h->d_erow; ma.ECOL = h->d_ecol; ma.NCNT = h->d_ncnt;
         ma.BL = h->BL; ma.USC = h->USC;
-        ma.E = E; ma.N = N; ma.PQ4 = (const v4f*)h->PQ4; ma.VDI = h->VDI; ma.VDJ = h->VDJ; ma.AGG = h->AGG; ma.PART = h->PART;
+        // node-level msg0 halves: layer l gathers set l & 1, its node tiles write set (l + 1) & 1 for layer l + 1
+        const bool odd = (l & 1) != 0;
+        ma.E = E; ma.N = N; ma.PQ4 = (const v4f*)(odd ? h->PQ4b : h->PQ4); ma.VDI = odd ? h->VDIb : h->VDI; ma.VDJ = odd ? h->VDJb : h->VDJ; ma.AGG = h->AGG; ma.PART = h->PART;
+        na.PQ4 = (v4f*)(odd ? h->PQ4 : h->PQ4b); na.VDI = odd ? h->VDI : h->VDIb; na.VDJ = odd ? h->VDJ : h->VDJb;
         ma.w0 = d.w0; ma.G0 = d.G0; ma.wddE = d.wddE; ma.wg0 = d.wg0; ma.bg0 = d.bg0; ma.wup0 = d.wup0;
         for (int k = 0; k < 3; ++k) ma.mk[k] = d.mk[k];
         ma.wa = d.wa; ma.ba = d.ba;
@@ -1097,13 +1167,41 @@ int gcdm_forward_sc(gcdm_handle* h, const float* xh, const float* xh_sc, const f
             // persistent workgroups: as many as fit the chip at once (one per CU with 64-edge tiles, two with 32), a multiple of 8 so that every
             // XCD gets the same number; fewer tiles than that -> one tile per workgroup, as before
             int wgs = h->cus * (ET == 64 ? 1 : 2) / 8 * 8;
-            if (h->persistent == 0 || tiles <= wgs || wgs < 8) { wgs = tiles; xa.wg_stride = tiles; } else xa.wg_stride = wgs / 8;
+            bool persistent = true;
+            if (h->persistent == 0 || tiles <= wgs || wgs < 8) { wgs = tiles; xa.wg_stride = tiles; persistent = false; } else xa.wg_stride = wgs / 8;
+            // one launch per layer: the node tiles as a tail role of the persistent workgroups (gcdm_layer_x3.hip.h) where the plan qualifies
+            int ft = 0;
+            if (ET == 64 && persistent && h->fuse_node && !h->profile_node && !h->d_mask && h->d_tail_ctr) {
+                // nodes per node tile of the tail role: 32.  (64-node tiles -- node_tile_x3w -- were built and measured too: QM9 6.85 against 6.94 ms per step on one box,
+                // 7.30 against 7.24 on another, GEOM 3.81 against 3.75; their node code keeps one SGPR spilled, which costs the edge role a VGPR: not instantiated)
+                ft = h->d_tail_tab[0] ? 32 : 0;
+            }
+            h->fuse_active = ft != 0;
+            if (ft) {
+                na.ff = d.ff; na.pos = d.pos;
+                set_next(l + 1);
+                if (!prep_node_x3(l + 1, &d)) return -1;
+                TailArgs ta{};
+                ta.nx = nx; ta.ready = h->d_tail_ctr; ta.qcur = h->d_tail_ctr + h->tail_tiles32; ta.tab = h->d_tail_tab[ft == 64 ? 1 : 0];
+                ta.num_wgs = wgs;
+                {
+                    NodeTailRole<32>::Args la{xa, ta};
+                    if (h->Se == 64) hipLaunchKernelGGL((k_edge_msg_x3<64, 16, 64, NodeTailRole<32>>), dim3(wgs), dim3(512), NodeTailRole<32>::LDS_BYTES, st, la);
+                    else hipLaunchKernelGGL((k_edge_msg_x3<16, 8, 64, NodeTailRole<32>>), dim3(wgs), dim3(512), NodeTailRole<32>::LDS_BYTES, st, la);
+                }
+                if (h->profile) {
+                    HIP_OK(h, hipEventRecord(h->ev[2 * l + 1], st)); h->ev_used = l + 1;
+                    HIP_OK(h, hipEventRecord(h->ev[2 * (size_t)h->L + l], st));
+                }
+                continue;
+            }
+            NoTailRole::Args la{xa};
             if (ET == 64) {
-                if (h->Se == 64) hipLaunchKernelGGL((k_edge_msg_x3<64, 16, 64>), dim3(wgs), dim3(512), EdgeGeo<64>::LDS_BYTES_X3, st, xa);
-                else hipLaunchKernelGGL((k_edge_msg_x3<16, 8, 64>), dim3(wgs), dim3(512), EdgeGeo<64>::LDS_BYTES_X3, st, xa);
+                if (h->Se == 64) hipLaunchKernelGGL((k_edge_msg_x3<64, 16, 64>), dim3(wgs), dim3(512), EdgeGeo<64>::LDS_BYTES_X3, st, la);
+                else hipLaunchKernelGGL((k_edge_msg_x3<16, 8, 64>), dim3(wgs), dim3(512), EdgeGeo<64>::LDS_BYTES_X3, st, la);
             } else {
-                if (h->Se == 64) hipLaunchKernelGGL((k_edge_msg_x3<64, 16, 32>), dim3(wgs), dim3(256), EdgeGeo<32>::LDS_BYTES_X3, st, xa);
-                else hipLaunchKernelGGL((k_edge_msg_x3<16, 8, 32>), dim3(wgs), dim3(256), EdgeGeo<32>::LDS_BYTES_X3, st, xa);
+                if (h->Se == 64) hipLaunchKernelGGL((k_edge_msg_x3<64, 16, 32>), dim3(wgs), dim3(256), EdgeGeo<32>::LDS_BYTES_X3, st, la);
+                else hipLaunchKernelGGL((k_edge_msg_x3<16, 8, 32>), dim3(wgs), dim3(256), EdgeGeo<32>::LDS_BYTES_X3, st, la);
             }
         } else if (ET == 64) {
             if (h->Se == 64) hipLaunchKernelGGL((k_edge_msg<64, 16, 64>), dim3(tiles), dim3(EdgeGeo<64>::THREADS), EdgeGeo<64>::LDS_BYTES, st, ma);
@@ -1423,6 +1521,8 @@ int gcdm_set_option(gcdm_handle* h, const char* name, int32_t value) {
     if (k == "flat_next") { h->flat_next = value ? 1 : 0; return 0; }
     if (k == "node_base") { if (value < 0) return fail(h, "gcdm_set_option(node_base): >= 0"); h->node_base = (uint32_t)value; return 0; }
     if (k == "persistent") { h->persistent = value ? 1 : 0; return 0; }
+    if (k == "fuse_node") { h->fuse_node = value ? 1 : 0; return 0; }
+    if (k == "fuse_tile") { if (value != 0 && value != 32) return fail(h, "gcdm_set_option(fuse_tile): 0 or 32"); h->fuse_tile = value; return 0; }
     if (k == "node_tile") {
         if (value != 0 && value != 32 && value != 64) return fail(h, "gcdm_set_option: node_tile must be 0 (automatic), 32 or 64");
         h->node_tile = value;
@@ -1448,6 +1548,9 @@ int gcdm_get_option(const gcdm_handle* h, const char* name) {
     if (k == "node_base") return (int)h->node_base;
     if (k == "x3_shift") return h->x3_shift;
     if (k == "persistent") return h->persistent;
+    if (k == "fuse_node") return h->fuse_node;
+    if (k == "fuse_active") return h->fuse_active;
+    if (k == "fuse_tile") return h->fuse_tile;
     if (k == "node_tile") return h->node_tile;
     if (k == "step_graph") return (h->step_graph && !h->step_graph_failed) ? 1 : 0;
     if (k == "graph_launches") return (int)(h->graph_launches & 0x7fffffff);

@@ -1062,9 +1062,26 @@ struct EdgeMsgX3Args {
 //          unit vectors (round 5) are staged in LDS its footprint is 83 260 B, 1.3 KB more than half of the CU's 160 KB: the launch's 2 x CUs workgroups run
 //          in two rounds of ONE per CU (QM9: 0.89 ms per launch against 0.72 ms with 64-edge tiles).  Kept as an option (edge_tile = 32) for A/B runs and
 //          for the determinism tests, which cover both tile sizes; not a production configuration.
-template <int SE, int VE, int ET>
-__global__ __launch_bounds__(ET * 8) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_edge_msg_x3(EdgeMsgX3Args ax0) {
+// TAIL ROLE (round 6).  `TR` is a policy: NoTailRole (below) = the kernel as it was; NodeTailRole (gcdm_layer_x3.hip.h) = the layer's NODE tiles run as a tail
+// role of the same persistent workgroups: a workgroup that has walked its (statically scheduled) edge tiles takes node tiles from its XCD's queue, each gated by
+// a readiness counter that the edge tiles covering the node tile's rows bump when their AGG / PART rows are in the L2.  The hooks the policy provides (static):
+//     TR::Args            kernel-argument struct whose FIRST member `e` is the EdgeMsgX3Args (X3_KARG and the opaque kernel-argument copy rely on offset 0)
+//     TR::arrived(...)    kernel start, one thread
+//     TR::published(...)  behind the first barrier of the NEXT tile (every wave has waited for its stores): the previous tile's rows are visible -> bump
+//     TR::tail(...)       behind the persistent loop: publish the last tile, then the node role
+// The hooks inside the tile loop are deliberately minimal (three scalars carried, one thread's atomics per tile: +1.3 % cycles per tile).  A unified, dynamically
+// scheduled work queue of edge AND node items was built and measured in round 6 (docs/r06_dynamic_queue/): any code that puts a second 250-register body or a stack
+// into this function costs the GEMM phases their schedule (the scheduler reverts regions whose pressure exceeds the budget once a register is reserved for spills):
+// +11 % cycles per edge tile, more than the balance returns.
+struct NoTailRole {
+    static constexpr bool ON = false;
+    struct Args { EdgeMsgX3Args e; };
+};
+
+template <int SE, int VE, int ET, class TR = NoTailRole>
+__global__ __launch_bounds__(ET * 8) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_edge_msg_x3(typename TR::Args lx) {
     constexpr int NW = ET / 8, MT = 8 / NW, NT = ET / 32;     // waves, M-tiles and N-tiles per wave
+    const EdgeMsgX3Args& ax0 = lx.e;
     const EdgeMsgArgs& a0 = ax0.base;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     using Geo = EdgeGeo<ET>;
@@ -1260,6 +1277,10 @@ __global__ __launch_bounds__(ET * 8) __attribute__((amdgpu_waves_per_eu(2, 2))) 
     };
     v4f* WAX4 = (v4f*)(smem + Geo::OFF_WAX);
     if (w0.tid < GCDM_SG) WAX4[w0.tid] = *(const v4f*)(ax0.wax + 4 * w0.tid);       // visible after the first tile's barriers
+    [[maybe_unused]] int tail_prev_first = 0, tail_prev_last = 0;      // row nodes of the tile whose publication is pending (TR::ON)
+    [[maybe_unused]] bool tail_have_prev = false;
+    [[maybe_unused]] int tail_rel_end = 0;                              // rows below this node are (also) consumed on the previous XCD: released (NodeTailRole)
+    if constexpr (TR::ON) { if (w0.tid == 0) TR::arrived(lx, smem, xcd_); tail_rel_end = TR::rel_node_end(lx, xcd_); }
     TileIdx ix = load_idx(a0, w0, start_ + it_);
     TileIn in;
     load_const(std::integral_constant<int, -1>{}, a0, w0, start_ + it_, in);
@@ -1459,7 +1480,16 @@ __global__ __launch_bounds__(ET * 8) __attribute__((amdgpu_waves_per_eu(2, 2))) 
     }
 #endif
     STAMP(1);
+    if constexpr (TR::ON) x3_wait_block<0>();      // every store of the PREVIOUS tile's segment sums has been acknowledged by the L2 (the loads still in flight -- msg0's
+                                                   // first weight blocks, the PQ rows -- are consumed right behind the barrier anyway)
     __syncthreads();
+    if constexpr (TR::ON) {
+        if (tail_have_prev && tid == 0) TR::published(lx, tail_prev_first, tail_prev_last, tail_rel_end);
+        // this tile's first / last row (uniform: lane e of every wave holds edge e0 + e, clamped to the last edge) for the publication one tile later
+        tail_prev_first = __builtin_amdgcn_readlane(ni, 0);
+        tail_prev_last = __builtin_amdgcn_readlane(ni, 63);
+        tail_have_prev = true;
+    }
     STAMP(2);
 
     const int half = lane >> 5, l31 = lane & 31;
@@ -1538,6 +1568,7 @@ __global__ __launch_bounds__(ET * 8) __attribute__((amdgpu_waves_per_eu(2, 2))) 
 
     // ---- residual message GCP2s k = 1..3; the vector part of the previous GCP2 rides in the shadow of each GEMM ------------------
     constexpr int GPP = GCDM_SG / PARTS;                 // attention: float4 groups of the message scalars per thread
+    int nxt_tile = start_ + it_;                         // the tile whose operands are requested from the last GCP2 on (set there)
     static_for<0, 3>([&](auto kc) {
         constexpr int k = decltype(kc)::value;
         const GcpW& w = a.mk[k];
@@ -1592,9 +1623,9 @@ __global__ __launch_bounds__(ET * 8) __attribute__((amdgpu_waves_per_eu(2, 2))) 
         }
 #endif
         if (k == 2) {
-            const int nxt = start_ + min(it_ + stride_, cnt_ - 1);
-            ix = load_idx(a, me, nxt);
-            load_const(std::integral_constant<int, 0>{}, a, me, nxt, in);      // (in three bursts with the fold / the residual add between them)
+            nxt_tile = start_ + min(it_ + stride_, cnt_ - 1);
+            ix = load_idx(a, me, nxt_tile);
+            load_const(std::integral_constant<int, 0>{}, a, me, nxt_tile, in);      // (in three bursts with the fold / the residual add between them)
         }
 #ifdef GCDM_ABL_GATE_NOPG
         asm volatile("" ::"v"(gm[0]), "v"(gl[0]));
@@ -1612,7 +1643,7 @@ __global__ __launch_bounds__(ET * 8) __attribute__((amdgpu_waves_per_eu(2, 2))) 
         if (k == GCDM_STAMP_K) STAMP(14);
         // 4 waves: every wave is done reading the old images; gate partials complete.  8 waves: the barrier inside the fold said the first, and
         // the partials are complete at the barrier behind the state images (last GCP2: behind the attention partials)
-        if (k == 2) load_const(std::integral_constant<int, 1>{}, a, me, start_ + min(it_ + stride_, cnt_ - 1), in);
+        if (k == 2) load_const(std::integral_constant<int, 1>{}, a, me, nxt_tile, in);
         if (NW == 4) __syncthreads();
         if (k == GCDM_STAMP_K) STAMP(15);
 #pragma unroll
@@ -1624,7 +1655,7 @@ __global__ __launch_bounds__(ET * 8) __attribute__((amdgpu_waves_per_eu(2, 2))) 
                     const f32x2 s2 = pk_add((f32x2){st[m][n][r], st[m][n][r + 1]}, (f32x2){am[m][n][r], am[m][n][r + 1]});
                     st[m][n][r] = s2[0]; st[m][n][r + 1] = s2[1];
                 }
-        if (k == 2) load_const(std::integral_constant<int, 2>{}, a, me, start_ + min(it_ + stride_, cnt_ - 1), in);
+        if (k == 2) load_const(std::integral_constant<int, 2>{}, a, me, nxt_tile, in);
         if (k < 2) {
 #ifndef GCDM_ABL_NOSTORE
             store_state_x3<MT, NT>(XH, XL, 0, st, ETP, mt0, lane, amax);
@@ -1759,5 +1790,11 @@ __global__ __launch_bounds__(ET * 8) __attribute__((amdgpu_waves_per_eu(2, 2))) 
     it_ += stride_;
     if (it_ >= cnt_) break;
     // (no barrier here: the one inside the next tile's pre-phase says that every wave is done with this tile's LDS)
+    }
+    if constexpr (TR::ON) {
+        static_assert(ET == 64, "tail role: 64-edge tiles (one workgroup per CU)");
+        x3_wait_block<0>();
+        __syncthreads();                           // every wave's stores of the last tile are in the L2; LDS is free
+        TR::tail(lx, smem, tail_have_prev, tail_prev_first, tail_prev_last, tail_rel_end);      // (takes the thread index and the workgroup's XCD group afresh: nothing is carried across the loop for it)
     }
 }

@@ -28,7 +28,7 @@ struct NodeX3Args {
 #ifdef GCDM_STAMPS          // (see STAMP in gcdm_kernels.hip.h)
 #define NSTAMP(i)                                                                                       \
     do {                                                                                                \
-        if (ax.prof && lane == 0) ax.prof[((size_t)blockIdx.x * 8 + wave) * 24 + (i)] = (float)(__builtin_amdgcn_s_memtime() - t_start); \
+        if (ax.prof && lane == 0) ax.prof[((size_t)tile_index * 8 + wave) * 24 + (i)] = (float)(__builtin_amdgcn_s_memtime() - t_start); \
     } while (0)
 #else
 #define NSTAMP(i) ((void)0)
@@ -225,10 +225,11 @@ constexpr int NX_GROUPS8 = 70;
 constexpr int NX_THREADS = 512;
 static_assert(2 * NX_GROUPS8 * NTP * 16 == NK_XS_GROUPS * NTP * 16, "XH8/XL8 must exactly fill the fp32 XS4 region of k_node");
 
+// One 32-node tile of the node kernel.  A device function since round 6: the stand-alone kernel k_node_x3 calls it with tile = blockIdx.x, the fused layer
+// kernel (k_edge_msg_x3<..., TAIL = true>, gcdm_edge_x3.hip.h) calls it from the TAIL ROLE of its persistent workgroups with tiles taken from a queue.
 template <bool EMBED, int VIN0 = 2>
-__global__ __launch_bounds__(NX_THREADS) void k_node_x3(NodeX3Args ax) {
+__device__ __forceinline__ void node_tile_x3(const NodeX3Args& ax, char* smem, const int tile_index, const int tid_in) {
     const NodeArgs& a = ax.base;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
     char* XH = smem + NK_OFF_XS;
     char* XL = XH + NX_GROUPS8 * NTP * 16;
     float* VV = (float*)(smem + NK_OFF_VV);
@@ -237,13 +238,13 @@ __global__ __launch_bounds__(NX_THREADS) void k_node_x3(NodeX3Args ax) {
     float* FR = (float*)(smem + NK_OFF_FR);
     float* XP = (float*)(smem + NK_OFF_XP);
 
-    const int tid = threadIdx.x, lane = tid & 63;
+    const int tid = tid_in, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int e = tid & 31, part = tid >> 5;       // 16 threads share an entity in the VALU phases
     constexpr int PARTS = NX_THREADS / NT_;
     const int half = lane >> 5, l31 = lane & 31;
     const int N = a.N;
-    const int n0 = blockIdx.x * NT_;
+    const int n0 = tile_index * NT_;
     const int nid = min(n0 + e, N - 1);
     const bool valid = (n0 + e) < N;
     const int nidl = min(n0 + l31, N - 1);           // node of this lane in the MFMA (C-layout) phases
@@ -586,4 +587,10 @@ __global__ __launch_bounds__(NX_THREADS) void k_node_x3(NodeX3Args ax) {
     NSTAMP(17);
     over |= amax > X3_RANGE;
     if (__any(over) && lane == 0) atomicOr(a.flags_dev, GCDM_FLAG_F16_RANGE_BIT);
+}
+
+template <bool EMBED, int VIN0 = 2>
+__global__ __launch_bounds__(NX_THREADS) void k_node_x3(NodeX3Args ax) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    node_tile_x3<EMBED, VIN0>(ax, smem, blockIdx.x, threadIdx.x);
 }

@@ -117,9 +117,9 @@ __device__ __forceinline__ void nw_vecmat_unit(const VecMatW<MT, KB>& w, const f
         for (int i = 0; i < 4; ++i) store(16 * m + 4 * q + i, x, 16 * g + n, am[m][i] + al[m][i] * X3_INV_SCALE);
 }
 
-__global__ __launch_bounds__(512) void k_node_x3w(NodeX3Args ax) {
+// (a device function since round 6, like node_tile_x3: the fused layer kernel's tail role runs 64-node tiles through it)
+__device__ __forceinline__ void node_tile_x3w(const NodeX3Args& ax, char* smem, const int tile_index, const int tid_in) {
     const NodeArgs& a = ax.base;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
     char* XH = smem + NW_OFF_XH;
     char* XL = smem + NW_OFF_XL;
     float* VV = (float*)(smem + NW_OFF_VV);
@@ -130,12 +130,12 @@ __global__ __launch_bounds__(512) void k_node_x3w(NodeX3Args ax) {
     constexpr int TP = NW_TP, PARTS = 8, CB = 32;      // CB: channel base of chi inside VV
     constexpr int PD = 2;
 
-    const int tid = threadIdx.x, lane = tid & 63;
+    const int tid = tid_in, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int e = lane, part = wave;                   // VALU phases: lane = node of the tile, 8 threads (one per wave) share a node
     const int half = lane >> 5, l31 = lane & 31;
     const int N = a.N;
-    const int n0 = blockIdx.x * NW_T;
+    const int n0 = tile_index * NW_T;
     const int nid = min(n0 + e, N - 1);
     const bool valid = (n0 + e) < N;
     bool over = false;
@@ -461,4 +461,9 @@ __global__ __launch_bounds__(512) void k_node_x3w(NodeX3Args ax) {
     NSTAMP(17);
     over |= amax > X3_RANGE;
     if (__any(over) && lane == 0) atomicOr(a.flags_dev, GCDM_FLAG_F16_RANGE_BIT);
+}
+
+__global__ __launch_bounds__(512) void k_node_x3w(NodeX3Args ax) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    node_tile_x3w(ax, smem, blockIdx.x, threadIdx.x);
 }

@@ -339,6 +339,8 @@ class GCPNetDynamics(nn.Module):
         self._flags_event.synchronize()
         self._flags_pending = False
         v = int(self._flags_host.item())
+        if v & _native.FLAG_TAIL:
+            self.disable_fused_layer("an earlier forward call")
         if v & _native.FLAG_F16_RANGE:
             self._flags.zero_()
             self.set_mfma_mode(0)
@@ -389,10 +391,21 @@ class GCPNetDynamics(nn.Module):
         return out
 
     # ------------------------------------------------------------------------------------------
+    def disable_fused_layer(self, where: str) -> None:
+        """GCDM_FLAG_TAIL was raised (fused layer launch: the workgroup-placement check or a bounded dependency wait failed -- never observed): from now on two
+        launches per layer on this handle.  The flag comes together with GCDM_FLAG_F16_RANGE, so the caller's fp32 re-run has already repaired / will repair the result."""
+        import warnings
+        if self._handle is not None and self._lib.gcdm_get_option(self._handle, b"fuse_node") != 0:
+            self._lib.gcdm_set_option(self._handle, b"fuse_node", 0)
+            warnings.warn(f"bio-diffusion_amd: the fused layer launch reported GCDM_FLAG_TAIL in {where}; the handle now uses two launches per layer "
+                          "(option fuse_node = 0) and the affected call is re-run", RuntimeWarning)
+
     def read_flags(self, reset: bool = True) -> int:
         """Device-side check word (host sync): bit 0 NaN in vel, bit 2 CoG drift re-projected."""
         self._flags_pending = False
         v = int(self._flags.item()) if self._flags is not None else 0
+        if v & _native.FLAG_TAIL:
+            self.disable_fused_layer("a forward call")
         if reset and self._flags is not None:
             self._flags.zero_()
         return v

@@ -176,6 +176,7 @@ class _RangeCheckpoints:
         self.good = None             # (state, tensors) verified clean
         self.pend = None             # (state, tensors, event, host flag) waiting for its flag copy
         self.rewinds = 0
+        self.tail_flag = False       # GCDM_FLAG_TAIL seen (comes together with GCDM_FLAG_F16_RANGE: the rewind repairs the trajectory)
 
     def snapshot(self, state: Dict[str, Any], tensors: List[torch.Tensor], flags: torch.Tensor):
         """Called on the stream the latent is valid on.  Returns the restart point to rewind to if the PREVIOUS snapshot's flag is dirty."""
@@ -197,6 +198,7 @@ class _RangeCheckpoints:
             st, copies, ev, host = self.pend
             ev.synchronize()
             dirty = any(int(v) & _native.FLAG_F16_RANGE for v in host.tolist())
+            self.tail_flag |= any(int(v) & _native.FLAG_TAIL for v in host.tolist())      # (fused layer launch; the caller of resolve() disables it on its handle)
             self.pend = None
             if dirty:
                 return self._rewind()
@@ -821,6 +823,8 @@ class EquivariantVariationalDiffusion(nn.Module):
         if fell_back:
             fl |= _native.FLAG_F16_RANGE          # reported in last_flags: part of this sample was computed with fp32 MFMA
         self.last_range_rewinds = 0 if guard is None else guard.rewinds
+        if guard is not None and (guard.tail_flag or (fl & _native.FLAG_TAIL)):
+            dyn.disable_fused_layer("mol_gen_sample")      # (the affected interval was repeated with two launches per layer by the range rewind)
         if not fell_back:
             self.last_range_resume_step = None
         if fl & _native.FLAG_MEAN_NOT_ZERO:
@@ -1094,6 +1098,9 @@ class EquivariantVariationalDiffusion(nn.Module):
             g = ddpm.gamma.gamma.detach().to("cpu", torch.float32).contiguous()
             _native.check(self.lib, self.h, self.lib.gcdm_set_gamma(self.h, C.c_void_p(g.data_ptr()), g.numel()), "gcdm_set_gamma")
             self.lib.gcdm_set_option(self.h, b"mfma_mode", dyn.mfma_mode)
+            # lane handles run CONCURRENTLY with other handles (slices of one batch, batches in flight): two launches per layer there -- the fused layer launch
+            # (option "fuse_node") packs a single handle's tiles better (-3 % per step), but beside another launch its node role is gated and loses (+3 %)
+            self.lib.gcdm_set_option(self.h, b"fuse_node", 0)
             self.stream = torch.cuda.Stream(device)
             self.key = ddpm._lane_key(device)
 

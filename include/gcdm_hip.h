@@ -38,6 +38,9 @@ extern "C" {
 #define GCDM_FLAG_MEAN_NOT_ZERO  0x2u  /* variational_diffusion.py:465-474 assert_mean_zero_with_mask fails  */
 #define GCDM_FLAG_COG_DRIFT      0x4u  /* variational_diffusion.py:1392-1402: CoG drift > 5e-2, re-projected  */
 #define GCDM_FLAG_F16_RANGE      0x8u  /* split-precision mode (GCDM_MFMA=f16x3): an activation exceeded 1.2e8 -> result invalid, re-run in fp32 mode */
+#define GCDM_FLAG_TAIL           0x10u /* fused layer launch (option "fuse_node"): a workgroup-placement check or a bounded dependency wait failed -> result invalid;
+                                          raised TOGETHER with GCDM_FLAG_F16_RANGE, so that every caller's existing re-run (fp32 mode: two launches per layer) repairs
+                                          the result; the caller should then set "fuse_node" to 0 on the handle */
 
 typedef struct GcdmConfig {
     int32_t abi_version;       /* must be GCDM_ABI_VERSION */
@@ -194,6 +197,11 @@ int gcdm_debug_set_layer_limit(gcdm_handle* h, int32_t num_layers_to_run);
  * current one the 64-edge tile (every weight byte read once per 64 edges) is the faster one for both edge widths, DESIGN.md 3.4.
  * "persistent": 1 (default; env GCDM_PERSISTENT) / 0 -- the split-precision edge-message kernel as one workgroup per CU (two at 32-edge tiles) that walks
  * the tile list with the next tile's operands prefetched, whenever there are more tiles than that; 0: one workgroup per tile (A/B runs).  Same bits.
+ * "fuse_node": 1 (default; env GCDM_FUSE_NODE) / 0 -- split-precision mode, persistent 64-edge launches, unmasked plans: a layer is ONE launch, its node tiles run
+ * as a tail role of the persistent edge-message workgroups (csrc/gcdm_layer_x3.hip.h: readiness counters per node tile, self-resetting; safe when several handles
+ * share the GPU -- the node role is entered only when every workgroup of the XCD group has arrived -- but then SLOWER than two launches per layer: set 0 on handles
+ * that run concurrently, as the package's slice / lane handles do).  Same bits.  "fuse_tile": nodes per node tile of that tail role (32; 0 = automatic).
+ * "fuse_active" (read-only): 1 if the last gcdm_forward of the handle used the fused launch.
  * "node_tile": nodes per workgroup of the split-precision per-layer node kernel: 64 (every streamed weight byte feeds two 32-node MFMA tiles), 32, or
  * 0 = automatic (default; env GCDM_NODE_TILE): whichever needs fewer CU rounds for the plan's node count.  Same bits.
  * "step_graph": 1 (default; env GCDM_STEP_GRAPH) / 0 -- gcdm_sample_step with on-device (Philox) noise enqueues ONE hipGraph launch per step instead
