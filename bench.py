@@ -193,8 +193,11 @@ def load_pmc_summary(workload, x3, prefix=None):
     with open(files[-1]) as f:
         d = json.load(f)
     meta = d.get("_meta", {})
-    for k, v in d.items():
-        if k.startswith(prefix):
+    # (round 6: the edge kernel has two instantiations per shape -- NoTailRole = the kernel by itself, what the roofline object is about; NodeTailRole = the fused layer)
+    keys = sorted(d, key=lambda k: ("NodeTailRole" in k) != ("NodeTailRole" in prefix))
+    for k in keys:
+        v = d[k]
+        if k.startswith(prefix.split("|")[0]) and ("NodeTailRole" in k) == ("NodeTailRole" in prefix):
             out = dict(v)
             out["source"] = os.path.relpath(files[-1], ROOT)
             out["collected_at_commit"] = meta.get("git_head")
@@ -216,7 +219,8 @@ def load_kernel_stats(workload, x3, prefix):
         return None, None
     with open(files[-1], newline="") as f:
         for row in csv.DictReader(f):
-            if row["Name"].replace("void ", "").startswith(prefix):
+            name = row["Name"].replace("void ", "")
+            if name.startswith(prefix.split("|")[0]) and ("NodeTailRole" in name) == ("NodeTailRole" in prefix):
                 return float(row["AverageNs"]) * 1e-6, os.path.relpath(files[-1], ROOT)
     return None, None
 
@@ -603,6 +607,7 @@ def main():
             if st < 0:
                 native.check(ln.lib, ln.h, st, "gcdm_sample_step")
 
+    fuse_default = int(lib.gcdm_get_option(h, b"fuse_node"))          # the primary handle's setting (1 unless GCDM_FUSE_NODE=0): restored behind every A/B below
     log(f"plan: N={N} E={E} cpu_count={os.cpu_count()}")
     clocks = ClockSampler(local_rank).start()          # sclk / socket power of THIS rank's GPU through every window below (roofline.sclk_mhz & co.)
     log(f"clock sampler: {clocks.source}")
@@ -726,8 +731,11 @@ def main():
     # library records on the launch stream.  These need WHOLE-BATCH launches on one handle (the slices' kernels of the timed loop overlap each
     # other on the chip, so their individual durations say nothing): 5 un-timed steps per mode on the primary handle = the command profiled
     # under profiles/ (bench.py --lanes 1).
-    def kernel_launch_ms(mode):
+    def kernel_launch_ms(mode, fuse=0):
+        # fuse = 0: two launches per layer, each kernel timed by itself (what the committed rocprofv3 statistics hold; the slices of the timed loop run this way);
+        # fuse = 1: the fused layer launch of a primary handle (node tiles as a tail role of the edge workgroups): the first figure is the whole layer then
         nonlocal s_idx
+        lib.gcdm_set_option(h, b"fuse_node", fuse)
         lib.gcdm_set_option(h, b"mfma_mode", mode)
         for _ in range(3):
             st_ = lib.gcdm_sample_step(h, zp, cptr, max(s_idx, 0), T, None, seed, fp, stream); s_idx -= 1
@@ -744,6 +752,7 @@ def main():
             native.check(lib, h, lib.gcdm_profile_node_kernel_ms(h, C.byref(ms), C.byref(nl)), "gcdm_profile_node_kernel_ms")
             totn += ms.value
         lib.gcdm_profile_enable(h, 0)
+        lib.gcdm_set_option(h, b"fuse_node", fuse_default)
         return tot / max(cnt, 1), totn / max(cnt, 1)
 
     mode_ms = {}
@@ -754,19 +763,47 @@ def main():
         torch.cuda.synchronize(dev)
         clk_kernel[m] = clocks.stats(t_m, time.perf_counter())
     lib.gcdm_set_option(h, b"mfma_mode", x3_mode)
+    # the fused layer launch (default on a primary handle; the timed loop's slice handles run two launches per layer): its launch time on the whole batch, and a
+    # short window of one-handle steps in both forms -- the A/B of the round-6 change in the line itself
+    fused = None
+    if x3_mode == 1:
+        f_ms, _ = kernel_launch_ms(1, fuse=1)
+        f_active = int(lib.gcdm_get_option(h, b"fuse_active"))
+
+        def one_handle_steps(k):
+            nonlocal s_idx
+            for _ in range(k):
+                lib.gcdm_sample_step(h, zp, cptr, max(s_idx, 0), T, None, seed, fp, stream); s_idx -= 1
+            torch.cuda.synchronize(dev)
+        ab = {}
+        for fz in (0, 1):
+            lib.gcdm_set_option(h, b"fuse_node", fz)
+            one_handle_steps(3)
+            ab[fz] = median_of_windows(one_handle_steps, 20)[0]
+        lib.gcdm_set_option(h, b"fuse_node", fuse_default)
+        fused = {"active": bool(f_active), "avg_launch_ms": f_ms, "one_handle_ms_per_step": {"two_launches_per_layer": ab[0], "fused": ab[1]}}
     # the shipped edge kernel's own cycles per tile (end-of-tile stamp, part of every build; split-precision mode): the figure that compares builds and boxes --
     # the boxes of the pool run this loop at 2.00-2.15 GHz, so milliseconds differ by +-4 % for identical kernels, cycles by +-0.1 %
     tile_cycles = tiles = None
     if x3_mode == 1:
         for _ in range(3):                       # (back in the split-precision mode: its weights are cold in the L2 after the fp32-mode steps)
             lib.gcdm_sample_step(h, zp, cptr, max(s_idx, 0), T, None, seed, fp, stream); s_idx -= 1
+    if x3_mode == 1:
+        lib.gcdm_set_option(h, b"fuse_node", 0)          # (the kernel of the timed loop's slices; the fused form's tile is ~0.7 % longer, fused_layer.tile_cycles)
     if x3_mode == 1 and lib.gcdm_profile_enable(h, 2) == 0:
         lib.gcdm_sample_step(h, zp, cptr, max(s_idx, 0), T, None, seed, fp, stream); s_idx -= 1
         torch.cuda.synchronize(dev)
         et = int(lib.gcdm_get_option(h, b"edge_tile"))
         ph = dyn.debug_read("phase").view(-1, 8, 24)[:, :(4 if et == 32 else 8), 20]
         tiles, tile_cycles = int(ph.shape[0]), float(ph.mean().item())
+        if fused is not None:
+            lib.gcdm_set_option(h, b"fuse_node", fuse_default)
+            lib.gcdm_sample_step(h, zp, cptr, max(s_idx, 0), T, None, seed, fp, stream); s_idx -= 1
+            torch.cuda.synchronize(dev)
+            fused["tile_cycles"] = float(dyn.debug_read("phase").view(-1, 8, 24)[:, :(4 if et == 32 else 8), 20].mean().item())
         lib.gcdm_profile_enable(h, 0)
+    if x3_mode == 1:
+        lib.gcdm_set_option(h, b"fuse_node", fuse_default)
     edge_ms, node_ms = mode_ms[x3_mode][1], mode_ms[x3_mode][2]
     clocks.stop()
     fallback_ms = mode_ms[0][0] if 0 in mode_ms and x3_mode == 1 else None
@@ -971,6 +1008,14 @@ def main():
                                         "autograd; parity with the reference's autograd: tests/test_modules_gpu.py); outside the sampling path"}
         if per_rank is not None:
             res["per_rank"] = per_rank
+        if fused is not None:
+            fa = (alg_edge_layer + alg_node_layer) / (fused["avg_launch_ms"] * 1e-3) / 1e12
+            fused.update({"kernel": "k_edge_msg_x3<..., NodeTailRole<32>>", "algorithmic_flop_per_launch": alg_edge_layer + alg_node_layer, "achieved": fa, "peak": peak,
+                          "unit": "TFLOP/s", "frac": fa / peak,
+                          "what": "one interaction layer as ONE launch (csrc/gcdm_layer_x3.hip.h): the layer's node tiles run as a tail role of the persistent edge-message "
+                                  "workgroups; default on a primary handle (plug point 1, one-handle sampling), off on the slice / lane handles of the timed loop, where "
+                                  "two launches per layer pack better beside the other slice's kernels; algorithmic FLOPs = edge kernel + node kernel of a layer"})
+            res["roofline"]["fused_layer"] = fused
         res["roofline"]["pmc_stale"] = pmc.get("stale")
         res["roofline"]["pmc_collected_at_commit"] = pmc.get("collected_at_commit")
         if other_configs is not None:

@@ -51,6 +51,10 @@ def _check_line(r, n_gpus, B):
     assert 400.0 < rf["sclk_mhz"] <= 2500.0 and 100.0 < rf["power_w"] < 2000.0
     assert 400.0 < rf["sclk_mhz_from_cycles"] <= 2600.0
     assert rf["frac"] <= rf["frac_at_measured_clock"] < 1.0          # the box never runs above the nominal 2.4 GHz the peak is quoted at
+    # the fused layer launch (round 6) is reported beside the roofline object, which stays about the edge kernel by itself
+    fz = rf["fused_layer"]
+    assert fz["active"] is (B * 361 > 64 * 256) and fz["avg_launch_ms"] > 0 and 0.0 < fz["frac"] < 1.0
+    assert set(fz["one_handle_ms_per_step"]) == {"two_launches_per_layer", "fused"}
     if n_gpus > 1:
         pr = r["per_rank"]
         assert len(pr["ms_per_step"]) == n_gpus == len(pr["sclk_mhz"]) == len(pr["power_w"])
