@@ -149,6 +149,11 @@ def load() -> C.CDLL:
     global _lib
     if _lib is not None:
         return _lib
+    if os.environ.get("GCDM_HIP_LIB"):
+        # a variant build (A/B, hazard runs): build() neither checks nor rebuilds it, so a library compiled from older sources would be loaded as it is
+        import warnings
+        warnings.warn(f"bio-diffusion_amd: loading the kernel library from GCDM_HIP_LIB={LIB_PATH} instead of the in-tree build "
+                      f"({DEFAULT_LIB_PATH}); it is NOT checked against the sources of this tree", RuntimeWarning)
     if not os.path.exists(LIB_PATH):
         raise RuntimeError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                            "(hipcc --offload-arch=gfx950).  bio-diffusion_amd has no CPU / eager fallback.")

@@ -129,6 +129,7 @@ struct gcdm_handle {
     } sg;
     hipStream_t cap_stream = nullptr;  // capture happens here (the caller's stream may be the null stream, which cannot capture)
     hipEvent_t sg_done = nullptr; bool sg_inflight = false;   // recorded behind every graph launch: an exec (and the row table it reads) is retired only after it
+    hipStream_t sg_last_stream = nullptr;                      // ... and a launch on ANOTHER stream first waits for it, so that the one event covers every launch in flight
     StepRow* d_rows = nullptr; int rows_steps = 0;
     int* d_cursor = nullptr; int cursor_expected = -1;
     int64_t graph_launches = 0;        // option "graph_launches" (read-only): steps served by the graph since the handle was created
@@ -1380,6 +1381,10 @@ static int step_via_graph(gcdm_handle* h, float* z, const float* context, int32_
         h->sg.graph = g; h->sg.exec = ex; h->sg.z = z; h->sg.ctx = context; h->sg.flags = flags; h->sg.seed = seed; h->sg.num_steps = num_steps;
         h->cursor_expected = -1;
     }
+    // a caller that alternates streams: the new stream waits for the graph launch in flight on the old one (the step reads and writes the handle's workspace
+    // anyway), so sg_done -- re-recorded below -- always covers everything that may still read the exec or the row table
+    if (h->sg_inflight && h->sg_done && h->sg_last_stream != st) (void)hipStreamWaitEvent(st, h->sg_done, 0);
+    h->sg_last_stream = st;
     if (h->cursor_expected != s_index) hipLaunchKernelGGL(k_cursor_set, dim3(1), dim3(1), 0, st, h->d_cursor, (int)s_index);
     if ((e = hipGraphLaunch(h->sg.exec, st)) != hipSuccess) return give_up("hipGraphLaunch", e);
     if (!h->sg_done && hipEventCreateWithFlags(&h->sg_done, hipEventDisableTiming) != hipSuccess) h->sg_done = nullptr;
@@ -1509,7 +1514,9 @@ int gcdm_set_option(gcdm_handle* h, const char* name, int32_t value) {
     // last step); an option set to the value it already has changes nothing either
     if (k == "step_graph") { h->step_graph = value ? 1 : 0; h->step_graph_failed = false; if (!value) drop_step_graph(h); return 0; }
     if (k == "cog_fix") { h->cog_fix = value ? 1 : 0; return 0; }
-    if (gcdm_get_option(h, name) != value || k == "mfma_mode") drop_step_graph(h);
+    // (the getters of the options below return the stored field itself -- edge_tile: the effective tile, which is what a captured step bakes in; an option whose
+    //  getter normalises its value must be added to the always-drop list beside mfma_mode)
+    if (gcdm_get_option(h, name) != value || k == "mfma_mode" || k == "fuse_node") drop_step_graph(h);
     if (k == "mfma_mode") {                 // 0: fp32 MFMA, 1: split-precision f16 x3 (fp32-equivalent, 5.3x the matrix rate)
         if (value != 0 && value != 1) return fail(h, "gcdm_set_option(mfma_mode): 0 or 1");
         if (value == 1 && !h->x3_weights_ok) return fail(h, "gcdm_set_option(mfma_mode): a weight of this model is >= 2047 in magnitude (or not finite), outside the split-precision images at every exponent split; only mode 0 (fp32 MFMA) is available");

@@ -1100,7 +1100,9 @@ class EquivariantVariationalDiffusion(nn.Module):
             self.lib.gcdm_set_option(self.h, b"mfma_mode", dyn.mfma_mode)
             # lane handles run CONCURRENTLY with other handles (slices of one batch, batches in flight): two launches per layer there -- the fused layer launch
             # (option "fuse_node") packs a single handle's tiles better (-3 % per step), but beside another launch its node role is gated and loses (+3 %)
-            self.lib.gcdm_set_option(self.h, b"fuse_node", 0)
+            # (GCDM_LANE_FUSE=1: A/B hook.  Stream priorities for the slices -- lane 0 high, lane 1 normal, so that one slice's launch would be dispatched whole before
+            #  the other's -- were measured too: no effect on the dispatch interleave, 7.00 vs 7.00 ms per step un-fused, 7.21 vs 7.22 fused; profiles/r06_ab_log.txt)
+            self.lib.gcdm_set_option(self.h, b"fuse_node", int(os.environ.get("GCDM_LANE_FUSE", "0")))
             self.stream = torch.cuda.Stream(device)
             self.key = ddpm._lane_key(device)
 
