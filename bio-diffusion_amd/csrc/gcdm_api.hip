@@ -1167,7 +1167,9 @@ int gcdm_forward_sc(gcdm_handle* h, const float* xh, const float* xh_sc, const f
             if (d.KB != 18 || d.KB0 != x3_msg0_kb(h->Se, h->H0)) return fail(h, "internal: k-block counts differ from the kernel's compile-time constants");
             // persistent workgroups: as many as fit the chip at once (one per CU with 64-edge tiles, two with 32), a multiple of 8 so that every
             // XCD gets the same number; fewer tiles than that -> one tile per workgroup, as before
-            int wgs = h->cus * (ET == 64 ? 1 : 2) / 8 * 8;
+            // (32-edge tiles: 83 KB of LDS since round 5, i.e. ONE workgroup per CU -- a grid of 2 x CUs would run in two rounds of one per CU)
+            constexpr int per_cu32 = EdgeGeo<32>::LDS_BYTES_X3 * 2 <= 160 * 1024 ? 2 : 1;
+            int wgs = h->cus * (ET == 64 ? 1 : per_cu32) / 8 * 8;
             bool persistent = true;
             if (h->persistent == 0 || tiles <= wgs || wgs < 8) { wgs = tiles; xa.wg_stride = tiles; persistent = false; } else xa.wg_stride = wgs / 8;
             // one launch per layer: the node tiles as a tail role of the persistent workgroups (gcdm_layer_x3.hip.h) where the plan qualifies

@@ -31,10 +31,10 @@ timeout 200 python bench.py --lanes 1 --steps 100 --warmup 5 --no-cpu-baseline -
 # in-kernel phase stamps need the -DGCDM_STAMPS build (tools/build_variants.sh stamps:-DGCDM_STAMPS -> build/ab/libgcdm_stamps.so)
 if [ -f build/ab/libgcdm_stamps.so ]; then
     cp bio-diffusion_amd/libgcdm_hip.so /tmp/libgcdm_keep.so; cp build/ab/libgcdm_stamps.so bio-diffusion_amd/libgcdm_hip.so
-    timeout 100 python tests/gpu_time.py qm9 1024 > $OUT/${TAG}_phase_stamps_qm9.txt 2>&1
-    timeout 100 python tests/gpu_time.py geom 256 > $OUT/${TAG}_phase_stamps_geom.txt 2>&1
+    GCDM_FUSE_NODE=0 timeout 100 python tests/gpu_time.py qm9 1024 > $OUT/${TAG}_phase_stamps_qm9.txt 2>&1
+    GCDM_FUSE_NODE=0 timeout 100 python tests/gpu_time.py geom 256 > $OUT/${TAG}_phase_stamps_geom.txt 2>&1
     timeout 100 python tests/gpu_node_phases.py qm9 512 > $OUT/${TAG}_node_phase_stamps_qm9.txt 2>&1
-    timeout 100 python tests/gpu_first_tile.py qm9 > $OUT/${TAG}_first_tile_qm9.txt 2>&1
+    GCDM_FUSE_NODE=0 timeout 100 python tests/gpu_first_tile.py qm9 > $OUT/${TAG}_first_tile_qm9.txt 2>&1
     cp /tmp/libgcdm_keep.so bio-diffusion_amd/libgcdm_hip.so
 fi
 tail -c 600 $OUT/${TAG}_bench_qm9.json; echo; tail -3 $OUT/${TAG}_profile_qm9.log
