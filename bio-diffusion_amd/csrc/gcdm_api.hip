@@ -74,7 +74,7 @@ struct gcdm_handle {
     float* ws = nullptr;  // workspace pool
     size_t ws_floats = 0;
     float *X0 = nullptr, *XC = nullptr, *FBAR = nullptr, *CHI0 = nullptr, *HIN4 = nullptr, *H4 = nullptr, *CHI = nullptr, *PQ4 = nullptr,
-          *VDI = nullptr, *VDJ = nullptr, *AGG = nullptr, *PART = nullptr, *VEL = nullptr, *EPS = nullptr, *TBUF = nullptr, *EP4 = nullptr, *AL = nullptr, *U = nullptr, *FR = nullptr, *PROF = nullptr, *ZK = nullptr, *ZU = nullptr, *ZROW = nullptr;
+          *VDI = nullptr, *VDJ = nullptr, *AGG = nullptr, *PART = nullptr, *VEL = nullptr, *EPS = nullptr, *EP4 = nullptr, *AL = nullptr, *U = nullptr, *FR = nullptr, *PROF = nullptr, *ZK = nullptr, *ZU = nullptr, *ZROW = nullptr;
     float *PQ4b = nullptr, *VDIb = nullptr, *VDJb = nullptr;   // second set of the node-level msg0 halves: layer l gathers set l & 1, its node tiles write set (l + 1) & 1 (round 6:
                                                                // with the node tiles as a tail role of the edge workgroups both happen in ONE launch)
     // Fused layer launch (gcdm_layer_x3.hip.h): tables of the node-tile queue for 32- and 64-node tiles ([0] / [1]); null when the plan does not qualify
@@ -949,7 +949,7 @@ int gcdm_plan_batch_masked(gcdm_handle* h, int32_t B, const int32_t* nn, const u
     const size_t n = (size_t)N, e = (size_t)E;
     const size_t oX0 = take(3 * n), oXC = take(3 * n), oFB = take(9 * n), oC0 = take(12 * n), oHIN = take(4 * h->FinG * n), oH4 = take(GCDM_S * n),
                  oCHI = take(96 * n), oPQ = take(512 * n), oVDI = take((size_t)(h->H0 + 3) * 3 * n), oVDJ = take((size_t)(h->H0 + 3) * 3 * n),
-                 oAGG = take(GCDM_AGGW * n), oPART = take(((e + 31) / 32) * 2 * GCDM_AGGW), oVEL = take(3 * n), oEPS = take((size_t)h->D * n), oT = take(n), oEP = take((size_t)h->Se * e),
+                 oAGG = take(GCDM_AGGW * n), oPART = take(((e + 31) / 32) * 2 * GCDM_AGGW), oVEL = take(3 * n), oEPS = take((size_t)h->D * n), oEP = take((size_t)h->Se * e),
                  oAL = take((size_t)h->Ve * e), oU = take(3 * e), oFR = take(9 * e), oPROF = take(((e + 31) / 32) * 192),
                  oX0SC = take(h->sc ? 3 * n : 0), oBL = take(h->sc ? (size_t)h->Ve * e : 0), oUSC = take(h->sc ? 3 * e : 0),
                  oZK = take((size_t)h->D * n), oZU = take((size_t)h->D * n), oZROW = take(GCDM_AGGW),
@@ -960,7 +960,7 @@ int gcdm_plan_batch_masked(gcdm_handle* h, int32_t B, const int32_t* nn, const u
     HIP_OK(h, hipMemset(h->ws, 0, off * sizeof(float)));
     float* w = h->ws;
     h->X0 = w + oX0; h->XC = w + oXC; h->FBAR = w + oFB; h->CHI0 = w + oC0; h->HIN4 = w + oHIN; h->H4 = w + oH4; h->CHI = w + oCHI;
-    h->PQ4 = w + oPQ; h->VDI = w + oVDI; h->VDJ = w + oVDJ; h->AGG = w + oAGG; h->PART = w + oPART; h->VEL = w + oVEL; h->EPS = w + oEPS; h->TBUF = w + oT; h->EP4 = w + oEP;
+    h->PQ4 = w + oPQ; h->VDI = w + oVDI; h->VDJ = w + oVDJ; h->AGG = w + oAGG; h->PART = w + oPART; h->VEL = w + oVEL; h->EPS = w + oEPS; h->EP4 = w + oEP;
     h->AL = w + oAL; h->U = w + oU; h->FR = w + oFR; h->PROF = w + oPROF;
     h->ZK = w + oZK; h->ZU = w + oZU; h->ZROW = w + oZROW;     // ZROW is never written: the workspace starts zeroed
     h->PQ4b = w + oPQb; h->VDIb = w + oVDIb; h->VDJb = w + oVDJb;
@@ -1054,22 +1054,36 @@ int gcdm_forward(gcdm_handle* h, const float* xh, const float* t, const float* c
     return gcdm_forward_sc(h, xh, nullptr, t, context, out, flags, stream_);
 }
 
+// The sampler's network evaluations (transition, gcdm_sample_final_sc) feed the time from the step instead of a t [N] tensor and fold the last stage
+// (k_finish) into their k_sample launch: one value for the whole batch, from the device step table when the step is being captured
+struct StepFeed { const StepRow* rows; const int* cursor; float t_value; };
+static int forward_impl(gcdm_handle* h, const float* xh, const float* xh_sc, const float* t, const StepFeed* feed, const float* context, float* out,
+                        uint32_t* flags, void* stream_);
+
 int gcdm_forward_sc(gcdm_handle* h, const float* xh, const float* xh_sc, const float* t, const float* context, float* out, uint32_t* flags,
                     void* stream_) {
+    if (!h) return -1;
+    if (!t) return fail(h, "gcdm_forward: null tensor");
+    return forward_impl(h, xh, xh_sc, t, nullptr, context, out, flags, stream_);
+}
+
+static int forward_impl(gcdm_handle* h, const float* xh, const float* xh_sc, const float* t, const StepFeed* feed, const float* context, float* out,
+                        uint32_t* flags, void* stream_) {
     if (!h) return -1;
     if (xh_sc && !h->sc) return fail(h, "gcdm_forward_sc: the handle was created without self_condition");
     if (!h->finalized) return fail(h, "gcdm_forward: weights not finalized");
     if (!h->N) return fail(h, "gcdm_forward: no batch plan");
-    if (!xh || !t || !out) return fail(h, "gcdm_forward: null tensor");
+    if (!xh || !out) return fail(h, "gcdm_forward: null tensor");
     if (h->C && !context) return fail(h, "gcdm_forward: context required");
     DeviceGuard guard(h->cfg.device);
     hipStream_t st = (hipStream_t)stream_;
     const int N = h->N, B = h->B;
     const int E = (int)h->E;
-    HIP_OK(h, hipMemsetAsync(h->d_flags, 0, sizeof(uint32_t), st));
     h->fuse_active = 0;
     PrepArgs pa{xh, t, context, h->d_noff, N, h->F, h->C, h->FinG, h->X0, h->XC, h->FBAR, h->CHI0, (v4f*)h->HIN4, h->flat_prev, h->flat_next,
                 h->sc, xh_sc, h->X0SC, h->d_mask};
+    if (feed) { pa.t = nullptr; pa.t_rows = feed->rows; pa.t_cursor = feed->cursor; pa.t_value = feed->t_value; }
+    pa.flags_dev = h->d_flags;            // cleared by the first kernel of the evaluation
     hipLaunchKernelGGL(k_prep, dim3(B), dim3(64), 3 * h->max_n * sizeof(float), st, pa);
     EdgeEmbedArgs ea{h->X0, h->XC, N, h->d_erow, h->d_ecol, E, h->ee_ws, h->ee_bs, h->ee_wd, h->ee_wdf, h->ee_kappa, h->ee_wg, h->ee_bg,
                      (v4f*)h->EP4, h->AL, h->U, h->FR,
@@ -1219,7 +1233,7 @@ int gcdm_forward_sc(gcdm_handle* h, const float* xh, const float* xh_sc, const f
         launch_node(false, l + 1, &d);
         if (h->profile) HIP_OK(h, hipEventRecord(h->ev[2 * (size_t)h->L + l], st));      // end of the layer's node kernel (gcdm_profile_node_kernel_ms)
     }
-    if (!truncated) {
+    if (!truncated && !feed) {              // (the sampler's evaluations: inside their k_sample launch)
         FinishArgs fa{h->VEL, h->d_noff, N, h->D, out, h->d_flags, flags, h->d_mask};
         hipLaunchKernelGGL(k_finish, dim3(B), dim3(64), 0, st, fa);
     }
@@ -1280,13 +1294,6 @@ int gcdm_encode_samples(gcdm_handle* h, const float* xh, float* z, uint32_t* fla
     return 0;
 }
 
-static int fill_t(gcdm_handle* h, float value, hipStream_t st) {
-    DeviceGuard guard(h->cfg.device);
-    hipLaunchKernelGGL(k_fill, dim3((h->N + 255) / 256), dim3(256), 0, st, h->TBUF, h->N, value);
-    HIP_OK(h, hipGetLastError());
-    return 0;
-}
-
 int gcdm_sample_step(gcdm_handle* h, float* z, const float* context, int32_t s_index, int32_t num_steps, const float* noise, uint64_t seed,
                      uint32_t* flags, void* stream_) {
     return gcdm_sample_step_to(h, z, z, context, s_index, num_steps, noise, seed, flags, stream_);
@@ -1312,16 +1319,14 @@ static StepRow step_row(const gcdm_handle* h, float s, float t, uint32_t draw) {
 static int transition(gcdm_handle* h, const float* z_in, float* z_out, const float* sc, const float* context, float s, float t,
                       const float* noise, uint64_t seed, uint32_t draw, uint32_t* flags, void* stream_) {
     hipStream_t st = (hipStream_t)stream_;
-    if (h->capturing) {       // the step being captured into a graph: t and the coefficients come from the device table at run time
-        DeviceGuard guard(h->cfg.device);
-        hipLaunchKernelGGL(k_fill_row, dim3((h->N + 255) / 256), dim3(256), 0, st, h->TBUF, h->N, h->d_rows, h->d_cursor);
-    } else if (fill_t(h, t, st)) {
-        return -1;
-    }
-    if (gcdm_forward_sc(h, z_in, sc, h->TBUF, context, h->EPS, flags, stream_)) return -1;
+    if (h->d_mask) return fail(h, "the sampler entry points need an all-True node mask (plan with gcdm_plan_batch); masked plans serve gcdm_forward only");
+    // the step being captured into a graph: t and the coefficients come from the device table at run time
+    const StepFeed feed{h->capturing ? h->d_rows : nullptr, h->capturing ? h->d_cursor : nullptr, t};
+    if (forward_impl(h, z_in, sc, nullptr, &feed, context, h->EPS, flags, stream_)) return -1;
     const StepRow r = step_row(h, s, t, draw);
     StepArgs sa{};
-    if (h->capturing) { sa.rows = h->d_rows; sa.cursor = h->d_cursor; }
+    if (h->capturing) { sa.rows = h->d_rows; sa.cursor = h->d_cursor; sa.cursor_rw = h->d_cursor; }
+    sa.VEL = h->VEL;
     sa.z = const_cast<float*>(z_in); sa.z_out = z_out; sa.eps = h->EPS; sa.noise = noise; sa.seed = seed; sa.draw = draw; sa.mode = 0;
     sa.alpha_coef = r.alpha_coef;
     sa.c_eps = r.c_eps;
@@ -1348,7 +1353,7 @@ static int step_via_graph(gcdm_handle* h, float* z, const float* context, int32_
     };
     hipError_t e;
     if (!h->cap_stream && (e = hipStreamCreateWithFlags(&h->cap_stream, hipStreamNonBlocking)) != hipSuccess) return give_up("hipStreamCreate", e);
-    if (!h->d_cursor && (e = hipMalloc(&h->d_cursor, sizeof(int))) != hipSuccess) return give_up("hipMalloc", e);
+    if (!h->d_cursor && (e = hipMalloc(&h->d_cursor, 2 * sizeof(int))) != hipSuccess) return give_up("hipMalloc", e);      // {step index, k_sample workgroups done}
     if (h->rows_steps != num_steps) {              // the table of this step count (s = i / num_steps, t = (i + 1) / num_steps, as gcdm_sample_step_to)
         std::vector<StepRow> rows((size_t)num_steps);
         for (int i = 0; i < num_steps; ++i) rows[i] = step_row(h, (float)i / (float)num_steps, (float)(i + 1) / (float)num_steps, (uint32_t)i);
@@ -1363,7 +1368,6 @@ static int step_via_graph(gcdm_handle* h, float* z, const float* context, int32_
         if ((e = hipStreamBeginCapture(h->cap_stream, hipStreamCaptureModeThreadLocal)) != hipSuccess) return give_up("hipStreamBeginCapture", e);
         h->capturing = true;
         const int rc = transition(h, z, z, nullptr, context, 0.f, 1.f / (float)num_steps, nullptr, seed, 0u, flags, (void*)h->cap_stream);
-        hipLaunchKernelGGL(k_cursor_dec, dim3(1), dim3(1), 0, h->cap_stream, h->d_cursor);
         h->capturing = false;
         hipGraph_t g = nullptr;
         e = hipStreamEndCapture(h->cap_stream, &g);
@@ -1433,13 +1437,14 @@ int gcdm_sample_final_sc(gcdm_handle* h, const float* z0, const float* self_cond
     if ((int64_t)h->gamma.size() != (int64_t)h->cfg.num_timesteps + 1) return fail(h, "gcdm_sample_final: gamma table not set");
     DeviceGuard guard(h->cfg.device);
     hipStream_t st = (hipStream_t)stream_;
-    if (fill_t(h, 0.0f, st)) return -1;
-    if (gcdm_forward_sc(h, z0, self_cond, h->TBUF, context, h->EPS, flags, stream_)) return -1;
+    if (h->d_mask) return fail(h, "the sampler entry points need an all-True node mask (plan with gcdm_plan_batch); masked plans serve gcdm_forward only");
+    const StepFeed feed{nullptr, nullptr, 0.0f};
+    if (forward_impl(h, z0, self_cond, nullptr, &feed, context, h->EPS, flags, stream_)) return -1;
     const float g0 = gamma_lookup(h, 0.0f);
     const float sigma_x = expf(0.5f * g0);                       // SNR(-0.5 * gamma_0)   (:855-859)
     const float sig0 = sqrtf(sigmoidf_(g0)), alp0 = sqrtf(sigmoidf_(-g0));
     StepArgs sa{};
-    sa.z = const_cast<float*>(z0); sa.eps = h->EPS; sa.noise = noise; sa.seed = seed; sa.draw = 0x7ffffffeu; sa.mode = 2;
+    sa.z = const_cast<float*>(z0); sa.eps = h->EPS; sa.VEL = h->VEL; sa.noise = noise; sa.seed = seed; sa.draw = 0x7ffffffeu; sa.mode = 2;
     sa.alpha_coef = 1.0f / alp0; sa.c_eps = sig0; sa.sigma = sigma_x;
     sa.out = out; sa.num_atom_types = h->cfg.num_atom_types; sa.include_charges = h->cfg.include_charges;
     sa.nv0 = h->cfg.norm_values[0]; sa.nv1 = h->cfg.norm_values[1]; sa.nv2 = h->cfg.norm_values[2];

@@ -363,6 +363,15 @@ __device__ __forceinline__ void frame_of(float xi0, float xi1, float xi2, float 
 // ================================================================================================
 // K1  prep: one workgroup per molecule (gcpnet.py:1081-1109, 1142-1166; scalarize node-mode mean)
 // ================================================================================================
+// Step-dependent scalars of one ancestral transition, one row per step index, resident on the device: the kernels of a CAPTURED step (hipGraph,
+// gcdm_api.hip: StepGraph) read row [*cursor] instead of taking the values as launch arguments, so one instantiated graph serves every step.
+struct StepRow {
+    float t;                            // network time of the step (k_prep puts it into the time column of h_in)
+    float alpha_coef, c_eps, sigma;     // as in StepArgs
+    uint32_t draw;                      // Philox draw index of the step's noise
+    uint32_t pad[3];
+};
+
 struct PrepArgs {
     const float* xh;   // [N][3+F]
     const float* t;    // [N]
@@ -381,11 +390,17 @@ struct PrepArgs {
     // masked nodes (batch.mask with False entries; gcpnet.py:1081, 1094-1099, components/__init__.py:53-92): 1 / 0 per node, or null (all True).
     // Masked nodes enter with zero positions and features, have no edges, are left out of the centroid and keep time / context inputs.
     const float* mask;
+    // the sampler's steps (gcdm_api.hip: transition): t is one value for the whole batch -- rows[*cursor].t of a captured step, else t_value -- when t is null;
+    // flags_dev: the handle's flag word, cleared here for the kernels behind (what a memset node did before round 6)
+    const StepRow* t_rows; const int* t_cursor; float t_value;
+    uint32_t* flags_dev;
 };
 
 __global__ __launch_bounds__(64) void k_prep(PrepArgs a) {
     extern __shared__ __attribute__((aligned(16))) float xs[];  // [3][n] centralised
     const int b = blockIdx.x, o = a.noff[b], n = a.noff[b + 1] - o, D = 3 + a.F;
+    if (a.flags_dev && b == 0 && threadIdx.x == 0) *a.flags_dev = 0u;
+    const float t_all = a.t_rows ? a.t_rows[*a.t_cursor].t : a.t_value;
     float m0 = 0.f, m1 = 0.f, m2 = 0.f, cnt = 0.f;
     for (int i = 0; i < n; ++i) {  // same summation order as scatter(sum) over a sorted index
         const float* p = a.xh + (size_t)(o + i) * D;
@@ -448,7 +463,7 @@ __global__ __launch_bounds__(64) void k_prep(PrepArgs a) {
                 float val = 0.f;
                 if (c < a.F) val = p[3 + c] * mk;
                 else if (c < a.F + Fsc) val = a.xh_sc ? a.xh_sc[(size_t)g * D + 3 + (c - a.F)] : 0.f;
-                else if (c == a.F + Fsc) val = a.t[g];
+                else if (c == a.F + Fsc) val = a.t ? a.t[g] : t_all;
                 else if (c < Fin) val = a.ctx[(size_t)g * a.C + (c - a.F - Fsc - 1)];
                 v[k] = val;
             }
@@ -1169,17 +1184,12 @@ __device__ __forceinline__ float philox_normal(uint64_t seed, uint32_t draw, uin
     return (col & 1) ? r * s : r * co;
 }
 
-// Step-dependent scalars of one ancestral transition, one row per step index, resident on the device: the kernels of a CAPTURED step (hipGraph,
-// gcdm_api.hip: StepGraph) read row [*cursor] instead of taking the values as launch arguments, so one instantiated graph serves every step.
-struct StepRow {
-    float t;                            // network time of the step (what k_fill writes into t [N])
-    float alpha_coef, c_eps, sigma;     // as in StepArgs
-    uint32_t draw;                      // Philox draw index of the step's noise
-    uint32_t pad[3];
-};
-
 struct StepArgs {
     const StepRow* rows; const int* cursor;   // captured step: alpha_coef / c_eps / sigma / draw come from rows[*cursor] (else null)
+    int* cursor_rw;      // captured step: {cursor, workgroups done}; the last workgroup out of the launch moves the cursor to the next step (else null)
+    // the network's last stage folded in (k_finish: CoM-free velocities; flags to the caller): the x columns of eps are VEL - mean(VEL) per molecule,
+    // computed here and also written to eps.  Null -> eps is complete already (gcdm_forward's own k_finish ran)
+    const float* VEL;
     float* z;            // [N][D] in/out
     float* z_out;        // step / init: where the new latent goes (null = in place)
     uint32_t node_base;  // flat index of node 0 in the whole batch (Philox counter), for plans that are slices of a flat batch
@@ -1195,18 +1205,8 @@ struct StepArgs {
     uint32_t* user_flags; uint32_t* flags_dev;
 };
 
-__global__ __launch_bounds__(256) void k_fill(float* p, int n, float v) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i < n) p[i] = v;
-}
-
-// k_fill with the value from the step table (captured steps), and the cursor's own two kernels
-__global__ __launch_bounds__(256) void k_fill_row(float* p, int n, const StepRow* rows, const int* cursor) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i < n) p[i] = rows[*cursor].t;
-}
-__global__ void k_cursor_set(int* cursor, int v) { *cursor = v; }
-__global__ void k_cursor_dec(int* cursor) { *cursor -= 1; }
+// the step cursor of a captured step: {step index, workgroups of k_sample done}
+__global__ void k_cursor_set(int* cursor, int v) { cursor[0] = v; cursor[1] = 0; }
 
 // whole-batch CoG re-projection if any molecule drifted (variational_diffusion.py:1389-1402)
 __global__ __launch_bounds__(64) void k_cog_fix(float* out, const int* noff, int D, const uint32_t* flags_dev, uint32_t* user_flags) {
@@ -1341,6 +1341,19 @@ __global__ __launch_bounds__(64) void k_sample(StepArgs a) {
         const StepRow r = a.rows[*a.cursor];
         a.alpha_coef = r.alpha_coef; a.c_eps = r.c_eps; a.sigma = r.sigma; a.draw = r.draw;
     }
+    // k_finish's arithmetic, in its order (plans of the sampler are unmasked: mk = 1, cnt = n)
+    bool vnan = false;
+    float vm[3] = {0.f, 0.f, 0.f};
+    if (a.VEL) {
+        const uint32_t fl = *a.flags_dev & ~4u;       // (bit 2 = CoG drift is this launch's own, raised by other workgroups below: k_cog_fix reports it)
+        vnan = (fl & 1u) != 0;
+        if (fl && a.user_flags && b == 0 && threadIdx.x == 0) atomicOr(a.user_flags, fl);
+        if (!vnan) {
+            float cnt = 0.f;
+            for (int i = 0; i < n; ++i) { vm[0] += a.VEL[o + i]; vm[1] += a.VEL[a.N + o + i]; vm[2] += a.VEL[2 * (size_t)a.N + o + i]; cnt += 1.f; }
+            vm[0] /= cnt; vm[1] /= cnt; vm[2] /= cnt;
+        }
+    }
     for (int idx = threadIdx.x; idx < n * D; idx += 64) {
         const int i = idx / D, c = idx - i * D;
         ns[idx] = a.noise ? a.noise[(size_t)(o + i) * D + c] : philox_normal(a.seed, a.draw, a.node_base + (uint32_t)(o + i), (uint32_t)c);
@@ -1361,13 +1374,22 @@ __global__ __launch_bounds__(64) void k_sample(StepArgs a) {
             v = e;
         } else {
             const size_t gi = (size_t)(o + i) * D + c;
+            float ep = 0.f;
+            if (a.mode < 3) {
+                if (a.VEL && c < 3) {
+                    ep = vnan ? 0.f : a.VEL[(size_t)c * a.N + o + i] - vm[c];
+                    const_cast<float*>(a.eps)[gi] = ep;
+                } else {
+                    ep = a.eps[gi];
+                }
+            }
             // mu = z / alpha_ts - (sigma2_ts / alpha_ts / sigma_t) * eps ; zs = mu + sigma * noise   (:1247-1263)
             // final: mu = 1/alpha_0 * (z0 - sigma_0 * eps) ; xh = mu + sigma_x * noise          (:571, :878-886)
             // forward noising: q(z_t | x, h) = alpha_t * xh + sigma_t * noise (:922-929) and q(z_t | z_s) (:1174-1185)
             if (a.mode >= 3) v = a.alpha_coef * a.z[gi] + a.sigma * e;
             else
-            v = (a.mode == 0) ? (a.z[gi] / a.alpha_coef - a.c_eps * a.eps[gi]) + a.sigma * e
-                              : a.alpha_coef * (a.z[gi] - a.c_eps * a.eps[gi]) + a.sigma * e;
+            v = (a.mode == 0) ? (a.z[gi] / a.alpha_coef - a.c_eps * ep) + a.sigma * e
+                              : a.alpha_coef * (a.z[gi] - a.c_eps * ep) + a.sigma * e;
         }
         ns[idx] = v;
     }
@@ -1406,6 +1428,13 @@ __global__ __launch_bounds__(64) void k_sample(StepArgs a) {
             }
             for (int c = 0; c < a.num_atom_types; ++c) dst[3 + c] = (c == best) ? 1.f : 0.f;
             if (a.include_charges) dst[3 + a.num_atom_types] = rintf(src[3 + a.num_atom_types] * a.nv2 + a.nb2);
+        }
+    }
+    if (a.cursor_rw) {      // every workgroup read rows[*cursor] on its way in: the last one out steps the cursor (what a k_cursor_dec node did before round 6)
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            __threadfence();
+            if (atomicAdd(a.cursor_rw + 1, 1) == (int)gridDim.x - 1) { a.cursor_rw[1] = 0; a.cursor_rw[0] -= 1; }
         }
     }
 }
