@@ -1056,7 +1056,7 @@ int gcdm_forward(gcdm_handle* h, const float* xh, const float* t, const float* c
 
 // The sampler's network evaluations (transition, gcdm_sample_final_sc) feed the time from the step instead of a t [N] tensor and fold the last stage
 // (k_finish) into their k_sample launch: one value for the whole batch, from the device step table when the step is being captured
-struct StepFeed { const StepRow* rows; const int* cursor; float t_value; };
+struct StepFeed { const StepRow* rows; int* cursor; float t_value; };
 static int forward_impl(gcdm_handle* h, const float* xh, const float* xh_sc, const float* t, const StepFeed* feed, const float* context, float* out,
                         uint32_t* flags, void* stream_);
 
@@ -1325,7 +1325,7 @@ static int transition(gcdm_handle* h, const float* z_in, float* z_out, const flo
     if (forward_impl(h, z_in, sc, nullptr, &feed, context, h->EPS, flags, stream_)) return -1;
     const StepRow r = step_row(h, s, t, draw);
     StepArgs sa{};
-    if (h->capturing) { sa.rows = h->d_rows; sa.cursor = h->d_cursor; sa.cursor_rw = h->d_cursor; }
+    if (h->capturing) { sa.rows = h->d_rows; sa.cursor = h->d_cursor + 1; sa.cursor_rw = h->d_cursor; }
     sa.VEL = h->VEL;
     sa.z = const_cast<float*>(z_in); sa.z_out = z_out; sa.eps = h->EPS; sa.noise = noise; sa.seed = seed; sa.draw = draw; sa.mode = 0;
     sa.alpha_coef = r.alpha_coef;
@@ -1353,7 +1353,7 @@ static int step_via_graph(gcdm_handle* h, float* z, const float* context, int32_
     };
     hipError_t e;
     if (!h->cap_stream && (e = hipStreamCreateWithFlags(&h->cap_stream, hipStreamNonBlocking)) != hipSuccess) return give_up("hipStreamCreate", e);
-    if (!h->d_cursor && (e = hipMalloc(&h->d_cursor, 2 * sizeof(int))) != hipSuccess) return give_up("hipMalloc", e);      // {step index, k_sample workgroups done}
+    if (!h->d_cursor && (e = hipMalloc(&h->d_cursor, 2 * sizeof(int))) != hipSuccess) return give_up("hipMalloc", e);      // two slots (k_cursor_set)
     if (h->rows_steps != num_steps) {              // the table of this step count (s = i / num_steps, t = (i + 1) / num_steps, as gcdm_sample_step_to)
         std::vector<StepRow> rows((size_t)num_steps);
         for (int i = 0; i < num_steps; ++i) rows[i] = step_row(h, (float)i / (float)num_steps, (float)(i + 1) / (float)num_steps, (uint32_t)i);

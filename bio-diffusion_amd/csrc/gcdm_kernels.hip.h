@@ -392,7 +392,7 @@ struct PrepArgs {
     const float* mask;
     // the sampler's steps (gcdm_api.hip: transition): t is one value for the whole batch -- rows[*cursor].t of a captured step, else t_value -- when t is null;
     // flags_dev: the handle's flag word, cleared here for the kernels behind (what a memset node did before round 6)
-    const StepRow* t_rows; const int* t_cursor; float t_value;
+    const StepRow* t_rows; int* t_cursor; float t_value;       // t_cursor: the two slots of the step cursor (k_cursor_set)
     uint32_t* flags_dev;
 };
 
@@ -400,15 +400,26 @@ __global__ __launch_bounds__(64) void k_prep(PrepArgs a) {
     extern __shared__ __attribute__((aligned(16))) float xs[];  // [3][n] centralised
     const int b = blockIdx.x, o = a.noff[b], n = a.noff[b + 1] - o, D = 3 + a.F;
     if (a.flags_dev && b == 0 && threadIdx.x == 0) *a.flags_dev = 0u;
-    const float t_all = a.t_rows ? a.t_rows[*a.t_cursor].t : a.t_value;
-    float m0 = 0.f, m1 = 0.f, m2 = 0.f, cnt = 0.f;
-    for (int i = 0; i < n; ++i) {  // same summation order as scatter(sum) over a sorted index
+    float t_all = a.t_value;
+    if (a.t_rows) {
+        const int cur = a.t_cursor[0];
+        t_all = a.t_rows[cur].t;
+        if (b == 0 && threadIdx.x == 0) a.t_cursor[1] = cur;
+    }
+    // the molecule's (masked) positions through LDS: the loads in parallel, the sum below in the serial order every thread repeats
+    for (int i = threadIdx.x; i < n; i += 64) {
         const float* p = a.xh + (size_t)(o + i) * D;
         const float mk = a.mask ? a.mask[o + i] : 1.f;
-        m0 += p[0] * mk; m1 += p[1] * mk; m2 += p[2] * mk;
-        cnt += mk;
+        xs[i] = p[0] * mk; xs[n + i] = p[1] * mk; xs[2 * n + i] = p[2] * mk;
+    }
+    __syncthreads();
+    float m0 = 0.f, m1 = 0.f, m2 = 0.f, cnt = 0.f;
+    for (int i = 0; i < n; ++i) {  // same summation order as scatter(sum) over a sorted index
+        m0 += xs[i]; m1 += xs[n + i]; m2 += xs[2 * n + i];
+        cnt += a.mask ? a.mask[o + i] : 1.f;
     }
     m0 /= cnt; m1 /= cnt; m2 /= cnt;
+    __syncthreads();                 // (xs is overwritten with the centralised positions below)
     for (int i = threadIdx.x; i < n; i += 64) {
         const int g = o + i;
         const float* p = a.xh + (size_t)g * D;
@@ -1186,7 +1197,7 @@ __device__ __forceinline__ float philox_normal(uint64_t seed, uint32_t draw, uin
 
 struct StepArgs {
     const StepRow* rows; const int* cursor;   // captured step: alpha_coef / c_eps / sigma / draw come from rows[*cursor] (else null)
-    int* cursor_rw;      // captured step: {cursor, workgroups done}; the last workgroup out of the launch moves the cursor to the next step (else null)
+    int* cursor_rw;      // captured step: the cursor's two slots {read by k_prep, read by k_sample}; `cursor` above points at slot 1 (else null)
     // the network's last stage folded in (k_finish: CoM-free velocities; flags to the caller): the x columns of eps are VEL - mean(VEL) per molecule,
     // computed here and also written to eps.  Null -> eps is complete already (gcdm_forward's own k_finish ran)
     const float* VEL;
@@ -1205,8 +1216,9 @@ struct StepArgs {
     uint32_t* user_flags; uint32_t* flags_dev;
 };
 
-// the step cursor of a captured step: {step index, workgroups of k_sample done}
-__global__ void k_cursor_set(int* cursor, int v) { cursor[0] = v; cursor[1] = 0; }
+// the step cursor of a captured step, two slots: k_prep reads slot 0 and copies it to slot 1, k_sample reads slot 1 and writes slot 0 = slot 1 - 1
+// (every reader of a slot is in another launch than its writer: stream order is the only synchronisation)
+__global__ void k_cursor_set(int* cursor, int v) { cursor[0] = v; cursor[1] = v; }
 
 // whole-batch CoG re-projection if any molecule drifted (variational_diffusion.py:1389-1402)
 __global__ __launch_bounds__(64) void k_cog_fix(float* out, const int* noff, int D, const uint32_t* flags_dev, uint32_t* user_flags) {
@@ -1348,11 +1360,15 @@ __global__ __launch_bounds__(64) void k_sample(StepArgs a) {
         const uint32_t fl = *a.flags_dev & ~4u;       // (bit 2 = CoG drift is this launch's own, raised by other workgroups below: k_cog_fix reports it)
         vnan = (fl & 1u) != 0;
         if (fl && a.user_flags && b == 0 && threadIdx.x == 0) atomicOr(a.user_flags, fl);
+        // (through LDS: parallel loads, then the serial sum every thread repeats; ns holds >= 3 n floats)
+        for (int i = threadIdx.x; i < n; i += 64) { ns[i] = a.VEL[o + i]; ns[n + i] = a.VEL[a.N + o + i]; ns[2 * n + i] = a.VEL[2 * (size_t)a.N + o + i]; }
+        __syncthreads();
         if (!vnan) {
             float cnt = 0.f;
-            for (int i = 0; i < n; ++i) { vm[0] += a.VEL[o + i]; vm[1] += a.VEL[a.N + o + i]; vm[2] += a.VEL[2 * (size_t)a.N + o + i]; cnt += 1.f; }
+            for (int i = 0; i < n; ++i) { vm[0] += ns[i]; vm[1] += ns[n + i]; vm[2] += ns[2 * n + i]; cnt += 1.f; }
             vm[0] /= cnt; vm[1] /= cnt; vm[2] /= cnt;
         }
+        __syncthreads();
     }
     for (int idx = threadIdx.x; idx < n * D; idx += 64) {
         const int i = idx / D, c = idx - i * D;
@@ -1430,11 +1446,7 @@ __global__ __launch_bounds__(64) void k_sample(StepArgs a) {
             if (a.include_charges) dst[3 + a.num_atom_types] = rintf(src[3 + a.num_atom_types] * a.nv2 + a.nb2);
         }
     }
-    if (a.cursor_rw) {      // every workgroup read rows[*cursor] on its way in: the last one out steps the cursor (what a k_cursor_dec node did before round 6)
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            __threadfence();
-            if (atomicAdd(a.cursor_rw + 1, 1) == (int)gridDim.x - 1) { a.cursor_rw[1] = 0; a.cursor_rw[0] -= 1; }
-        }
-    }
+    // captured step: this launch reads slot 1 of the cursor (k_prep copied slot 0 there), so ONE thread may step slot 0 for the next launch of the graph
+    // while the other workgroups are still on their way in (what a k_cursor_dec node did before round 6; no atomics, no fence)
+    if (a.cursor_rw && b == 0 && threadIdx.x == 0) a.cursor_rw[0] = a.cursor_rw[1] - 1;
 }
