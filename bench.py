@@ -775,13 +775,21 @@ def main():
             for _ in range(k):
                 lib.gcdm_sample_step(h, zp, cptr, max(s_idx, 0), T, None, seed, fp, stream); s_idx -= 1
             torch.cuda.synchronize(dev)
-        ab = {}
-        for fz in (0, 1):
+        # alternating (0, 1, 0, 1): the clock drifts over a run, and whichever form is measured later would carry the drift; each entry with its own clock
+        ab, ab_clk = {0: [], 1: []}, {0: [], 1: []}
+        for fz in (0, 1, 0, 1):
             lib.gcdm_set_option(h, b"fuse_node", fz)
             one_handle_steps(3)
-            ab[fz] = median_of_windows(one_handle_steps, 20)[0]
+            t_ab = time.perf_counter()
+            ab[fz] += median_of_windows(one_handle_steps, 20)[1]
+            ab_clk[fz].append(clocks.stats(t_ab, time.perf_counter()).get("sclk_mhz"))
         lib.gcdm_set_option(h, b"fuse_node", fuse_default)
-        fused = {"active": bool(f_active), "avg_launch_ms": f_ms, "one_handle_ms_per_step": {"two_launches_per_layer": ab[0], "fused": ab[1]}}
+        med = lambda v: sorted(v)[len(v) // 2]
+        clk = lambda v: (sum(x for x in v if x) / max(1, sum(1 for x in v if x))) or None
+        fused = {"active": bool(f_active), "avg_launch_ms": f_ms,
+                 "one_handle_ms_per_step": {"two_launches_per_layer": med(ab[0]), "fused": med(ab[1])},
+                 "one_handle_sclk_mhz": {"two_launches_per_layer": clk(ab_clk[0]), "fused": clk(ab_clk[1])},
+                 "order": "two_launches, fused, two_launches, fused; median over both windows sets"}
     # the shipped edge kernel's own cycles per tile (end-of-tile stamp, part of every build; split-precision mode): the figure that compares builds and boxes --
     # the boxes of the pool run this loop at 2.00-2.15 GHz, so milliseconds differ by +-4 % for identical kernels, cycles by +-0.1 %
     tile_cycles = tiles = None

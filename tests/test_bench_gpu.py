@@ -54,7 +54,7 @@ def _check_line(r, n_gpus, B):
     # the fused layer launch (round 6) is reported beside the roofline object, which stays about the edge kernel by itself
     fz = rf["fused_layer"]
     assert fz["active"] is (B * 361 > 64 * 256) and fz["avg_launch_ms"] > 0 and 0.0 < fz["frac"] < 1.0
-    assert set(fz["one_handle_ms_per_step"]) == {"two_launches_per_layer", "fused"}
+    assert set(fz["one_handle_ms_per_step"]) == {"two_launches_per_layer", "fused"} == set(fz["one_handle_sclk_mhz"])        # alternating windows, each form with its clock
     if n_gpus > 1:
         pr = r["per_rank"]
         assert len(pr["ms_per_step"]) == n_gpus == len(pr["sclk_mhz"]) == len(pr["power_w"])
