@@ -97,6 +97,113 @@ __device__ __forceinline__ void gemm(f32x16 (&am)[MT][NT], f32x16 (&al)[MT][NT],
     }
 }
 
+// Schedule Z (round 6): ONE accumulator per N-tile.  The three products land at the same scale when W_hi . X_lo' reads a THIRD, natural-scale image of W_hi
+// (streamed from wN: +50 % weight bytes), so there is no `am + al * inv` merge and the wave holds 32 accumulator registers less.
+template <int MT, int NT>
+__device__ __forceinline__ void gemm1(f32x16 (&am)[MT][NT], const WPool& wp, uint32_t wH, uint32_t wL, uint32_t wN, const h8* xh, const h8* xl, int lane) {
+    constexpr int R = PD + 1;
+    h8 ah[R][MT], alo[R][MT], an[R][MT], bh[2][NT], bl[2][NT];
+    const int boff = (lane >> 5) * TP + (lane & 31);
+    const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int r = 0; r < PD; ++r)
+#pragma unroll
+        for (int m = 0; m < MT; ++m) { ah[r][m] = wp.ld(wH + (m * KB + r) * 1024); alo[r][m] = wp.ld(wL + (m * KB + r) * 1024); an[r][m] = wp.ld(wN + (m * KB + r) * 1024); }
+#pragma unroll
+    for (int n = 0; n < NT; ++n) { bh[0][n] = xh[boff + 32 * n]; bl[0][n] = xl[boff + 32 * n]; }
+#pragma unroll
+    for (int k = 0; k < KB; ++k) {
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            const int kk = k + PD < KB ? k + PD : KB - 1;
+            ah[(k + PD) % R][m] = wp.ld(wH + (m * KB + kk) * 1024);
+            alo[(k + PD) % R][m] = wp.ld(wL + (m * KB + kk) * 1024);
+            an[(k + PD) % R][m] = wp.ld(wN + (m * KB + kk) * 1024);
+        }
+        const int kn = k + 1 < KB ? k + 1 : k;
+#pragma unroll
+        for (int n = 0; n < NT; ++n) { bh[(k + 1) & 1][n] = xh[boff + kn * 2 * TP + 32 * n]; bl[(k + 1) & 1][n] = xl[boff + kn * 2 * TP + 32 * n]; }
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int n = 0; n < NT; ++n) am[m][n] = MFMA16(ah[k % R][m], bh[k & 1][n], k == 0 ? zero : am[m][n]);
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int n = 0; n < NT; ++n) am[m][n] = MFMA16(an[k % R][m], bl[k & 1][n], am[m][n]);
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int n = 0; n < NT; ++n) am[m][n] = MFMA16(alo[k % R][m], bh[k & 1][n], am[m][n]);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+// the finish work of schedule Z: as `finish`, the gate contraction on one accumulator as well (third gate-weight image at GWN), no merges
+template <int NB>
+__device__ __forceinline__ void finish1(const f32x16 (&p)[NB], f32x16 (&st)[NB], const WPool& wp, uint32_t GW, uint32_t GWN, char* XH,
+                                        char* XL, float* PG, int slot, int lane, float pre, float neg) {
+    const int half = lane >> 5, l31 = lane & 31;
+    const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    f32x16 act[NB], gm = zero;
+    h8 gwh[NB][2], gwl[NB][2], gwn[NB][2];
+#pragma unroll
+    for (int b = 0; b < NB; ++b)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            gwh[b][j] = wp.ld(GW + ((slot * NB + b) * 2 + j) * 1024); gwl[b][j] = wp.ld(GW + (32 + (slot * NB + b) * 2 + j) * 1024);
+            gwn[b][j] = wp.ld(GWN + ((slot * NB + b) * 2 + j) * 1024);
+        }
+#pragma unroll
+    for (int b = 0; b < NB; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float x = p[b][r];
+            act[b][r] = x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x));
+        }
+#pragma unroll
+    for (int b = 0; b < NB; ++b)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            h8 bh, bl;
+#pragma unroll
+            for (int s = 0; s < 8; s += 2) {
+                h2 hi, lo;
+                split16x2(act[b][8 * j + s], act[b][8 * j + s + 1], hi, lo, pre, neg);
+                bh[s] = hi[0]; bh[s + 1] = hi[1]; bl[s] = lo[0]; bl[s + 1] = lo[1];
+            }
+            asm("s_nop 1" : "+v"(bh), "+v"(bl));
+            gm = MFMA16(gwh[b][j], bh, gm);
+            gm = MFMA16(gwn[b][j], bl, gm);
+            gm = MFMA16(gwl[b][j], bh, gm);
+        }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        v4f v;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = gm[4 * t + i];
+        *(v4f*)(PG + (((slot & 3) * 64 + l31) * 32 + 4 * ((2 * t + half) ^ (l31 & 7)))) = v;
+    }
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) st[b][r] += act[b][r];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            h4 vh, vl;
+#pragma unroll
+            for (int t = 0; t < 4; t += 2) {
+                h2 hi, lo;
+                split16x2(st[b][4 * q + t], st[b][4 * q + t + 1], hi, lo, pre, neg);
+                vh[t] = hi[0]; vh[t + 1] = hi[1]; vl[t] = lo[0]; vl[t + 1] = lo[1];
+            }
+            const int off = ((4 * (slot & 3) + q) * TP + 32 * b + l31) * 16 + 8 * half;
+            *(h4*)(XH + off) = vh;
+            *(h4*)(XL + off) = vl;
+        }
+    }
+}
+
 // finish work on NV = 2 blocks of 16 accumulator values: SiLU, gate contraction, residual add, state images
 template <int NB>
 __device__ __forceinline__ void finish(const f32x16 (&p)[NB], f32x16 (&st)[NB], const WPool& wp, uint32_t GW, char* XH,
@@ -275,12 +382,13 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
     __syncthreads();
     WPool wp;
-    wp.rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<h8*>(W), 0, (2 * 8 * (KB + 4) + 64) * 1024, 0x00020000);
+    wp.rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<h8*>(W), 0, (3 * 8 * (KB + 4) + 96) * 1024, 0x00020000);
     wp.voff = (uint32_t)lane * 16u;
     const uint32_t wH = 0, wL = 8 * (KB + 4) * 1024;     // [8 M-tiles][KB][64] hi, then lo'
     const h8* xh = (const h8*)XH;
     const h8* xl = (const h8*)XL;
     const uint32_t GW = 2 * 8 * (KB + 4) * 1024;
+    [[maybe_unused]] const uint32_t wN = GW + 64 * 1024, GWN = wN + 8 * (KB + 4) * 1024;      // schedule Z: natural-scale W_hi images (GEMM, gate)
     f32x16 st[2], p[2];
     for (int b = 0; b < 2; ++b)
         for (int r = 0; r < 16; ++r) { st[b][r] = 0.1f * r; p[b][r] = 0.01f * (lane + r); }
@@ -295,6 +403,13 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 for (int r = 0; r < 16; ++r) p[b][r] = am[0][b][r] + al[0][b][r] * inv;
             __syncthreads();
             finish<2>(p, st, wp, GW, YH, YL, PG, wave, lane, pre, neg, inv);
+            __syncthreads();
+        } else if (VAR == 20) {                         // Z: lockstep on ONE accumulator per N-tile (third weight image, no merges)
+            f32x16 am[1][2];
+            gemm1<1, 2>(am, wp, wH + (uint32_t)wave * KB * 1024, wL + (uint32_t)wave * KB * 1024, wN + (uint32_t)wave * KB * 1024, xh, xl, lane);
+            p[0] = am[0][0]; p[1] = am[0][1];
+            __syncthreads();
+            finish1<2>(p, st, wp, GW, GWN, YH, YL, PG, wave, lane, pre, neg);
             __syncthreads();
         } else if (VAR == 11 || VAR == 12) {
             // M (round 6): M-TILE de-phasing of the two waves of a SIMD.  Every wave keeps the kernel's tile (its M-tile x both N-tiles: nothing is streamed twice), but
@@ -920,7 +1035,7 @@ void run(const char* name, int blocks) {
     const int n = 300;
     float* out; unsigned long long* ticks; h8* W;
     (void)hipMalloc(&out, 4 * 512 * blocks); (void)hipMalloc(&ticks, 8 * 8 * blocks);
-    const size_t wbytes = (size_t)(2 * 8 * (KB + 4) + 64) * 64 * 16;
+    const size_t wbytes = (size_t)(3 * 8 * (KB + 4) + 96) * 64 * 16;
     (void)hipMalloc(&W, wbytes); (void)hipMemset(W, 0x11, wbytes);       // every f16 = 0x1111 = 1.3e-4: finite data, the state stays bounded
     const size_t lds = (2 * 36 + 2 * 16) * TP * 16 + 4 * 64 * 32 * 4;
     (void)hipFuncSetAttribute((const void*)kb<VAR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -938,6 +1053,15 @@ void run(const char* name, int blocks) {
 }
 
 int main(int argc, char** argv) {
+    if (argc > 1 && argv[1][0] == 'Z') {       // round 6: one accumulator per N-tile (third weight image), lockstep
+        for (int rep = 0; rep < 3; ++rep) {
+            run<0>("L lockstep (8 waves GEMM, then finish)", 256);
+            run<20>("Z lockstep, ONE accumulator (3 weight images, no merge)", 256);
+        }
+        run<0>("L lockstep, one workgroup", 1);
+        run<20>("Z, one workgroup", 1);
+        return 0;
+    }
     if (argc > 1 && argv[1][0] == 'M') {       // round 6: M-tile de-phasing of the two waves of a SIMD (8 waves, the kernel's own tile per wave)
         for (int rep = 0; rep < 2; ++rep) {
             run<0>("L lockstep (8 waves GEMM, then finish)", 256);
