@@ -466,6 +466,17 @@ __device__ __forceinline__ void tile_gemm_x3z(f32x16 (&am)[MT][NT], f32x16 (&al)
             for (int n = 0; n < NT; ++n) { bh[(r + 1) & 1][n] = sh[(r + 1) * 2 * TP + n * 32]; bl[(r + 1) & 1][n] = sl[(r + 1) * 2 * TP + n * 32]; }
         };
         auto mfmas = [&] {
+#if !defined(GCDM_X3_MFMA_ORDER) || GCDM_X3_MFMA_ORDER >= 1
+            if constexpr (MT == 1 && NT == 2) {      // the block's six products in the order of tile_gemm_x3s (round 6: al0 al1 am0 al0 al1 am1; same bits)
+                al[0][0] = MFMA16(ring.ah[r % R][0], bl[r & 1][0], (ZAL && r == 0) ? zero : al[0][0]);
+                al[0][1] = MFMA16(ring.ah[r % R][0], bl[r & 1][1], (ZAL && r == 0) ? zero : al[0][1]);
+                am[0][0] = MFMA16(ring.ah[r % R][0], bh[r & 1][0], (ZAM && r == 0) ? zero : am[0][0]);
+                al[0][0] = MFMA16(ring.alo[r % R][0], bh[r & 1][0], al[0][0]);
+                al[0][1] = MFMA16(ring.alo[r % R][0], bh[r & 1][1], al[0][1]);
+                am[0][1] = MFMA16(ring.ah[r % R][0], bh[r & 1][1], (ZAM && r == 0) ? zero : am[0][1]);
+                return;
+            }
+#endif
 #pragma unroll
             for (int m = 0; m < MT; ++m)
 #pragma unroll
@@ -965,6 +976,22 @@ __device__ __forceinline__ void tile_gemm_x3s(f32x16 (&am)[MT][NT], f32x16 (&al)
 #endif
         };
         auto mfmas = [&] {
+#if (!defined(GCDM_X3_MFMA_ORDER) || GCDM_X3_MFMA_ORDER >= 1) && !defined(GCDM_ABL_MFMA1)
+            // Round 6: the block's six products in the order al0 al1 am0 al0 al1 am1 -- the two visits of an `al` accumulator three MFMAs apart instead of two
+            // (am0 am1 al0 al1 al0 al1 before; -DGCDM_X3_MFMA_ORDER=0).  Every accumulator still sees its products in the same order: same bits; with msg0's GEMM
+            // (tile_gemm_x3z) in the same order QM9 59 110 -> 58 975 cycles per tile of the fused form (-0.25 %; -0.4 % on a second box), GEOM 58 075 -> 57 845 (-0.4 %)
+            // (profiles/r06_ab_log.txt run 13).  The same reorder in the gate contraction costs +0.6 % and stays out; the two other orders with every distance >= 3
+            // (am0 al0 al1 am1 al0 al1; al0 am0 al1 al0 am1 al1) are +0.1 / +0.2 % at QM9 (the second -0.3 % at GEOM).
+            if constexpr (MT == 1 && NT == 2) {
+                al[0][0] = MFMA16(ring.ah[r % R][0], bl[r & 1][0], r == 0 ? zero : al[0][0]);
+                al[0][1] = MFMA16(ring.ah[r % R][0], bl[r & 1][1], r == 0 ? zero : al[0][1]);
+                am[0][0] = MFMA16(ring.ah[r % R][0], bh[r & 1][0], r == 0 ? zero : am[0][0]);
+                al[0][0] = MFMA16(ring.alo[r % R][0], bh[r & 1][0], al[0][0]);
+                al[0][1] = MFMA16(ring.alo[r % R][0], bh[r & 1][1], al[0][1]);
+                am[0][1] = MFMA16(ring.ah[r % R][0], bh[r & 1][1], r == 0 ? zero : am[0][1]);
+                return;
+            }
+#endif
 #pragma unroll
             for (int m = 0; m < MT; ++m)
 #pragma unroll
