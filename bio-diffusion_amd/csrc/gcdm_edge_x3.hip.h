@@ -431,7 +431,7 @@ __device__ __forceinline__ void x3_tail_skew(f32x16 (&am)[1][2], f32x16 (&al)[1]
     __builtin_amdgcn_sched_barrier(0);
 }
 
-template <int MT, int NT, int PD, int KB, bool ZAM, bool ZAL, class Tail = NoTail>
+template <int MT, int NT, int PD, int KB, bool ZAM, bool ZAL, bool RO, class Tail = NoTail>
 __device__ __forceinline__ void tile_gemm_x3z(f32x16 (&am)[MT][NT], f32x16 (&al)[MT][NT], X3Ring<MT, PD>& ring, const WPool& wp, uint32_t wH,
                                               uint32_t wL, const h8* xh8, const h8* xl8, int TP, int lane, Tail&& tail = NoTail{}) {
     constexpr bool SKEW = !std::is_same<std::decay_t<Tail>, NoTail>::value && NT == 2 && MT == 1 && KB >= 3;
@@ -467,7 +467,7 @@ __device__ __forceinline__ void tile_gemm_x3z(f32x16 (&am)[MT][NT], f32x16 (&al)
         };
         auto mfmas = [&] {
 #if !defined(GCDM_X3_MFMA_ORDER) || GCDM_X3_MFMA_ORDER >= 1
-            if constexpr (MT == 1 && NT == 2) {      // the block's six products in the order of tile_gemm_x3s (round 6: al0 al1 am0 al0 al1 am1; same bits)
+            if constexpr (RO && MT == 1 && NT == 2) {      // the block's six products in the order of tile_gemm_x3s (round 6: al0 al1 am0 al0 al1 am1; same bits)
                 al[0][0] = MFMA16(ring.ah[r % R][0], bl[r & 1][0], (ZAL && r == 0) ? zero : al[0][0]);
                 al[0][1] = MFMA16(ring.ah[r % R][0], bl[r & 1][1], (ZAL && r == 0) ? zero : al[0][1]);
                 am[0][0] = MFMA16(ring.ah[r % R][0], bh[r & 1][0], (ZAM && r == 0) ? zero : am[0][0]);
@@ -940,7 +940,7 @@ struct VecStage {
 
 // Scalar GEMM of a residual GCP2 with the vector stages in its shadow: k-blocks [0, SPLIT) carry hook(stage r) between their MFMAs
 // (vector waves; the others pass a no-op), then a workgroup barrier (the extended-K rows are complete), then k-blocks [SPLIT, KB).
-template <int MT, int NT, int PD, int KB, int SPLIT, bool HOOKED, class Hook, class Tail = NoTail>
+template <int MT, int NT, int PD, int KB, int SPLIT, bool HOOKED, bool RO, class Hook, class Tail = NoTail>
 __device__ __forceinline__ void tile_gemm_x3s(f32x16 (&am)[MT][NT], f32x16 (&al)[MT][NT], X3Ring<MT, PD>& ring, const WPool& wp, uint32_t wH,
                                               uint32_t wL, const h8* xh8, const h8* xl8, int TP, int lane, Hook&& hook, Tail&& tail = NoTail{}) {
     constexpr int R = PD + 1;
@@ -981,8 +981,10 @@ __device__ __forceinline__ void tile_gemm_x3s(f32x16 (&am)[MT][NT], f32x16 (&al)
             // (am0 am1 al0 al1 al0 al1 before; -DGCDM_X3_MFMA_ORDER=0).  Every accumulator still sees its products in the same order: same bits; with msg0's GEMM
             // (tile_gemm_x3z) in the same order QM9 59 110 -> 58 975 cycles per tile of the fused form (-0.25 %; -0.4 % on a second box), GEOM 58 075 -> 57 845 (-0.4 %)
             // (profiles/r06_ab_log.txt run 13).  The same reorder in the gate contraction costs +0.6 % and stays out; the two other orders with every distance >= 3
-            // (am0 al0 al1 am1 al0 al1; al0 am0 al1 al0 am1 al1) are +0.1 / +0.2 % at QM9 (the second -0.3 % at GEOM).
-            if constexpr (MT == 1 && NT == 2) {
+            // (am0 al0 al1 am1 al0 al1; al0 am0 al1 al0 am1 al1) are +0.1 / +0.2 % at QM9 (the second -0.3 % at GEOM).  RO: which instantiations take the new order (X3_RO in
+            // the kernel) -- the two-launch form of the 8-channel edge width is 0.3 % FASTER in the old one (57 150 against 57 325 cycles), its fused form and both forms of the
+            // 16-channel width in the new one (58 755 -> 58 490 two-launch QM9).
+            if constexpr (RO && MT == 1 && NT == 2) {
                 al[0][0] = MFMA16(ring.ah[r % R][0], bl[r & 1][0], r == 0 ? zero : al[0][0]);
                 al[0][1] = MFMA16(ring.ah[r % R][0], bl[r & 1][1], r == 0 ? zero : al[0][1]);
                 am[0][0] = MFMA16(ring.ah[r % R][0], bh[r & 1][0], r == 0 ? zero : am[0][0]);
@@ -1113,6 +1115,7 @@ __global__ __launch_bounds__(ET * 8) __attribute__((amdgpu_waves_per_eu(2, 2))) 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     using Geo = EdgeGeo<ET>;
     constexpr int ETP = Geo::TP, EK_THREADS = Geo::THREADS, PARTS = Geo::PARTS;
+    constexpr bool X3_RO = VE == 16 || TR::ON;             // MFMA order inside a k-block of the tile GEMMs (tile_gemm_x3s): measured per instantiation
     constexpr int X3_GROUPS8 = 36;                      // 32 state + 1 norm + 2 frame scalars + 1 pad (K' = 288)
     char* XH = smem + Geo::OFF_XS;                      // [36][65] x 16 B : hi images
     char* XL = XH + X3_GROUPS8 * ETP * 16;              // [36][65] x 16 B : lo' images
@@ -1556,11 +1559,11 @@ __global__ __launch_bounds__(ET * 8) __attribute__((amdgpu_waves_per_eu(2, 2))) 
         STAMP(3);
         constexpr int SILU0_N0 = (NT == 2 && MT == 1) ? 1 : 0;       // N-tile 0's SiLU rides in the GEMM's tail (x3_tail_skew)
         if constexpr (SILU0_N0) {
-            tile_gemm_x3z<MT, NT, PD, KB0C, false, true>(am, al2, ring, wp, o0H, o0L, xh8, xl8, ETP, lane, [&]() {
+            tile_gemm_x3z<MT, NT, PD, KB0C, false, true, X3_RO>(am, al2, ring, wp, o0H, o0L, xh8, xl8, ETP, lane, [&]() {
                 silu_merge16<X3_PKG>(st[0][0], am[0][0], al2[0][0], X3_INV_SCALE);
             });
         } else {
-            tile_gemm_x3z<MT, NT, PD, KB0C, false, true>(am, al2, ring, wp, o0H, o0L, xh8, xl8, ETP, lane);
+            tile_gemm_x3z<MT, NT, PD, KB0C, false, true, X3_RO>(am, al2, ring, wp, o0H, o0L, xh8, xl8, ETP, lane);
         }
         x3_prefetch_b<MT, PD>(ring, wp, wp.off(ax.wH[0] + (size_t)mt0 * 18 * 64), wp.off(ax.wL[0] + (size_t)mt0 * 18 * 64), 18);
         GateW<MT> gw0;
@@ -1614,16 +1617,16 @@ __global__ __launch_bounds__(ET * 8) __attribute__((amdgpu_waves_per_eu(2, 2))) 
 #ifdef GCDM_ABL_VECFMA       // (timing ablation: the hooked stages replaced by the same number of INDEPENDENT fp32 FMAs -- is it the instruction count or the stages' dependency structure?)
             AblFmaFill fx_;
             for (int i = 0; i < 24; ++i) fx_.x[i] = 0.001f * (lane + i);
-            tile_gemm_x3s<MT, NT, PD, 18, 16, true>(am, al2, ring, wp, gwH, gwL, xh8, xl8, ETP, lane, [&](auto) { fx_.run(); }, silu_n0);
+            tile_gemm_x3s<MT, NT, PD, 18, 16, true, X3_RO>(am, al2, ring, wp, gwH, gwL, xh8, xl8, ETP, lane, [&](auto) { fx_.run(); }, silu_n0);
             amax = fmaxf(amax, fx_.x[0] * 1e-30f + fx_.x[23] * 1e-30f);
 #elif defined(GCDM_ABL_VECNONE)
-            tile_gemm_x3s<MT, NT, PD, 18, 16, true>(am, al2, ring, wp, gwH, gwL, xh8, xl8, ETP, lane, [&](auto) {}, silu_n0);
+            tile_gemm_x3s<MT, NT, PD, 18, 16, true, X3_RO>(am, al2, ring, wp, gwH, gwL, xh8, xl8, ETP, lane, [&](auto) {}, silu_n0);
 #else
-            tile_gemm_x3s<MT, NT, PD, 18, 16, true>(am, al2, ring, wp, gwH, gwL, xh8, xl8, ETP, lane, [&](auto rc) { vs.template run<decltype(rc)::value>(); }, silu_n0);
+            tile_gemm_x3s<MT, NT, PD, 18, 16, true, X3_RO>(am, al2, ring, wp, gwH, gwL, xh8, xl8, ETP, lane, [&](auto rc) { vs.template run<decltype(rc)::value>(); }, silu_n0);
 #endif
             amax = fmaxf(amax, vs.amax);
         } else {
-            tile_gemm_x3s<MT, NT, PD, 18, 16, false>(am, al2, ring, wp, gwH, gwL, xh8, xl8, ETP, lane, [](auto) {}, silu_n0);
+            tile_gemm_x3s<MT, NT, PD, 18, 16, false, X3_RO>(am, al2, ring, wp, gwH, gwL, xh8, xl8, ETP, lane, [](auto) {}, silu_n0);
         }
         if (k < 2) x3_prefetch_b<MT, PD>(ring, wp, wp.off(ax.wH[k < 2 ? k + 1 : 2] + (size_t)mt0 * 18 * 64), wp.off(ax.wL[k < 2 ? k + 1 : 2] + (size_t)mt0 * 18 * 64), 18);
         GateW<MT> gwk;
