@@ -15,9 +15,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
 
 
-def main():
+def build_step():
     import synth
-    steps = int(sys.argv[1]) if len(sys.argv) > 1 else 10
     pkg = importlib.import_module("bio-diffusion_amd")
     dev = torch.device("cuda", 0)
     d = synth.DATASET_DIMS["qm9"]
@@ -50,6 +49,12 @@ def main():
         terms = ddpm(tb)
         (terms[1] + terms[3] + terms[4]).mean().backward()
 
+    return once, dev
+
+
+def main():
+    steps = int(sys.argv[1]) if len(sys.argv) > 1 else 10
+    once, dev = build_step()
     for _ in range(3):
         once()
     torch.cuda.synchronize(dev)
