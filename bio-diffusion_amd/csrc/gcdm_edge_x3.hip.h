@@ -431,7 +431,7 @@ __device__ __forceinline__ void x3_tail_skew(f32x16 (&am)[1][2], f32x16 (&al)[1]
     __builtin_amdgcn_sched_barrier(0);
 }
 
-template <int MT, int NT, int PD, int KB, bool ZAM, bool ZAL, bool RO, class Tail = NoTail>
+template <int MT, int NT, int PD, int KB, bool ZAM, bool ZAL, int RO, class Tail = NoTail>
 __device__ __forceinline__ void tile_gemm_x3z(f32x16 (&am)[MT][NT], f32x16 (&al)[MT][NT], X3Ring<MT, PD>& ring, const WPool& wp, uint32_t wH,
                                               uint32_t wL, const h8* xh8, const h8* xl8, int TP, int lane, Tail&& tail = NoTail{}) {
     constexpr bool SKEW = !std::is_same<std::decay_t<Tail>, NoTail>::value && NT == 2 && MT == 1 && KB >= 3;
@@ -467,7 +467,7 @@ __device__ __forceinline__ void tile_gemm_x3z(f32x16 (&am)[MT][NT], f32x16 (&al)
         };
         auto mfmas = [&] {
 #if !defined(GCDM_X3_MFMA_ORDER) || GCDM_X3_MFMA_ORDER >= 1
-            if constexpr (RO && MT == 1 && NT == 2) {      // the block's six products in the order of tile_gemm_x3s (round 6: al0 al1 am0 al0 al1 am1; same bits)
+            if constexpr (RO >= 1 && MT == 1 && NT == 2) {      // the block's six products in the order of tile_gemm_x3s (round 6: al0 al1 am0 al0 al1 am1; same bits)
                 al[0][0] = MFMA16(ring.ah[r % R][0], bl[r & 1][0], (ZAL && r == 0) ? zero : al[0][0]);
                 al[0][1] = MFMA16(ring.ah[r % R][0], bl[r & 1][1], (ZAL && r == 0) ? zero : al[0][1]);
                 am[0][0] = MFMA16(ring.ah[r % R][0], bh[r & 1][0], (ZAM && r == 0) ? zero : am[0][0]);
@@ -940,7 +940,7 @@ struct VecStage {
 
 // Scalar GEMM of a residual GCP2 with the vector stages in its shadow: k-blocks [0, SPLIT) carry hook(stage r) between their MFMAs
 // (vector waves; the others pass a no-op), then a workgroup barrier (the extended-K rows are complete), then k-blocks [SPLIT, KB).
-template <int MT, int NT, int PD, int KB, int SPLIT, bool HOOKED, bool RO, class Hook, class Tail = NoTail>
+template <int MT, int NT, int PD, int KB, int SPLIT, bool HOOKED, int RO, class Hook, class Tail = NoTail>
 __device__ __forceinline__ void tile_gemm_x3s(f32x16 (&am)[MT][NT], f32x16 (&al)[MT][NT], X3Ring<MT, PD>& ring, const WPool& wp, uint32_t wH,
                                               uint32_t wL, const h8* xh8, const h8* xl8, int TP, int lane, Hook&& hook, Tail&& tail = NoTail{}) {
     constexpr int R = PD + 1;
@@ -983,14 +983,30 @@ __device__ __forceinline__ void tile_gemm_x3s(f32x16 (&am)[MT][NT], f32x16 (&al)
             // (profiles/r06_ab_log.txt run 13).  The same reorder in the gate contraction costs +0.6 % and stays out; the two other orders with every distance >= 3
             // (am0 al0 al1 am1 al0 al1; al0 am0 al1 al0 am1 al1) are +0.1 / +0.2 % at QM9 (the second -0.3 % at GEOM).  RO: which instantiations take the new order (X3_RO in
             // the kernel) -- the two-launch form of the 8-channel edge width is 0.3 % FASTER in the old one (57 150 against 57 325 cycles), its fused form and both forms of the
-            // 16-channel width in the new one (58 755 -> 58 490 two-launch QM9).
-            if constexpr (RO && MT == 1 && NT == 2) {
+            // 16-channel width in the new one (58 755 -> 58 490 two-launch QM9); its fused form is another 0.3 % faster in the third order (RO = 3).
+            if constexpr (RO == 1 && MT == 1 && NT == 2) {
                 al[0][0] = MFMA16(ring.ah[r % R][0], bl[r & 1][0], r == 0 ? zero : al[0][0]);
                 al[0][1] = MFMA16(ring.ah[r % R][0], bl[r & 1][1], r == 0 ? zero : al[0][1]);
                 am[0][0] = MFMA16(ring.ah[r % R][0], bh[r & 1][0], r == 0 ? zero : am[0][0]);
                 al[0][0] = MFMA16(ring.alo[r % R][0], bh[r & 1][0], al[0][0]);
                 al[0][1] = MFMA16(ring.alo[r % R][0], bh[r & 1][1], al[0][1]);
                 am[0][1] = MFMA16(ring.ah[r % R][0], bh[r & 1][1], r == 0 ? zero : am[0][1]);
+                return;
+            } else if constexpr (RO == 2 && MT == 1 && NT == 2) {      // am0 al0 al1 am1 al0 al1
+                am[0][0] = MFMA16(ring.ah[r % R][0], bh[r & 1][0], r == 0 ? zero : am[0][0]);
+                al[0][0] = MFMA16(ring.ah[r % R][0], bl[r & 1][0], r == 0 ? zero : al[0][0]);
+                al[0][1] = MFMA16(ring.ah[r % R][0], bl[r & 1][1], r == 0 ? zero : al[0][1]);
+                am[0][1] = MFMA16(ring.ah[r % R][0], bh[r & 1][1], r == 0 ? zero : am[0][1]);
+                al[0][0] = MFMA16(ring.alo[r % R][0], bh[r & 1][0], al[0][0]);
+                al[0][1] = MFMA16(ring.alo[r % R][0], bh[r & 1][1], al[0][1]);
+                return;
+            } else if constexpr (RO == 3 && MT == 1 && NT == 2) {      // al0 am0 al1 al0 am1 al1
+                al[0][0] = MFMA16(ring.ah[r % R][0], bl[r & 1][0], r == 0 ? zero : al[0][0]);
+                am[0][0] = MFMA16(ring.ah[r % R][0], bh[r & 1][0], r == 0 ? zero : am[0][0]);
+                al[0][1] = MFMA16(ring.ah[r % R][0], bl[r & 1][1], r == 0 ? zero : al[0][1]);
+                al[0][0] = MFMA16(ring.alo[r % R][0], bh[r & 1][0], al[0][0]);
+                am[0][1] = MFMA16(ring.ah[r % R][0], bh[r & 1][1], r == 0 ? zero : am[0][1]);
+                al[0][1] = MFMA16(ring.alo[r % R][0], bh[r & 1][1], al[0][1]);
                 return;
             }
 #endif
@@ -1115,7 +1131,9 @@ __global__ __launch_bounds__(ET * 8) __attribute__((amdgpu_waves_per_eu(2, 2))) 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     using Geo = EdgeGeo<ET>;
     constexpr int ETP = Geo::TP, EK_THREADS = Geo::THREADS, PARTS = Geo::PARTS;
-    constexpr bool X3_RO = VE == 16 || TR::ON;             // MFMA order inside a k-block of the tile GEMMs (tile_gemm_x3s): measured per instantiation
+    // MFMA order inside a k-block of the tile GEMMs (tile_gemm_x3s: 0 = am0 am1 al0 al1 al0 al1, 1 = al0 al1 am0 al0 al1 am1, 3 = al0 am0 al1 al0 am1 al1), measured per
+    // instantiation: 16-channel edge width 1 in both forms; 8-channel: two-launch form 0 (57 130 cycles; 1: 57 325, 2: 57 250, 3: 57 220), fused form 3 (57 690; 1: 57 880, 0: 58 030)
+    constexpr int X3_RO = VE == 16 ? 1 : (TR::ON ? 3 : 0);
     constexpr int X3_GROUPS8 = 36;                      // 32 state + 1 norm + 2 frame scalars + 1 pad (K' = 288)
     char* XH = smem + Geo::OFF_XS;                      // [36][65] x 16 B : hi images
     char* XL = XH + X3_GROUPS8 * ETP * 16;              // [36][65] x 16 B : lo' images
