@@ -986,6 +986,50 @@ def test_teacher_forced_sampler_steps(case):
             assert zc.cpu()[bi == b, :3].sum(0).abs().max().item() < 1e-4 * scale
 
 
+@pytest.mark.parametrize("shift", [0.0, 0.75])
+def test_final_decode_cog_drift_flag_and_reprojection(shift):
+    """sample_p_xh_given_z0 + the whole-batch CoG re-projection of mol_gen_sample (variational_diffusion.py:840-907, 1389-1402) through gcdm_sample_final, whose k_sample
+    launch also does the network's last stage since round 6: a z_0 whose centroid is off in ONE molecule raises GCDM flag 4 (and nothing else) and comes back with every molecule
+    re-centred, exactly as the oracle decides; a centred z_0 raises nothing and is left alone.  Discrete outputs identical."""
+    net, W, cfgs = _net("qm9", seed=47, scale=0.25)
+    ocfg = _ocfg("qm9")
+    ddpm = pkg.EquivariantVariationalDiffusion(net, cfgs["diffusion_cfg"], cfgs["dataloader_cfg"], pkg.dataset_info("qm9")).cuda()
+    dev = torch.device("cuda")
+    dyn, lib, h = ddpm._native(dev)
+    nn_ = torch.tensor([5, 19, 8])
+    B = len(nn_)
+    bi = O.num_nodes_to_batch_index(nn_)
+    N, F = len(bi), ocfg.num_node_scalar_features
+    mask = torch.ones(N, dtype=torch.bool)
+    gam = O.gamma_table(ocfg)
+    dyn.plan(nn_)
+    assert lib.gcdm_set_option(h, b"cog_fix", 1) == 0
+    z = torch.randn((N, 3 + F), generator=torch.Generator().manual_seed(9)) * 0.3
+    z[:, :3] = O.centralize(z[:, :3], bi, B, mask)
+    z[bi == 1, 0] += shift                                    # molecule 1 drifts along x
+    x, one_hot, charges = O.sample_p_xh_given_z0(W, ocfg, gam, z, bi, B, mask, None, O.TapeNoise(77))
+    cog = torch.zeros(B, 3).index_add_(0, bi, x).abs().max().item()
+    assert (cog > 5e-2) == (shift > 0)
+    if cog > 5e-2:
+        x = O.centralize(x, bi, B, mask)
+    raw = _raw_noise(77, N, F).to(dev)
+    zc, out = z.to(dev).contiguous(), torch.empty((N, 3 + F), device=dev)
+    flags = torch.zeros(1, dtype=torch.int32, device=dev)
+    st = lib.gcdm_sample_final(h, C.c_void_p(zc.data_ptr()), None, C.c_void_p(raw.data_ptr()), C.c_uint64(0), C.c_void_p(out.data_ptr()), C.c_void_p(flags.data_ptr()),
+                               C.c_void_p(torch.cuda.current_stream().cuda_stream))
+    assert st == 0, lib.gcdm_last_error(h)
+    torch.cuda.synchronize()
+    out = out.cpu()
+    assert int(flags.item()) == (pkg._native.FLAG_COG_DRIFT if shift > 0 else 0)
+    scale = max(1.0, x.abs().max().item())
+    assert (out[:, :3] - x).abs().max().item() <= TOL * scale
+    assert torch.equal(out[:, 3:3 + ocfg.num_atom_types], one_hot.float())
+    if ocfg.include_charges:
+        assert torch.equal(out[:, -1:], charges.float())
+    if shift > 0:                                             # EVERY molecule re-centred, not only the one that drifted
+        assert torch.zeros(B, 3).index_add_(0, bi, out[:, :3]).abs().max().item() < 1e-4 * scale
+
+
 @pytest.mark.parametrize("case", ["qm9", "geom"])
 def test_free_running_sampling_short(case):
     """mol_gen_sample (init + T' steps + final decode) on the same noise tape as the oracle: continuous outputs within the
