@@ -986,6 +986,66 @@ def test_teacher_forced_sampler_steps(case):
             assert zc.cpu()[bi == b, :3].sum(0).abs().max().item() < 1e-4 * scale
 
 
+def test_nan_velocity_is_zeroed_for_the_whole_batch_in_forward_and_in_a_sampler_step():
+    """gcpnet.py:1212-1220: a NaN anywhere in vel zeroes vel for the WHOLE batch (the reference warns and carries on).  A model whose last position update has one NaN weight
+    -- only vel sees it -- through gcdm_forward (k_finish) and through gcdm_sample_step, whose k_sample launch does k_finish's work since round 6: eps_x = 0 for every node,
+    the feature columns as the oracle has them, GCDM flag 1 raised in both.  Exact fp32 MFMA mode (the split-precision mode answers a non-finite value with its range flag and
+    the fp32 re-run, which is this path)."""
+    d = _dims("qm9")
+    cfgs = pkg.default_cfgs("qm9", ())
+    W = synth.make_weights(synth.dynamics_shapes(d["S"], d["V"], d["Se"], d["Ve"], d["L"], synth.dims_h_in(d)), seed=53, scale_2d=0.25)
+    W["interaction_layers.8.node_position_update_gcp.vector_up.weight"][0, 0] = float("nan")
+    net = pkg.GCPNetDynamics(**cfgs)
+    net.load_state_dict(W)
+    net = net.cuda().eval()
+    ocfg = _ocfg("qm9")
+    ddpm = pkg.EquivariantVariationalDiffusion(net, cfgs["diffusion_cfg"], cfgs["dataloader_cfg"], pkg.dataset_info("qm9")).cuda()
+    dev = torch.device("cuda")
+    dyn, lib, h = ddpm._native(dev)
+    dyn.set_mfma_mode(0)
+    nn_ = torch.tensor([6, 19, 9])
+    B = len(nn_)
+    bi = O.num_nodes_to_batch_index(nn_)
+    N, F = len(bi), ocfg.num_node_scalar_features
+    mask = torch.ones(N, dtype=torch.bool)
+    gam = O.gamma_table(ocfg)
+    dyn.plan(nn_)
+    stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    z = torch.randn((N, 3 + F), generator=torch.Generator().manual_seed(5))
+    z[:, :3] = O.centralize(z[:, :3], bi, B, mask)
+    s = 600
+    t = torch.full((N, 1), (s + 1) / 1000)
+    want_eps = O.dynamics_forward(W, ocfg, z, t, bi, mask, None)
+    assert torch.equal(want_eps[:, :3], torch.zeros(N, 3)) and bool(torch.isfinite(want_eps).all())
+    # (a) the network by itself
+    zc, tc, out = z.to(dev).contiguous(), t.to(dev).reshape(-1).contiguous(), torch.empty((N, 3 + F), device=dev)
+    flags = torch.zeros(1, dtype=torch.int32, device=dev)
+    assert lib.gcdm_forward(h, C.c_void_p(zc.data_ptr()), C.c_void_p(tc.data_ptr()), None, C.c_void_p(out.data_ptr()), C.c_void_p(flags.data_ptr()), stream) == 0, lib.gcdm_last_error(h)
+    torch.cuda.synchronize()
+    assert int(flags.item()) == pkg._native.FLAG_NAN_VEL
+    assert torch.equal(out[:, :3].cpu(), torch.zeros(N, 3))
+    assert (out[:, 3:].cpu() - want_eps[:, 3:]).abs().max().item() <= TOL * max(1.0, want_eps.abs().max().item())
+    # (b) one ancestral step: direct launches (noise tape) and the captured step graph (Philox noise: compared with the direct Philox step, bitwise)
+    want, _ = O.sample_p_zs_given_zt(W, ocfg, gam, s / 1000, (s + 1) / 1000, z, bi, B, mask, None, O.TapeNoise(11))
+    raw = _raw_noise(11, N, F).to(dev)
+    z1 = z.to(dev).contiguous()
+    flags.zero_()
+    assert lib.gcdm_sample_step(h, C.c_void_p(z1.data_ptr()), None, s, 1000, C.c_void_p(raw.data_ptr()), C.c_uint64(0), C.c_void_p(flags.data_ptr()), stream) == 0, lib.gcdm_last_error(h)
+    torch.cuda.synchronize()
+    assert int(flags.item()) == pkg._native.FLAG_NAN_VEL
+    assert (z1.cpu() - want).abs().max().item() <= TOL * max(1.0, want.abs().max().item())
+    res = []
+    for graph in (1, 0):
+        assert lib.gcdm_set_option(h, b"step_graph", graph) == 0
+        z2 = z.to(dev).contiguous()
+        flags.zero_()
+        assert lib.gcdm_sample_step(h, C.c_void_p(z2.data_ptr()), None, s, 1000, None, C.c_uint64(123), C.c_void_p(flags.data_ptr()), stream) == 0, lib.gcdm_last_error(h)
+        torch.cuda.synchronize()
+        assert int(flags.item()) == pkg._native.FLAG_NAN_VEL
+        res.append(z2.cpu())
+    assert torch.equal(res[0], res[1]) and bool(torch.isfinite(res[0]).all())
+
+
 @pytest.mark.parametrize("shift", [0.0, 0.75])
 def test_final_decode_cog_drift_flag_and_reprojection(shift):
     """sample_p_xh_given_z0 + the whole-batch CoG re-projection of mol_gen_sample (variational_diffusion.py:840-907, 1389-1402) through gcdm_sample_final, whose k_sample
